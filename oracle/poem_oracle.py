@@ -1,0 +1,421 @@
+"""CPU oracle for the POEM-v2 point-embedded decoder hot path.  TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+
+A from-scratch fp32 restatement (torch CPU tensors, loop-free where the reference loops) of
+``POEM_Generalized_Head.forward`` + ``PtEmbedTRv4`` exactly as the upstream reference computes them.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+file; the product (``poem-v2_amd/``) never does and fails loudly without its HIP library.
+
+Parity status: PINNED for everything expressed in torch + BERT blocks -- checked against golden vectors
+captured from the imported reference itself (``tests/golden/make_golden.py`` ->
+``tests/golden/*.npz``; test: ``tests/test_oracle_golden.py``).  UNPINNED (third-party code absent from
+/root/reference, no upstream tests): pytorch3d ``knn_points`` tie order, the pytorch3d rot6d->axis-angle
+chain and manotorch MANO LBS of the ``medium_MANO`` tail (restated from their published algorithms).
+
+Every function cites the reference lines it follows (paths relative to the reference root).
+Weights are passed as a flat dict keyed by the reference's own ``state_dict`` names relative to the head
+(e.g. ``transformer.pt_metro_encoder.0.encoder.attn.self.query.weight``).
+"""
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class PathConfig:
+    """Hyper-parameters of the path (config/release/train_*.yaml:185-225)."""
+    embed: int = 256          # EMBED_DIMS = POINTS_FEAT_DIM = INPUT_FEAT_DIM
+    in_channels: int = 160    # IN_CHANNELS
+    nsample: int = 4096       # N_SAMPLE (rows of assets/bps.npy)
+    nquery: int = 799         # hard-coded 799 in the reference
+    heads: int = 4            # NUM_ATTENTION_HEADS
+    nblocks: int = 3          # N_BLOCKS
+    knn: int = 32             # N_NEIGHBOR = N_NEIGHBOR_QUERY
+    radius: float = 0.1       # RADIUS_SAMPLE
+    parametric: bool = False  # TRANSFORMER.PARAMETRIC_OUTPUT
+    center_idx: int = 9       # TRANSFORMER_CENTER_IDX
+    ln_eps: float = 1e-12     # BertConfig.layer_norm_eps default
+
+
+def linear(x, w, b=None):
+    return F.linear(x, w, b)
+
+
+# ----------------------------------------------------------------------------------------------------
+# positional encoding  (lib/models/layers/petr_transformer.py:434-469, ptEmb_head.py:853-860)
+# ----------------------------------------------------------------------------------------------------
+def sine_pe_3d(n_views, H, W, num_feats, temperature=10000.0, scale=2 * math.pi, eps=1e-6):
+    """SinePositionalEncoding3D on an all-valid mask of shape (1,N,H,W) -> (N, 3*num_feats, H, W).
+
+    Per axis the num_feats channels are [sin(even dims) || cos(odd dims)] *concatenated* (the
+    ``torch.stack(dim=4)`` there acts on a 5-D tensor), axis order (n, y, x)."""
+    ones = torch.ones(1, n_views, H, W, dtype=torch.float32)
+    n_e = ones.cumsum(1)
+    y_e = ones.cumsum(2)
+    x_e = ones.cumsum(3)
+    n_e = n_e / (n_e[:, -1:] + eps) * scale
+    y_e = y_e / (y_e[:, :, -1:] + eps) * scale
+    x_e = x_e / (x_e[:, :, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_feats)
+
+    def enc(e):
+        p = e[..., None] / dim_t
+        return torch.cat((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1)
+
+    pos = torch.cat((enc(n_e), enc(y_e), enc(x_e)), dim=4).permute(0, 1, 4, 2, 3)
+    return pos[0]
+
+
+def positional_table(w, n_views, H, W, embed):
+    """adapt_pos3d(sine PE) for a sample with n_views views -> (N, C, H, W) (ptEmb_head.py:857-858)."""
+    pe = sine_pe_3d(n_views, H, W, embed // 2)
+    return F.conv2d(pe, w["adapt_pos3d.weight"], w["adapt_pos3d.bias"])
+
+
+# ----------------------------------------------------------------------------------------------------
+# projection + sampling  (lib/utils/collation.py:48-65, lib/utils/transform.py:898-930,
+#                         ptEmb_head.py:873-883,900-901)
+# ----------------------------------------------------------------------------------------------------
+def project_points(points_world, cam_intr, cam_extr, view_sample, eps=1e-7):
+    """points_world (B,S,3), cam_intr (BN,3,3), cam_extr (BN,4,4) camera->master, view_sample (BN,) sample id
+    of each view -> pixel uv (BN,S,2).  T = inv(extr); p = R p + t; q = K p; z[|z|<eps]=eps; uv = q_xy / z."""
+    T = torch.linalg.inv(cam_extr)
+    p = points_world[view_sample]                                         # (BN,S,3)
+    pc = (T[:, :3, :3] @ p.transpose(1, 2)).transpose(1, 2) + T[:, None, :3, 3]
+    q = (cam_intr @ pc.transpose(1, 2)).transpose(1, 2)
+    xy = q[..., 0:2]
+    z = q[..., 2:].clone()
+    z[torch.abs(z) < eps] = eps
+    return xy / z
+
+
+def grid_sample_bilinear(x, grid):
+    """Explicit restatement of ``F.grid_sample(x, grid[:, :, None], mode=bilinear, padding_mode=zeros,
+    align_corners=False)``.  x (BN,C,H,W), grid (BN,S,2) in [-1,1] (x then y) -> (BN,C,S)."""
+    BN, C, H, W = x.shape
+    ix = ((grid[..., 0] + 1) * W - 1) / 2
+    iy = ((grid[..., 1] + 1) * H - 1) / 2
+    ix0 = torch.floor(ix)
+    iy0 = torch.floor(iy)
+    ix1 = ix0 + 1
+    iy1 = iy0 + 1
+    w_nw = (ix1 - ix) * (iy1 - iy)
+    w_ne = (ix - ix0) * (iy1 - iy)
+    w_sw = (ix1 - ix) * (iy - iy0)
+    w_se = (ix - ix0) * (iy - iy0)
+    xf = x.reshape(BN, C, H * W)
+
+    def tap(xi, yi, wt):
+        ok = (xi >= 0) & (xi <= W - 1) & (yi >= 0) & (yi <= H - 1)
+        lin = (yi.clamp(0, H - 1) * W + xi.clamp(0, W - 1)).long()
+        v = torch.gather(xf, 2, lin[:, None, :].expand(-1, C, -1))
+        return v * (wt * ok)[:, None, :]
+
+    return tap(ix0, iy0, w_nw) + tap(ix1, iy0, w_ne) + tap(ix0, iy1, w_sw) + tap(ix1, iy1, w_se)
+
+
+def q1_rows(g_sample):
+    """QUIRK Q1 (ptEmb_head.py:914-915): the per-sample (N,C,S) block is *reinterpreted* (``.view``) as
+    (S,N,C): q[s,n,c] = flat[(s*N+n)*C + c]."""
+    N, C, S = g_sample.shape
+    return g_sample.reshape(-1).view(S, N, C)
+
+
+def merge_mlp0(w, q):
+    h = F.relu(linear(q, w["merge_net_feature.0.0.weight"], w["merge_net_feature.0.0.bias"]))
+    return linear(h, w["merge_net_feature.0.2.weight"], w["merge_net_feature.0.2.bias"])
+
+
+def merge_mlp1(w, m):
+    h = F.relu(linear(m, w["merge_net_feature.1.0.weight"], w["merge_net_feature.1.0.bias"]))
+    return linear(h, w["merge_net_feature.1.2.weight"], w["merge_net_feature.1.2.bias"])
+
+
+def merge_views(w, q):
+    """q (S,N,C) -> (S,C).  N>1: merge_features_mv (ptEmb_head.py:745-762); N==1: merge_features_sv (:764-771)."""
+    S, N, C = q.shape
+    if N == 1:
+        q0 = q[:, 0]
+        return q0 + merge_mlp1(w, merge_mlp0(w, q0))
+    q1 = q[:, 0]
+    h = merge_mlp0(w, q)                                   # (S,N,C/2)
+    master, others = h[:, 0], h[:, 1:]
+    wts = torch.matmul(others, master.unsqueeze(-1))       # (S,N-1,1)  no softmax
+    m = torch.matmul(others.transpose(1, 2), wts).squeeze(-1)
+    return q1 + merge_mlp1(w, m) / N
+
+
+# ----------------------------------------------------------------------------------------------------
+# decoder blocks  (lib/models/bricks/pt_metro_transformer.py, point_transformers.py)
+# ----------------------------------------------------------------------------------------------------
+def layer_norm(x, g, b, eps):
+    return F.layer_norm(x, (x.shape[-1],), g, b, eps)
+
+
+def bert_cross_attention(w, pre, hidden, enc, heads, eps):
+    """transformers-v4 BertAttention with encoder_hidden_states (pt_metro_transformer.py:57-74):
+    Q from hidden, K/V from enc; softmax(QK^T/sqrt(dh)) V; LN(dense(ctx) + hidden).  No mask (v4 replaces the
+    mask by encoder_attention_mask=None when cross-attending)."""
+    B, Q, C = hidden.shape
+    dh = C // heads
+
+    def split(x):
+        return x.view(B, -1, heads, dh).permute(0, 2, 1, 3)
+
+    q = split(linear(hidden, w[pre + "self.query.weight"], w[pre + "self.query.bias"]))
+    k = split(linear(enc, w[pre + "self.key.weight"], w[pre + "self.key.bias"]))
+    v = split(linear(enc, w[pre + "self.value.weight"], w[pre + "self.value.bias"]))
+    scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)
+    probs = torch.softmax(scores, dim=-1)
+    ctx = torch.matmul(probs, v).permute(0, 2, 1, 3).reshape(B, Q, C)
+    out = linear(ctx, w[pre + "output.dense.weight"], w[pre + "output.dense.bias"])
+    return layer_norm(out + hidden, w[pre + "output.LayerNorm.weight"], w[pre + "output.LayerNorm.bias"], eps)
+
+
+def knn_indices(query_xyz, src_xyz, K):
+    """pytorch3d.ops.knn_points semantics (call sites point_transformers.py:83,134): squared L2
+    ((dx*dx + dy*dy) + dz*dz, fp32, no matmul expansion), K smallest sorted ascending.  Ties: lower index
+    first (upstream: implementation-defined -> unpinned)."""
+    d = query_xyz[:, :, None, :] - src_xyz[:, None, :, :]
+    d = d * d
+    dist = (d[..., 0] + d[..., 1]) + d[..., 2]
+    # stable sort => lower index first among equal distances
+    order = torch.sort(dist, dim=-1, stable=True).indices[..., :K]
+    return order
+
+
+def index_points(points, idx):
+    """lib/utils/points_utils.py:9-20."""
+    B = idx.shape[0]
+    flat = idx.reshape(B, -1)
+    res = torch.gather(points, 1, flat[..., None].expand(-1, -1, points.size(-1)))
+    return res.reshape(*idx.shape, -1)
+
+
+def _vec_attn_core(w, pre, q, k, v, delta_xyz, C):
+    pos = linear(F.relu(linear(delta_xyz, w[pre + "fc_delta.0.weight"], w[pre + "fc_delta.0.bias"])),
+                 w[pre + "fc_delta.2.weight"], w[pre + "fc_delta.2.bias"])
+    a = linear(F.relu(linear(q[:, :, None] - k + pos, w[pre + "fc_gamma.0.weight"], w[pre + "fc_gamma.0.bias"])),
+               w[pre + "fc_gamma.2.weight"], w[pre + "fc_gamma.2.bias"])
+    a = torch.softmax(a / np.sqrt(C), dim=-2)
+    return torch.einsum("bmnf,bmnf->bmf", a, v + pos)
+
+
+def vec_attn_self(w, pre, xyz, feats, idx, nxyz):
+    """ptTransformerBlock._forward (point_transformers.py:70-96)."""
+    C = feats.shape[-1]
+    x = linear(feats, w[pre + "fc1.weight"], w[pre + "fc1.bias"])
+    q = linear(x, w[pre + "w_qs.weight"])
+    k = index_points(linear(x, w[pre + "w_ks.weight"]), idx)
+    v = index_points(linear(x, w[pre + "w_vs.weight"]), idx)
+    res = _vec_attn_core(w, pre, q, k, v, xyz[:, :, None] - nxyz, C)
+    return linear(res, w[pre + "fc2.weight"], w[pre + "fc2.bias"]) + feats
+
+
+def vec_attn_cross(w, pre, query_xyz, query_f, pt_feats, idx, nxyz, hoist=False):
+    """ptTransformerBlock_CrossAttn._forward (point_transformers.py:125-156).  ``hoist`` applies
+    fc1/w_ks/w_vs to the source rows before gathering (same per-row arithmetic, 6x fewer rows)."""
+    C = query_f.shape[-1]
+    q = linear(query_f, w[pre + "w_qs.weight"])
+    if hoist:
+        x = linear(pt_feats, w[pre + "fc1.weight"], w[pre + "fc1.bias"])
+        k = index_points(linear(x, w[pre + "w_ks.weight"]), idx)
+        v = index_points(linear(x, w[pre + "w_vs.weight"]), idx)
+    else:
+        x = linear(index_points(pt_feats, idx), w[pre + "fc1.weight"], w[pre + "fc1.bias"])
+        k = linear(x, w[pre + "w_ks.weight"])
+        v = linear(x, w[pre + "w_vs.weight"])
+    res = _vec_attn_core(w, pre, q, k, v, query_xyz[:, :, None] - nxyz, C)
+    return linear(res, w[pre + "fc2.weight"], w[pre + "fc2.bias"]) + query_f
+
+
+def gather_xyz(src_xyz, idx):
+    B, Q, K = idx.shape
+    return torch.gather(src_xyz[:, None].expand(-1, Q, -1, -1), 2, idx[..., None].expand(-1, -1, -1, 3))
+
+
+def rotation_6d_to_matrix(d6):
+    """pytorch3d.transforms.rotation_6d_to_matrix (published algorithm; parity unpinned)."""
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = F.normalize(a1, dim=-1)
+    b2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = F.normalize(b2, dim=-1)
+    b3 = torch.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-2)
+
+
+def matrix_to_quaternion(R):
+    """pytorch3d 0.7.x matrix_to_quaternion (published algorithm; parity unpinned).  (w,x,y,z)."""
+    m00, m01, m02 = R[..., 0, 0], R[..., 0, 1], R[..., 0, 2]
+    m10, m11, m12 = R[..., 1, 0], R[..., 1, 1], R[..., 1, 2]
+    m20, m21, m22 = R[..., 2, 0], R[..., 2, 1], R[..., 2, 2]
+    q_abs = torch.sqrt(torch.clamp(torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22,
+                                                1 - m00 + m11 - m22, 1 - m00 - m11 + m22], dim=-1), min=0))
+    cand = torch.stack([
+        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
+        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
+        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
+        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
+    cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
+    best = q_abs.argmax(dim=-1)
+    return torch.gather(cand, -2, best[..., None, None].expand(*best.shape, 1, 4)).squeeze(-2)
+
+
+def quaternion_to_axis_angle(quat):
+    """pytorch3d quaternion_to_axis_angle (published algorithm; parity unpinned)."""
+    norms = torch.norm(quat[..., 1:], p=2, dim=-1, keepdim=True)
+    half = torch.atan2(norms, quat[..., :1])
+    ang = 2 * half
+    small = ang.abs() < 1e-6
+    s = torch.where(small, 0.5 - ang * ang / 48, torch.sin(half) / torch.where(small, torch.ones_like(ang), ang))
+    return quat[..., 1:] / s
+
+
+def matrix_to_axis_angle(R):
+    return quaternion_to_axis_angle(matrix_to_quaternion(R))
+
+
+def parametric_tail(w, pre, feats, xyz, mano_fn, C):
+    """get_parametric_output (pt_metro_transformer.py:139-151).  QUIRK Q3: (B,799,C).reshape(-1,799).
+    ``mano_fn(pose_aa (B,48), betas (B,10)) -> (verts (B,778,3), joints (B,21,3))`` is an input of the path
+    (manotorch + MANO assets are absent)."""
+    rows = feats.reshape(-1, 799)
+    flat = linear(rows, w[pre + "flat_verts.weight"], w[pre + "flat_verts.bias"]).reshape(-1, C)
+    par = linear(flat, w[pre + "mano_linear.weight"], w[pre + "mano_linear.bias"])
+    pose6d, betas = par[:, :96], par[:, 96:]
+    pose_aa = matrix_to_axis_angle(rotation_6d_to_matrix(pose6d.view(-1, 16, 6))).view(-1, 48)
+    verts, joints = mano_fn(pose_aa, betas)
+    xyz = xyz.clone()
+    xyz[:, 21:] = verts
+    xyz[:, :21] = joints
+    return xyz, pose_aa, betas
+
+
+def decoder_block(w, cfg, i, query_xyz, query_feats, pt_xyz, pt_feats, consts, hoist=False, taps=None, mano_fn=None):
+    """point_METRO_block.forward (pt_metro_transformer.py:153-200) for block i."""
+    p = f"transformer.pt_metro_encoder.{i}."
+    C = cfg.embed
+    B, Q = query_feats.shape[:2]
+    qe = linear(query_feats, w[p + "embedding.weight"], w[p + "embedding.bias"])
+    ke = linear(pt_feats, w[p + "embedding.weight"], w[p + "embedding.bias"])
+    h = bert_cross_attention(w, p + "encoder.attn.", qe, ke, cfg.heads, cfg.ln_eps)
+    h = bert_cross_attention(w, p + "encoder.cross_attn.", h, ke, cfg.heads, cfg.ln_eps)
+    if i == 0:
+        # QUIRK Q2 (point_transformers.py:10-32,71-79,129-132): fixed anchors for both attentions
+        idx_s = consts["anchor_idx"].view(1, 1, -1).expand(B, Q, -1)
+        nxyz_s = consts["anchor"].view(1, 1, -1, 3).expand(B, Q, -1, -1)
+        idx_c, nxyz_c = idx_s, nxyz_s
+    else:
+        idx_s = knn_indices(query_xyz, query_xyz, cfg.knn)
+        nxyz_s = gather_xyz(query_xyz, idx_s)
+        idx_c = knn_indices(query_xyz, pt_xyz, cfg.knn)
+        nxyz_c = gather_xyz(pt_xyz, idx_c)
+    vp = p + "encoder.vec_attn."
+    f_self = vec_attn_self(w, vp + "query_self_attn.", query_xyz, h, idx_s, nxyz_s)
+    f_cross = vec_attn_cross(w, vp + "query_cross_attn.", query_xyz, f_self, ke, idx_c, nxyz_c, hoist=hoist)
+    r = F.relu(linear(f_cross, w[vp + "reg_branch.0.weight"], w[vp + "reg_branch.0.bias"]))
+    new_xyz = linear(r, w[vp + "reg_branch.2.weight"], w[vp + "reg_branch.2.bias"]) + query_xyz
+    inter = F.gelu(linear(f_cross, w[p + "encoder.intermediate.dense.weight"], w[p + "encoder.intermediate.dense.bias"]))
+    out = linear(inter, w[p + "encoder.output.dense.weight"], w[p + "encoder.output.dense.bias"])
+    feats = layer_norm(out + f_cross, w[p + "encoder.output.LayerNorm.weight"], w[p + "encoder.output.LayerNorm.bias"],
+                       cfg.ln_eps)
+    pose = shape = None
+    xyz_pre_tail = new_xyz
+    if cfg.parametric and i == cfg.nblocks - 1:
+        new_xyz, pose, shape = parametric_tail(w, p, feats, new_xyz, mano_fn, C)
+    if taps is not None:
+        taps[f"b{i}.h_cross"] = h
+        taps[f"b{i}.idx_self"] = idx_s
+        taps[f"b{i}.idx_cross"] = idx_c
+        taps[f"b{i}.f_self"] = f_self
+        taps[f"b{i}.f_cross"] = f_cross
+        taps[f"b{i}.xyz"] = xyz_pre_tail
+        taps[f"b{i}.feats"] = feats
+    return feats, new_xyz, pose, shape
+
+
+def head_forward(w, cfg, consts, mlvl_feat, cam_intr, cam_extr, cam_view_num, reference_joints,
+                 inp_img_shape=(256, 256), hoist=False, taps=None, mano_fn=None):
+    """POEM_Generalized_Head.forward (ptEmb_head.py:825-964).
+
+    consts: dict(bps (S,3), anchor (32,3), anchor_idx (32,) int64, template (799,3) metres).
+    Returns all_coords_preds (nblocks,B,799,3) [, pred_pose (B,16,3), pred_shape (B,10)]."""
+    C, S = cfg.embed, cfg.nsample
+    views = [int(v) for v in cam_view_num]
+    B = len(views)
+    BN = mlvl_feat.shape[0]
+    assert sum(views) == BN
+    H, W = mlvl_feat.shape[-2:]
+    inp_w, inp_h = inp_img_shape   # the reference's (swapped) naming, ptEmb_head.py:831
+    x = F.conv2d(mlvl_feat, w["input_proj.weight"], w["input_proj.bias"])                      # :835
+    pe = torch.cat([positional_table(w, n, H, W, C) for n in views], dim=0)                      # :853-860
+    x = x + pe                                                                                   # :870
+    centre = reference_joints[:, 9, :]                                                           # :873 (always joint 9)
+    bps_world = consts["bps"][None] + centre[:, None, :]                                         # :874,790-809
+    view_sample = torch.repeat_interleave(torch.arange(B), torch.tensor(views))
+    uv = project_points(bps_world, cam_intr, cam_extr, view_sample)                              # :878
+    inp_res = torch.tensor([inp_w, inp_h], dtype=torch.float32)
+    grid = uv * (1.0 / inp_res) * 2 - 1                                                          # :880-883
+    g = grid_sample_bilinear(x, grid)                                                            # :900-901 (BN,C,S)
+    offs = np.concatenate([[0], np.cumsum(views)])
+    bps_feat = torch.stack([merge_views(w, q1_rows(g[offs[i]:offs[i + 1]])) for i in range(B)])  # :910-926
+    query_feat = w["query_feat_embedding.weight"][None].expand(B, -1, -1)                        # :930-931
+    ref_pts = centre[:, None, :] + consts["template"][None]                                      # :893-894
+    pt_xyz = (bps_world - centre[:, None, :]) / cfg.radius                                       # :934
+    query_xyz = (ref_pts - centre[:, None, :]) / cfg.radius                                      # :935
+    if taps is not None:
+        taps.update(x=x, uv=uv, g=g, bps_feat=bps_feat, pt_xyz=pt_xyz, query_xyz=query_xyz)
+    feats, xyz = query_feat, query_xyz
+    stack = []
+    pose = shape = None
+    for i in range(cfg.nblocks):                                                                 # ptEmb_transformer.py:115-121
+        feats, xyz, pose, shape = decoder_block(w, cfg, i, xyz, feats, pt_xyz, bps_feat, consts, hoist, taps, mano_fn)
+        stack.append(xyz)
+    out = torch.nan_to_num(torch.stack(stack))                                                   # :944
+    c = centre[None, :, None, :]
+    if not cfg.parametric:
+        out = out * cfg.radius + c                                                               # :949-951
+    else:
+        out = torch.cat([out[:-1] * cfg.radius + c, out[-1:] + c])                               # :953-958
+    res = {"all_coords_preds": out}
+    if cfg.parametric:
+        res["pred_pose"] = pose.reshape(-1, 16, 3)
+        res["pred_shape"] = shape.reshape(-1, 10)
+    return res
+
+
+def synthetic_template(seed=1234):
+    """Seeded synthetic (799,3) hand template in metres (rows 0..20 joints, 21..798 verts), centred at joint 9.
+    Stands in for ManoLayer(zero pose, zero betas, center_idx=9) (ptEmb_head.py:732-736,886-892): MANO assets are
+    licence-gated and absent, so the template is an INPUT of the path fed identically to every implementation."""
+    g = torch.Generator().manual_seed(seed)
+    t = (torch.rand(799, 3, generator=g) * 2 - 1) * 0.08
+    return t - t[9:10]
+
+
+def toy_mano(template, center_idx):
+    """Deterministic stand-in for manotorch ManoLayer(pose_aa, betas) used ONLY to exercise the Q3 plumbing of the
+    medium_MANO tail in tests (identity at zero pose/betas).  Not a MANO implementation."""
+    def fn(pose, betas):
+        B = pose.shape[0]
+        joints = template[:21][None].repeat(B, 1, 1)
+        verts = template[21:][None].repeat(B, 1, 1)
+        s = 1.0 + 0.01 * betas.sum(-1).view(B, 1, 1)
+        off = 0.001 * pose.view(B, -1).sum(-1).view(B, 1, 1)
+        joints = joints * s + off
+        verts = verts * s + off
+        if center_idx is not None:
+            c = joints[:, center_idx:center_idx + 1].clone()
+            joints = joints - c
+            verts = verts - c
+        return verts, joints
+    return fn
+
+
+def mean_epe(pred, gt):
+    """MeanEPE.feed (lib/metrics/mean_epe.py:23-33): returns (sum over batch of per-sample mean L2, batch)."""
+    d = torch.norm(pred - gt, p="fro", dim=2).mean(dim=1)
+    return float(d.sum()), int(d.shape[0])

@@ -1,0 +1,61 @@
+"""Synthetic multi-view inputs of the path's boundary: backbone feature maps, pinhole
+intrinsics, camera->master extrinsics on a ring around the hand, triangulated reference joints.  Seeded and
+generated on CPU so that the oracle, the HIP path and the bench see identical numbers.
+
+Layout follows the reference's batch contract (lib/utils/collation.py:7-25): per-view tensors are concatenated
+over samples -> (BN, ...) with ``cam_view_num`` = views per sample; view 0 of every sample is the master whose
+extrinsic is the identity (lib/data_wds/multiview_wds.py:97-126)."""
+import math
+
+import numpy as np
+import torch
+
+
+def ring_extrinsics(n_views, ring=8, hand=(0.0, 0.0, 0.6), jitter=None):
+    """camera->master 4x4 for views 0..n_views-1: camera n sits on a circle around ``hand`` (radius = |hand|) at
+    angle 2*pi*n/ring about the y axis and looks at the hand; view 0 is the identity."""
+    hand = torch.tensor(hand, dtype=torch.float64)
+    out = torch.eye(4, dtype=torch.float64).repeat(n_views, 1, 1)
+    for n in range(n_views):
+        th = 2 * math.pi * n / ring
+        if jitter is not None and n > 0:
+            th = th + float(jitter[n])
+        R = torch.tensor([[math.cos(th), 0, math.sin(th)], [0, 1, 0], [-math.sin(th), 0, math.cos(th)]],
+                         dtype=torch.float64)
+        out[n, :3, :3] = R
+        out[n, :3, 3] = hand - R @ hand
+    return out.float()
+
+
+def synthetic_batch(views, seed=0, in_channels=160, feat_hw=16, img=256, ring=None):
+    """views: list of views per sample.  Returns the arguments of ``POEM_Generalized_Head.forward``."""
+    g = torch.Generator().manual_seed(seed)
+    views = [int(v) for v in views]
+    B, BN = len(views), int(sum(views))
+    ring = ring or max(8, max(views))
+    mlvl_feat = torch.randn(BN, in_channels, feat_hw, feat_hw, generator=g)
+    K = torch.tensor([[300.0, 0, img / 2], [0, 300.0, img / 2], [0, 0, 1]])
+    cam_intr = K[None].repeat(BN, 1, 1).contiguous()
+    extr = []
+    for n in views:
+        jit = 0.05 * torch.randn(n, generator=g)
+        extr.append(ring_extrinsics(n, ring=ring, jitter=jit))
+    cam_extr = torch.cat(extr, 0).contiguous()
+    reference_joints = torch.tensor([0.0, 0.0, 0.6]) + 0.03 * torch.randn(B, 21, 3, generator=g)
+    img_metas = {
+        "inp_img_shape": (img, img),
+        "cam_intr": cam_intr,
+        "cam_extr": cam_extr,
+        "master_id": [0] * B,
+        "cam_view_num": np.asarray(views, dtype=np.int64),
+    }
+    return {"mlvl_feat": mlvl_feat, "img_metas": img_metas, "reference_joints": reference_joints}
+
+
+def synthetic_template(seed=1234):
+    """Seeded synthetic (799,3) zero-pose hand template in metres, centred at joint 9 (rows 0..20 joints, 21..798
+    vertices).  MANO assets are licence-gated (docs/datasets.md:31-38 upstream); on a licensed machine pass the
+    real ManoLayer output instead."""
+    g = torch.Generator().manual_seed(seed)
+    t = (torch.rand(799, 3, generator=g) * 2 - 1) * 0.08
+    return t - t[9:10]

@@ -1,0 +1,178 @@
+"""Generate golden vectors from the upstream reference (run in the build container only):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Imports /root/reference via ref_harness (nothing is copied), fills the reference's own POEM_Generalized_Head with
+the seeded weights of ``poem_v2_amd.weights.seeded_state_dict`` and records inputs-by-seed + outputs (+ stage
+taps) as compressed .npz fixtures.  Cases:
+  tiny      C=32, S=1024 (own bps/anchor assets in a temp cwd), views [1,2,3]: every stage tap, full tensors
+  tinymano  same + PARAMETRIC_OUTPUT (medium_MANO tail, Q3) with the toy MANO stand-in
+  small     release shape C=128, views [2]       (BASELINE config c1)
+  medium    release shape C=256, views [2,8]
+  large     release shape C=512, views [10]
+  mepe      MeanEPE known-answer (lib/metrics/mean_epe.py)
+"""
+import hashlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+
+import ref_harness as rh  # noqa: E402
+import poem_v2_amd as pk  # noqa: E402
+from poem_v2_amd.inputs import synthetic_batch  # noqa: E402
+
+CASES = {
+    "tiny": dict(model="medium", embed=32, nsample=1024, views=[1, 2, 3], seed=11, parametric=False, full=True),
+    "tinymano": dict(model="medium_MANO", embed=32, nsample=1024, views=[2, 1], seed=12, parametric=True, full=True),
+    "small": dict(model="small", embed=128, nsample=4096, views=[2], seed=1, parametric=False, full=False),
+    "medium": dict(model="medium", embed=256, nsample=4096, views=[2, 8], seed=2, parametric=False, full=False),
+    "large": dict(model="large", embed=512, nsample=4096, views=[10], seed=3, parametric=False, full=False),
+}
+
+
+def make_cwd(nsample):
+    """Temp cwd with the asset files the reference reads relative to cwd (ptEmb_head.py:791,
+    point_transformers.py:12-13, ptEmb_transformer.py:334)."""
+    d = tempfile.mkdtemp(prefix="poem_golden_")
+    os.makedirs(os.path.join(d, "assets"))
+    os.makedirs(os.path.join(d, "config", "backbone"))
+    bps = np.load(os.path.join(rh.REF_ROOT, "assets", "bps.npy"))
+    np.save(os.path.join(d, "assets", "bps.npy"), bps[:, :nsample].copy())
+    for f in ("anchor.npy", "anchor_idx.npy"):
+        shutil.copy(os.path.join(rh.REF_ROOT, "assets", f), os.path.join(d, "assets", f))
+    shutil.copy(os.path.join(rh.REF_ROOT, "config/backbone/bert_cfg.json"), os.path.join(d, "config/backbone/bert_cfg.json"))
+    return d
+
+
+def run_case(name, spec):
+    CN, build_head = rh.setup()
+    cfg, y = rh.load_head_cfg(CN, spec["model"])
+    C = spec["embed"]
+    cfg["EMBED_DIMS"] = C
+    cfg["POINTS_FEAT_DIM"] = C
+    cfg["N_SAMPLE"] = spec["nsample"]
+    cfg["TRANSFORMER"]["INPUT_FEAT_DIM"] = C
+    cfg["TRANSFORMER"]["BPS_FEAT_DIM"] = spec["nsample"]
+    cfg["TRANSFORMER"]["PARAMETRIC_OUTPUT"] = spec["parametric"]
+    cfg["POSITIONAL_ENCODING"]["NUM_FEATS"] = C // 2
+    cwd = make_cwd(spec["nsample"])
+    os.chdir(cwd)
+    try:
+        head = build_head(cfg, data_preset=CN(y["DATA_PRESET"]))
+        head.eval()
+        sd = pk.weights.seeded_state_dict(C, seed=spec["seed"], parametric=spec["parametric"])
+        ref_sd = head.state_dict()
+        for k, v in sd.items():
+            assert k in ref_sd and tuple(ref_sd[k].shape) == tuple(v.shape), f"key/shape mismatch: {k}"
+        missing, unexpected = head.load_state_dict(sd, strict=False)
+        assert not unexpected, unexpected
+        batch = synthetic_batch(spec["views"], seed=spec["seed"])
+        taps = {}
+        import lib.models.heads.ptEmb_head as H
+        orig_gs = H.F.grid_sample
+
+        def rec_gs(x, grid, **kw):
+            out = orig_gs(x, grid, **kw)
+            taps["x"] = x.detach().clone()
+            taps["grid"] = grid.detach().clone()
+            taps["g"] = out.detach().squeeze(-1).clone()
+            return out
+
+        H.F.grid_sample = rec_gs
+        hooks = []
+
+        def pre(mod, args, kwargs):
+            taps["bps_feat"] = kwargs["pt_feats"].detach().clone()
+            taps["pt_xyz"] = kwargs["pt_xyz"].detach().clone()
+            taps["query_xyz"] = kwargs["query_xyz"].detach().clone()
+
+        hooks.append(head.transformer.register_forward_pre_hook(pre, with_kwargs=True))
+        for i, blk in enumerate(head.transformer.pt_metro_encoder):
+            def mk(tag, pick=lambda o: o):
+                def hk(mod, inp, out):
+                    taps[tag] = pick(out).detach().clone()
+                return hk
+            hooks.append(blk.encoder.attn.register_forward_hook(mk(f"b{i}.h_attn", lambda o: o[0])))
+            hooks.append(blk.encoder.cross_attn.register_forward_hook(mk(f"b{i}.h_cross", lambda o: o[0])))
+            hooks.append(blk.encoder.vec_attn.query_self_attn.register_forward_hook(mk(f"b{i}.f_self", lambda o: o[0])))
+            hooks.append(blk.encoder.vec_attn.query_cross_attn.register_forward_hook(mk(f"b{i}.f_cross", lambda o: o[0])))
+            hooks.append(blk.encoder.vec_attn.register_forward_hook(mk(f"b{i}.xyz", lambda o: o[1])))
+            hooks.append(blk.encoder.register_forward_hook(mk(f"b{i}.feats", lambda o: o[0])))
+        # the template the reference builds from its (stubbed) ManoLayer
+        with torch.no_grad():
+            out = head(batch["mlvl_feat"], batch["img_metas"], batch["reference_joints"])
+        H.F.grid_sample = orig_gs
+        for h in hooks:
+            h.remove()
+    finally:
+        os.chdir(ROOT)
+        shutil.rmtree(cwd, ignore_errors=True)
+
+    blob = hashlib.sha256()
+    for k, v in sd.items():
+        blob.update(k.encode())
+        blob.update(v.numpy().tobytes())
+    rec = {"all_coords_preds": out["all_coords_preds"].numpy()}
+    if spec["parametric"]:
+        rec["pred_pose"] = out["pred_pose"].numpy()
+        rec["pred_shape"] = out["pred_shape"].numpy()
+    for k, v in taps.items():
+        v = v.numpy()
+        if spec["full"]:
+            # tiny cases: whole tensors for the sampling stage, strided rows for the per-block taps
+            if k.endswith((".h_attn", ".h_cross", ".f_self", ".f_cross", ".feats")):
+                v = v[:, ::9]
+            rec["tap." + k] = v
+        else:
+            # release shapes: keep fixtures small -- strided rows of the big taps
+            if k in ("x", "g", "grid"):
+                continue
+            if k in ("bps_feat", "pt_xyz"):
+                rec["tap." + k] = v[:, ::64]
+            elif k.endswith((".h_attn", ".h_cross", ".f_self", ".f_cross", ".feats")):
+                rec["tap." + k] = v[:, ::47]
+            else:
+                rec["tap." + k] = v
+    meta = dict(case=name, spec=spec, weights_sha256=blob.hexdigest(), torch=torch.__version__,
+                template_seed=1234, note="inputs = poem_v2_amd.inputs.synthetic_batch(views, seed); weights = "
+                "poem_v2_amd.weights.seeded_state_dict(embed, seed, parametric=...)")
+    rec["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, f"{name}.npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e3:.0f} kB), out[-1,0,:2]={out['all_coords_preds'][-1, 0, :2].tolist()}")
+
+
+def run_mepe():
+    rh.setup()
+    from lib.metrics.mean_epe import MeanEPE
+    g = torch.Generator().manual_seed(5)
+    m = MeanEPE(None, "v")
+    pred = torch.randn(4, 778, 3, generator=g) * 0.01
+    gt = torch.randn(4, 778, 3, generator=g) * 0.01
+    s1 = m.feed(pred, gt)
+    s2 = m.feed(pred[:2] * 2, gt[:2])
+    np.savez_compressed(os.path.join(HERE, "mepe.npz"), pred=pred.numpy(), gt=gt.numpy(), sum1=s1, sum2=s2,
+                        avg=m.get_result())
+    print("mepe:", s1, s2, m.get_result())
+    os.chdir(ROOT)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(CASES) + ["mepe"]
+    torch.set_num_threads(8)
+    for n in which:
+        if n == "mepe":
+            run_mepe()
+        else:
+            run_case(n, CASES[n])
