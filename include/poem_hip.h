@@ -1,0 +1,158 @@
+/* poem_hip.h -- C ABI of the MI355X-native POEM-v2 point-embedded decoder (libpoem_hip.so).
+ *
+ * Plain pointers and sizes only; every pointer is a DEVICE pointer unless the name ends in _host.  All entry
+ * points are stream-ordered, allocate nothing, never throw, and return 0 on success or a negative POEM_E_* code.
+ * Tensors are fp32, row-major/contiguous; indices are int32.  hipStream_t is passed as void*.
+ *
+ * What each entry point replaces in the upstream reference (paths relative to the reference root) -- the
+ * reference has no FFI of its own (it is pure Python on torch / pytorch3d / transformers), so these are the
+ * native calls its hot path makes today:
+ *
+ *   poem_gemm                 torch.nn.Linear forward: every Linear of the path
+ *                             (lib/models/bricks/pt_metro_transformer.py:180-181 embedding, :88-91 FFN, :25,38
+ *                             reg_branch; point_transformers.py:49-56,86-87,138-142 fc1/fc2/w_qs/w_ks/w_vs;
+ *                             ptEmb_head.py:701-707 merge_net_feature; BertSelfAttention query/key/value,
+ *                             BertSelfOutput.dense)
+ *   poem_layernorm            BertSelfOutput.LayerNorm / BertOutput.LayerNorm (transformers, call sites
+ *                             pt_metro_transformer.py:57-74,88-91)
+ *   poem_input_proj           nn.Conv2d 1x1 input_proj + positional table add (ptEmb_head.py:835,853-870)
+ *   poem_pe_table             SinePositionalEncoding3D + adapt_pos3d (petr_transformer.py:434-469,
+ *                             ptEmb_head.py:857-858), constant-folded per view count
+ *   poem_project_sample       generate_grid_sample_proj + F.grid_sample (lib/utils/collation.py:48-65,
+ *                             lib/utils/transform.py:898-930, ptEmb_head.py:873-883,900-901)
+ *   poem_merge_reduce /       merge_features_mv / merge_features_sv around the two merge MLPs, on the Q1
+ *   poem_merge_finalize       re-interpreted rows (ptEmb_head.py:745-771,910-926)
+ *   poem_cross_attention      BertSelfAttention scores/softmax/context for encoder_hidden_states
+ *                             (pt_metro_transformer.py:57-72; transformers v4 semantics)
+ *   poem_knn                  pytorch3d.ops.knn_points(K=32) (point_transformers.py:83,134)
+ *   poem_vector_attention     ptTransformerBlock._forward / ptTransformerBlock_CrossAttn._forward from
+ *                             fc_delta to the softmax-weighted sum (point_transformers.py:88-95,144-151)
+ *   poem_reg_update           reg_branch second Linear + xyz residual (pt_metro_transformer.py:38)
+ *   poem_head_forward         POEM_Generalized_Head.forward + PtEmbedTRv4.forward (ptEmb_head.py:825-964,
+ *                             lib/models/layers/ptEmb_transformer.py:371-376)
+ */
+#ifndef POEM_HIP_H
+#define POEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POEM_OK 0
+#define POEM_E_ARG (-1)        /* bad argument (null pointer, unsupported size, misaligned) */
+#define POEM_E_WORKSPACE (-2)  /* workspace too small */
+#define POEM_E_LAUNCH (-3)     /* HIP launch/runtime error (see poem_last_hip_error) */
+#define POEM_E_UNSUPPORTED (-4)
+
+#define POEM_ACT_NONE 0
+#define POEM_ACT_RELU 1
+#define POEM_ACT_GELU 2 /* erf form */
+
+typedef struct poem_config {
+  int32_t embed;       /* C: EMBED_DIMS = POINTS_FEAT_DIM = INPUT_FEAT_DIM (32..1024, multiple of 32) */
+  int32_t in_channels; /* IN_CHANNELS (160), multiple of 8 */
+  int32_t nsample;     /* S: N_SAMPLE (4096); S % C == 0 (Q1 re-interpretation) */
+  int32_t nquery;      /* Q: 799 */
+  int32_t heads;       /* NUM_ATTENTION_HEADS (4) */
+  int32_t nblocks;     /* N_BLOCKS (3) */
+  int32_t knn;         /* N_NEIGHBOR = N_NEIGHBOR_QUERY; must be 32 */
+  int32_t parametric;  /* TRANSFORMER.PARAMETRIC_OUTPUT */
+  int32_t feat_h, feat_w; /* backbone feature map (16x16) */
+  int32_t max_views;   /* largest views-per-sample the positional table is folded for */
+  float radius;        /* RADIUS_SAMPLE (0.1) */
+  float ln_eps;        /* BertConfig.layer_norm_eps (1e-12) */
+} poem_config_t;
+
+typedef struct poem_handle_s* poem_handle_t;
+
+/* ---- library ------------------------------------------------------------------------------------------ */
+int poem_abi_version(void);
+int poem_last_hip_error(void);            /* hipError_t of the last failing runtime call on this thread */
+const char* poem_error_string(int code);
+
+/* ---- weights ------------------------------------------------------------------------------------------- */
+/* Number of raw tensors / their element counts in canonical order (the order of
+ * poem_v2_amd.weights.live_key_shapes == the reference's state_dict order of the live tensors). */
+int poem_num_weight_tensors(const poem_config_t* cfg);
+int64_t poem_weight_tensor_numel(const poem_config_t* cfg, int index);
+/* Bytes of the packed device image (MFMA-fragment order weights + folded tables) the handle keeps. */
+size_t poem_packed_bytes(const poem_config_t* cfg);
+/* raw: host array of `n` device pointers to the raw fp32 tensors in canonical order.
+ * bps (S,3), anchor (32,3) fp32, anchor_idx (32) int32, template_xyz (Q,3) fp32 metres: device pointers.
+ * packed: caller-owned device buffer of poem_packed_bytes(); must outlive the handle. */
+int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, const float* bps, const float* anchor,
+                const int32_t* anchor_idx, const float* template_xyz, void* packed, size_t packed_bytes,
+                void* stream, poem_handle_t* out);
+void poem_destroy(poem_handle_t h);
+
+/* ---- whole path ---------------------------------------------------------------------------------------- */
+size_t poem_workspace_bytes(poem_handle_t h, int batch, int total_views);
+/* view_offsets_host: B+1 prefix sums of views per sample (host memory, the reference's cam_view_num).
+ * cam_extr is camera->master (as in the reference's img_metas["cam_extr"]).
+ * out_xyz: (nblocks, B, Q, 3) metres in the master frame (all_coords_preds).
+ * Parametric configs: out_xyz holds the pre-MANO stack; pose_aa (B,48) and betas (B,10) are written and the caller
+ * finishes with its MANO layer + poem_finalize_parametric. */
+int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_intr, const float* cam_extr,
+                      const int32_t* view_offsets_host, int batch, const float* reference_joints, int img_w,
+                      int img_h, float* out_xyz, float* pose_aa, float* betas, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* Decoder only (PtEmbedTRv4.forward, lib/models/layers/ptEmb_transformer.py:371-376): normalised inputs
+ * query_xyz (B,Q,3), query_feat (B,Q,C), pt_xyz (B,S,3), pt_feats (B,S,C) -> out_xyz_norm (nblocks,B,Q,3). */
+int poem_decoder_forward(poem_handle_t h, const float* query_xyz, const float* query_feat, const float* pt_xyz,
+                         const float* pt_feats, int batch, float* out_xyz_norm, float* pose_aa, float* betas,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int poem_finalize_parametric(poem_handle_t h, const float* mano_verts, const float* mano_joints,
+                             const float* reference_joints, int batch, float* out_xyz, void* stream);
+/* Debug taps: copies of intermediate tensors of the LAST poem_head_forward on this handle (device->device).
+ * name: "x","g","bps_feat","pt_xyz","query_xyz","b<i>.h_cross","b<i>.f_self","b<i>.f_cross","b<i>.xyz",
+ * "b<i>.feats","b<i>.idx_self","b<i>.idx_cross".  Returns number of elements or <0. */
+int64_t poem_tap(poem_handle_t h, const char* name, void* dst, int64_t dst_elems, void* stream);
+int poem_enable_taps(poem_handle_t h, int enable);
+
+/* ---- individual operators (same kernels the whole path launches) ----------------------------------------- */
+size_t poem_packed_linear_bytes(int out_features, int in_features);
+int poem_pack_linear(const float* w, int out_features, int in_features, void* packed, void* stream);
+/* Y[M,N] = act(X[M,K] . W^T + bias) + residual ; ldx/ldr/ldy in floats; bias/residual may be NULL. */
+int poem_gemm(const float* x, int ldx, const void* w_packed, const float* bias, const float* residual, int ldr,
+              float* y, int ldy, int M, int N, int K, int act, void* stream);
+int poem_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int cols, float eps,
+                   void* stream);
+/* table: (sum_{N=1..max_views} N, C, H*W) */
+int poem_pe_table(const void* adapt_w_packed, const float* adapt_b, int embed, int h, int w, int max_views,
+                  float* scratch_sine, float* table, void* stream);
+/* x[v,c,p] = W[c,:] . feat[v,:,p] + b[c] + table[pe_index[v], c, p] */
+int poem_input_proj(const float* feat, const void* w_packed, const float* bias, const float* table,
+                    const int32_t* pe_index, float* x, int views, int in_channels, int embed, int hw, void* stream);
+/* g[v,c,s] = bilinear sample of x[v,c] at the projection of (bps[s] + centre[view_sample[v]]) into view v.
+ * uv_scratch: (views, S, 2) floats (pixel-space sample coordinates ix, iy). */
+int poem_project_sample(const float* x, const float* bps, const float* centre, const int32_t* view_sample,
+                        const float* cam_intr, const float* cam_extr, float* uv_scratch, float* g, int views,
+                        int embed, int fh, int fw, int nsample, int img_w, int img_h, void* stream);
+int poem_merge_reduce(const float* h2, const int32_t* view_offsets, float* m, int batch, int nsample, int half,
+                      void* stream);
+int poem_merge_finalize(const float* g, const float* y, const int32_t* view_offsets, float* out, int batch,
+                        int nsample, int embed, void* stream);
+/* q (B,Q,C) k,v (B,S,C) -> ctx (B,Q,C); softmax(q k^T / sqrt(C/heads)) v per head. */
+int poem_cross_attention(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk,
+                         int embed, int heads, void* stream);
+/* idx (B,Q,32) int32: 32 nearest src points per query, ascending squared L2, ties -> lower index. */
+int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream);
+/* Vector attention core.  q (B,Q,C); k,v (B,NS,C) gathered by idx; idx (B,Q,32) or (32) when shared_idx!=0;
+ * neighbour coordinates: anchor_xyz (32,3) when non-NULL, else src_xyz[b, idx];
+ * wd1 (C,3)+bd1 raw; wd2, wg1, wg2 packed (C,C) + biases.  out r (B,Q,C) = sum_j softmax_j(a/sqrt(C)) * (v_j + pos_j). */
+int poem_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz, const int32_t* idx,
+                          int shared_idx, const float* q, const float* k, const float* v, int nsrc,
+                          const float* wd1, const float* bd1, const void* wd2_packed, const float* bd2,
+                          const void* wg1_packed, const float* bg1, const void* wg2_packed, const float* bg2,
+                          float* out, int batch, int nq, int embed, void* stream);
+/* xyz_out = xyz_in + r . W^T + b   (W (3,C) raw) */
+int poem_reg_update(const float* r, const float* w, const float* b, const float* xyz_in, float* xyz_out, int rows,
+                    int embed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POEM_HIP_H */

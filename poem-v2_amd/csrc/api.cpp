@@ -1,0 +1,648 @@
+// C ABI of libpoem_hip.so (see include/poem_hip.h): handle, weight packing, workspace plan and the launch sequence
+// of the whole POEM_Generalized_Head + PtEmbedTRv4 path.  Host code only; all kernels live in the .hip files.
+#include "../../include/poem_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+// ---- kernel launchers (defined in the .hip translation units) -----------------------------------------------
+extern "C" {
+hipError_t poem_launch_pack_linear(const float* w, int N, int K, void* out, hipStream_t s);
+hipError_t poem_launch_gemm(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
+                            float* Y, int ldy, int M, int N, int K, int act, hipStream_t s);
+hipError_t poem_launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int cols,
+                                 float eps, hipStream_t s);
+hipError_t poem_launch_narrow_linear(const float* x, int ldx, const float* w, const float* b, const float* base,
+                                     float* out, int rows, int K, int N, hipStream_t s);
+hipError_t poem_launch_sine_pe(float* out, int F, int H, int W, int max_views, hipStream_t s);
+hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, const float* bias, const float* table,
+                               const int* pe_index, float* x, int views, int K, int C, int hw, hipStream_t s);
+hipError_t poem_launch_project_sample(const float* x, const float* bps, const float* centre, const int* view_sample,
+                                      const float* intr, const float* extr, float* inv_scratch, float* uv, float* g,
+                                      int views, int C, int fh, int fw, int S, int img_w, int img_h, hipStream_t s);
+hipError_t poem_launch_merge_reduce(const float* h2, const int* offs, float* m, int B, int S, int HALF, hipStream_t s);
+hipError_t poem_launch_merge_finalize(const float* g, const float* y, const int* offs, float* out, int B, int S, int C,
+                                      hipStream_t s);
+hipError_t poem_launch_cross_attention(const float* q, const float* k, const float* v, float* ctx, int B, int NQ, int NK,
+                                       int C, int heads, hipStream_t s);
+hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS, hipStream_t s);
+hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
+                                        const int* idx, int shared_idx, const float* q, const float* k, const float* v,
+                                        int nsrc, const float* wd1, const float* bd1, const void* wd2, const float* bd2,
+                                        const void* wg1, const float* bg1, const void* wg2, const float* bg2, float* out,
+                                        int B, int Q, int C, hipStream_t s);
+hipError_t poem_launch_prep_xyz(const float* ref_joints, const float* bps, const float* tmpl, float* centre,
+                                float* pt_xyz, float* query_xyz, int B, int S, int Q, float radius, hipStream_t s);
+hipError_t poem_launch_broadcast(const float* src, float* dst, long per, int copies, hipStream_t s);
+hipError_t poem_launch_finalize(const float* xyz, const float* centre, float* out, int L, int B, int Q, float radius,
+                                hipStream_t s);
+hipError_t poem_launch_finalize_param(const float* verts, const float* joints, const float* ref_joints, float* out_last,
+                                      int B, int Q, hipStream_t s);
+hipError_t poem_launch_q3_flatten(const float* feats, const float* fw, const float* fb, float* t, int B, int Q, int C,
+                                  hipStream_t s);
+hipError_t poem_launch_rot6d_to_aa(const float* par, float* pose_aa, float* betas, int B, hipStream_t s);
+}
+
+static thread_local int g_last_hip_error = 0;
+
+#define HIPCHK(expr)                                 \
+  do {                                               \
+    hipError_t e_ = (expr);                          \
+    if (e_ != hipSuccess) {                          \
+      g_last_hip_error = (int)e_;                    \
+      return POEM_E_LAUNCH;                          \
+    }                                                \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline size_t packed_bytes_linear(int N, int K) { return (size_t)((N + 31) / 32) * (size_t)(K / 8) * 64 * 16; }
+
+// ---- canonical tensor table (== poem_v2_amd.weights.live_key_shapes order) -----------------------------------
+struct TensorSpec {
+  int rows, cols;  // Linear (out, in); 1-D tensors: rows = n, cols = 1
+  bool pack;
+};
+
+enum {  // head-level slots
+  T_INPROJ_W = 0, T_INPROJ_B, T_ADAPT_W, T_ADAPT_B, T_M00_W, T_M00_B, T_M02_W, T_M02_B, T_M10_W, T_M10_B, T_M12_W,
+  T_M12_B, T_QEMB, T_HEAD_COUNT
+};
+enum {  // per-block slots
+  B_EMB_W = 0, B_EMB_B,
+  B_A1 = 2,    // attn:       +0 q.w +1 q.b +2 k.w +3 k.b +4 v.w +5 v.b +6 o.w +7 o.b +8 ln.w +9 ln.b
+  B_A2 = 12,   // cross_attn: same
+  B_VS = 22,   // query_self_attn: +0 fc1.w +1 fc1.b +2 fc2.w +3 fc2.b +4 d0.w +5 d0.b +6 d2.w +7 d2.b +8 g0.w +9 g0.b
+               //                  +10 g2.w +11 g2.b +12 wq +13 wk +14 wv
+  B_VC = 37,   // query_cross_attn: same
+  B_REG0_W = 52, B_REG0_B, B_REG2_W, B_REG2_B, B_INT_W, B_INT_B, B_OUT_W, B_OUT_B, B_LN_W, B_LN_B,
+  B_COUNT = 62,
+  B_FLAT_W = 62, B_FLAT_B, B_MANO_W, B_MANO_B, B_COUNT_PARAM = 66
+};
+
+static std::vector<TensorSpec> tensor_table(const poem_config_t& c) {
+  const int C = c.embed, Q = c.nquery;
+  std::vector<TensorSpec> t;
+  auto lin = [&](int o, int i, bool pack, bool bias = true) {
+    t.push_back({o, i, pack});
+    if (bias) t.push_back({o, 1, false});
+  };
+  lin(C, c.in_channels, true);
+  lin(C, 3 * C / 2, true);
+  lin(C, C, true);
+  lin(C / 2, C, true);
+  lin(C / 2, C / 2, true);
+  lin(C, C / 2, true);
+  t.push_back({Q, C, false});
+  for (int b = 0; b < c.nblocks; ++b) {
+    lin(C, C, true);
+    for (int a = 0; a < 2; ++a) {
+      lin(C, C, true); lin(C, C, true); lin(C, C, true); lin(C, C, true);
+      t.push_back({C, 1, false}); t.push_back({C, 1, false});
+    }
+    for (int a = 0; a < 2; ++a) {
+      lin(C, C, true); lin(C, C, true);
+      lin(C, 3, false);
+      lin(C, C, true); lin(C, C, true); lin(C, C, true);
+      lin(C, C, true, false); lin(C, C, true, false); lin(C, C, true, false);
+    }
+    lin(C, C, true);
+    lin(3, C, false);
+    lin(4 * C, C, true);
+    lin(C, 4 * C, true);
+    t.push_back({C, 1, false}); t.push_back({C, 1, false});
+    if (c.parametric) {
+      lin(1, Q, false);
+      lin(106, C, false);
+    }
+  }
+  return t;
+}
+
+struct poem_handle_s {
+  poem_config_t cfg;
+  std::vector<TensorSpec> specs;
+  std::vector<const float*> raw;     // caller-owned raw tensors (biases, narrow weights, embedding)
+  std::vector<const void*> packed;   // fragment-order image per tensor (nullptr when not packed)
+  const float* bps = nullptr;
+  const float* anchor = nullptr;
+  const int32_t* anchor_idx = nullptr;
+  const float* tmpl = nullptr;
+  float* pe_table = nullptr;         // (sum N, C, HW)
+  bool taps = false;
+  struct Tap { const void* p; int64_t elems; };
+  std::map<std::string, Tap> tapmap;
+  int block_base(int b) const { return T_HEAD_COUNT + b * (cfg.parametric ? B_COUNT_PARAM : B_COUNT); }
+  const float* R(int idx) const { return raw[idx]; }
+  const void* P(int idx) const { return packed[idx]; }
+};
+
+static int check_config(const poem_config_t* c) {
+  if (!c) return POEM_E_ARG;
+  const int C = c->embed;
+  if (C < 32 || C > 1024 || (C & (C - 1))) return POEM_E_UNSUPPORTED;       // 32,64,...,1024
+  if (c->knn != 32) return POEM_E_UNSUPPORTED;
+  if (c->in_channels % 8 || c->nsample % 32 || c->nsample % C) return POEM_E_UNSUPPORTED;
+  if (c->heads <= 0 || C % c->heads) return POEM_E_UNSUPPORTED;
+  const int dh = C / c->heads;
+  if (!(dh == 8 || dh == 16 || dh == 32 || dh == 64 || dh == 128)) return POEM_E_UNSUPPORTED;
+  if (c->nsample > 4096 || c->nquery > 4096 || c->nquery < 33) return POEM_E_UNSUPPORTED;
+  if ((c->feat_h * c->feat_w) % 32) return POEM_E_UNSUPPORTED;
+  if (c->max_views < 1 || c->max_views > 64 || c->nblocks < 1) return POEM_E_ARG;
+  return POEM_OK;
+}
+
+// ---- workspace plan -------------------------------------------------------------------------------------------------
+namespace {
+struct Arena {
+  char* base;
+  size_t off = 0;
+  explicit Arena(void* b) : base((char*)b) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = align_up(off, 256);
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Plan {
+  // ints
+  int32_t *offs, *view_sample, *pe_index, *idx_self[8], *idx_cross[8];
+  // sampling stage
+  float *x, *uv, *g, *h1, *h2, *mm, *mh, *y, *bps_feat, *centre, *pt_xyz, *xyz[9];
+  // decoder (per call scratch)
+  float *feats0, *qe, *ke, *qp, *kp, *vp, *ctx, *att, *h_attn, *xs, *qs, *ks, *vs, *rs, *qc, *xk, *kc, *vc, *rc, *regh,
+      *ffh, *ffo;
+  // per block kept tensors (taps)
+  float *h_cross[8], *f_self[8], *f_cross[8], *feats[8];
+  float *q3t, *par;
+  size_t bytes;
+};
+
+Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
+  Plan p{};
+  Arena a(base);
+  const size_t C = c.embed, S = c.nsample, Q = c.nquery, HW = (size_t)c.feat_h * c.feat_w;
+  const size_t BS = (size_t)B * S, BQ = (size_t)B * Q, VS = (size_t)BN * S;
+  p.offs = a.take<int32_t>(B + 1);
+  p.view_sample = a.take<int32_t>(BN);
+  p.pe_index = a.take<int32_t>(BN);
+  p.x = a.take<float>((size_t)BN * C * HW);
+  p.uv = a.take<float>(VS * 2 + (size_t)BN * 16);
+  p.g = a.take<float>(VS * C);
+  p.h1 = a.take<float>(VS * C);
+  p.h2 = a.take<float>(VS * C / 2);
+  p.mm = a.take<float>(BS * C / 2);
+  p.mh = a.take<float>(BS * C / 2);
+  p.y = a.take<float>(BS * C);
+  p.bps_feat = a.take<float>(BS * C);
+  p.centre = a.take<float>((size_t)B * 3);
+  p.pt_xyz = a.take<float>(BS * 3);
+  for (int i = 0; i <= c.nblocks; ++i) p.xyz[i] = nullptr;
+  float* xyz_all = a.take<float>((size_t)(c.nblocks + 1) * BQ * 3);   // [0] = initial, [1..] = per-block outputs (contiguous)
+  for (int i = 0; i <= c.nblocks; ++i) p.xyz[i] = xyz_all ? xyz_all + (size_t)i * BQ * 3 : nullptr;
+  p.feats0 = a.take<float>(BQ * C);
+  p.qe = a.take<float>(BQ * C);
+  p.ke = a.take<float>(BS * C);
+  p.qp = a.take<float>(BQ * C);
+  p.kp = a.take<float>(BS * C);
+  p.vp = a.take<float>(BS * C);
+  p.ctx = a.take<float>(BQ * C);
+  p.att = a.take<float>(BQ * C);
+  p.h_attn = a.take<float>(BQ * C);
+  p.xs = a.take<float>(BQ * C);
+  p.qs = a.take<float>(BQ * C);
+  p.ks = a.take<float>(BQ * C);
+  p.vs = a.take<float>(BQ * C);
+  p.rs = a.take<float>(BQ * C);
+  p.qc = a.take<float>(BQ * C);
+  p.xk = a.take<float>(BS * C);
+  p.kc = a.take<float>(BS * C);
+  p.vc = a.take<float>(BS * C);
+  p.rc = a.take<float>(BQ * C);
+  p.regh = a.take<float>(BQ * C);
+  p.ffh = a.take<float>(BQ * C * 4);
+  p.ffo = a.take<float>(BQ * C);
+  for (int i = 0; i < c.nblocks; ++i) {
+    p.h_cross[i] = a.take<float>(BQ * C);
+    p.f_self[i] = a.take<float>(BQ * C);
+    p.f_cross[i] = a.take<float>(BQ * C);
+    p.feats[i] = a.take<float>(BQ * C);
+    p.idx_self[i] = a.take<int32_t>(BQ * 32);
+    p.idx_cross[i] = a.take<int32_t>(BQ * 32);
+  }
+  p.q3t = a.take<float>((size_t)B * C);
+  p.par = a.take<float>((size_t)B * 106);
+  p.bytes = align_up(a.off, 256);
+  return p;
+}
+}  // namespace
+
+// Decoder (PtEmbedTRv4.forward): p.xyz[0] holds the initial normalised query coordinates; writes p.xyz[1..nblocks].
+static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const float* pt_xyz, const float* pt_feats, int B,
+                       float* pose_aa, float* betas, hipStream_t s) {
+  const poem_config_t& c = h->cfg;
+  const int C = c.embed, S = c.nsample, Q = c.nquery;
+  const int BS = B * S, BQ = B * Q;
+#define GEMM(X, LDX, WI, BI, RES, LDR, Y, LDY, M, N, K, ACT) \
+  HIPCHK(poem_launch_gemm(X, LDX, h->P(WI), (BI) >= 0 ? h->R(BI) : nullptr, RES, LDR, Y, LDY, M, N, K, ACT, s))
+  // ---- decoder ---------------------------------------------------------------------------------------------------
+  const float* feats = feats_in;
+  for (int i = 0; i < c.nblocks; ++i) {
+    const int bb = h->block_base(i);
+    const float* xyz = p.xyz[i];
+    GEMM(feats, C, bb + B_EMB_W, bb + B_EMB_B, nullptr, 0, p.qe, C, BQ, C, C, POEM_ACT_NONE);
+    GEMM(pt_feats, C, bb + B_EMB_W, bb + B_EMB_B, nullptr, 0, p.ke, C, BS, C, C, POEM_ACT_NONE);
+    const float* hidden = p.qe;
+    for (int a = 0; a < 2; ++a) {
+      const int ab = bb + (a == 0 ? B_A1 : B_A2);
+      float* hout = a == 0 ? p.h_attn : p.h_cross[i];
+      GEMM(hidden, C, ab + 0, ab + 1, nullptr, 0, p.qp, C, BQ, C, C, POEM_ACT_NONE);
+      GEMM(p.ke, C, ab + 2, ab + 3, nullptr, 0, p.kp, C, BS, C, C, POEM_ACT_NONE);
+      GEMM(p.ke, C, ab + 4, ab + 5, nullptr, 0, p.vp, C, BS, C, C, POEM_ACT_NONE);
+      HIPCHK(poem_launch_cross_attention(p.qp, p.kp, p.vp, p.ctx, B, Q, S, C, c.heads, s));
+      GEMM(p.ctx, C, ab + 6, ab + 7, hidden, C, p.att, C, BQ, C, C, POEM_ACT_NONE);
+      HIPCHK(poem_launch_layernorm(p.att, h->R(ab + 8), h->R(ab + 9), hout, BQ, C, c.ln_eps, s));
+      hidden = hout;
+    }
+    // neighbours (block 0: the fixed anchors for both attentions -- Q2)
+    const int* idx_s = h->anchor_idx;
+    const int* idx_c = h->anchor_idx;
+    const float* anchor = h->anchor;
+    int shared = 1;
+    if (i > 0) {
+      HIPCHK(poem_launch_knn(xyz, xyz, p.idx_self[i], B, Q, Q, s));
+      HIPCHK(poem_launch_knn(xyz, pt_xyz, p.idx_cross[i], B, Q, S, s));
+      idx_s = p.idx_self[i];
+      idx_c = p.idx_cross[i];
+      anchor = nullptr;
+      shared = 0;
+    }
+    // vector self-attention over the queries
+    const int vsb = bb + B_VS;
+    GEMM(hidden, C, vsb + 0, vsb + 1, nullptr, 0, p.xs, C, BQ, C, C, POEM_ACT_NONE);
+    GEMM(p.xs, C, vsb + 12, -1, nullptr, 0, p.qs, C, BQ, C, C, POEM_ACT_NONE);
+    GEMM(p.xs, C, vsb + 13, -1, nullptr, 0, p.ks, C, BQ, C, C, POEM_ACT_NONE);
+    GEMM(p.xs, C, vsb + 14, -1, nullptr, 0, p.vs, C, BQ, C, C, POEM_ACT_NONE);
+    HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.qs, p.ks, p.vs, Q, h->R(vsb + 4), h->R(vsb + 5),
+                                        h->P(vsb + 6), h->R(vsb + 7), h->P(vsb + 8), h->R(vsb + 9), h->P(vsb + 10),
+                                        h->R(vsb + 11), p.rs, B, Q, C, s));
+    GEMM(p.rs, C, vsb + 2, vsb + 3, hidden, C, p.f_self[i], C, BQ, C, C, POEM_ACT_NONE);
+    // vector cross-attention over the basis points (fc1 / w_k / w_v hoisted to the S source rows)
+    const int vcb = bb + B_VC;
+    GEMM(p.f_self[i], C, vcb + 12, -1, nullptr, 0, p.qc, C, BQ, C, C, POEM_ACT_NONE);
+    GEMM(p.ke, C, vcb + 0, vcb + 1, nullptr, 0, p.xk, C, BS, C, C, POEM_ACT_NONE);
+    GEMM(p.xk, C, vcb + 13, -1, nullptr, 0, p.kc, C, BS, C, C, POEM_ACT_NONE);
+    GEMM(p.xk, C, vcb + 14, -1, nullptr, 0, p.vc, C, BS, C, C, POEM_ACT_NONE);
+    HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.kc, p.vc, S, h->R(vcb + 4),
+                                        h->R(vcb + 5), h->P(vcb + 6), h->R(vcb + 7), h->P(vcb + 8), h->R(vcb + 9),
+                                        h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, s));
+    GEMM(p.rc, C, vcb + 2, vcb + 3, p.f_self[i], C, p.f_cross[i], C, BQ, C, C, POEM_ACT_NONE);
+    // xyz update
+    GEMM(p.f_cross[i], C, bb + B_REG0_W, bb + B_REG0_B, nullptr, 0, p.regh, C, BQ, C, C, POEM_ACT_RELU);
+    HIPCHK(poem_launch_narrow_linear(p.regh, C, h->R(bb + B_REG2_W), h->R(bb + B_REG2_B), xyz, p.xyz[i + 1], BQ, C, 3, s));
+    // feed forward
+    GEMM(p.f_cross[i], C, bb + B_INT_W, bb + B_INT_B, nullptr, 0, p.ffh, 4 * C, BQ, 4 * C, C, POEM_ACT_GELU);
+    GEMM(p.ffh, 4 * C, bb + B_OUT_W, bb + B_OUT_B, p.f_cross[i], C, p.ffo, C, BQ, C, 4 * C, POEM_ACT_NONE);
+    HIPCHK(poem_launch_layernorm(p.ffo, h->R(bb + B_LN_W), h->R(bb + B_LN_B), p.feats[i], BQ, C, c.ln_eps, s));
+    feats = p.feats[i];
+    if (c.parametric && i == c.nblocks - 1) {
+      HIPCHK(poem_launch_q3_flatten(feats, h->R(bb + B_FLAT_W), h->R(bb + B_FLAT_B), p.q3t, B, Q, C, s));
+      HIPCHK(poem_launch_narrow_linear(p.q3t, C, h->R(bb + B_MANO_W), h->R(bb + B_MANO_B), nullptr, p.par, B, C, 106, s));
+      HIPCHK(poem_launch_rot6d_to_aa(p.par, pose_aa, betas, B, s));
+    }
+  }
+#undef GEMM
+  return POEM_OK;
+}
+
+static void register_taps(poem_handle_t h, const Plan& p, int B, int BN, bool sampling) {
+  const poem_config_t& c = h->cfg;
+  const int64_t C = c.embed, S = c.nsample, Q = c.nquery, HW = c.feat_h * c.feat_w;
+  const int64_t BS = B * S, BQ = B * Q;
+  h->tapmap.clear();
+  if (!h->taps) return;
+  auto put = [&](const std::string& k, const void* ptr, int64_t n) { h->tapmap[k] = {ptr, n}; };
+  if (sampling) {
+    put("x", p.x, (int64_t)BN * C * HW);
+    put("g", p.g, (int64_t)BN * C * S);
+    put("bps_feat", p.bps_feat, BS * C);
+    put("pt_xyz", p.pt_xyz, BS * 3);
+  }
+  put("query_xyz", p.xyz[0], BQ * 3);
+  for (int i = 0; i < c.nblocks; ++i) {
+    const std::string pre = "b" + std::to_string(i) + ".";
+    put(pre + "h_cross", p.h_cross[i], BQ * C);
+    put(pre + "f_self", p.f_self[i], BQ * C);
+    put(pre + "f_cross", p.f_cross[i], BQ * C);
+    put(pre + "feats", p.feats[i], BQ * C);
+    put(pre + "xyz", p.xyz[i + 1], BQ * 3);
+    if (i > 0) {
+      put(pre + "idx_self", p.idx_self[i], BQ * 32);
+      put(pre + "idx_cross", p.idx_cross[i], BQ * 32);
+    }
+  }
+}
+
+extern "C" {
+
+int poem_abi_version(void) { return 1; }
+int poem_last_hip_error(void) { return g_last_hip_error; }
+const char* poem_error_string(int code) {
+  switch (code) {
+    case POEM_OK: return "ok";
+    case POEM_E_ARG: return "bad argument";
+    case POEM_E_WORKSPACE: return "workspace too small";
+    case POEM_E_LAUNCH: return "HIP runtime/launch error";
+    case POEM_E_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown";
+  }
+}
+
+int poem_num_weight_tensors(const poem_config_t* cfg) {
+  if (check_config(cfg) != POEM_OK) return POEM_E_UNSUPPORTED;
+  return (int)tensor_table(*cfg).size();
+}
+
+int64_t poem_weight_tensor_numel(const poem_config_t* cfg, int index) {
+  if (check_config(cfg) != POEM_OK) return POEM_E_UNSUPPORTED;
+  auto t = tensor_table(*cfg);
+  if (index < 0 || index >= (int)t.size()) return POEM_E_ARG;
+  return (int64_t)t[index].rows * t[index].cols;
+}
+
+static size_t pe_views(int max_views) { return (size_t)max_views * (max_views + 1) / 2; }
+
+size_t poem_packed_bytes(const poem_config_t* cfg) {
+  if (check_config(cfg) != POEM_OK) return 0;
+  size_t total = 0;
+  for (auto& s : tensor_table(*cfg))
+    if (s.pack) total += align_up(packed_bytes_linear(s.rows, s.cols), 256);
+  const size_t hw = (size_t)cfg->feat_h * cfg->feat_w;
+  total += align_up(pe_views(cfg->max_views) * cfg->embed * hw * 4, 256);              // folded positional table
+  total += align_up(pe_views(cfg->max_views) * (3 * cfg->embed / 2) * hw * 4, 256);    // sine scratch (init only)
+  return total;
+}
+
+size_t poem_packed_linear_bytes(int out_features, int in_features) {
+  if (in_features % 8) return 0;
+  return packed_bytes_linear(out_features, in_features);
+}
+
+int poem_pack_linear(const float* w, int out_features, int in_features, void* packed, void* stream) {
+  if (!w || !packed || in_features % 8 || out_features <= 0) return POEM_E_ARG;
+  HIPCHK(poem_launch_pack_linear(w, out_features, in_features, packed, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, const float* bps, const float* anchor,
+                const int32_t* anchor_idx, const float* template_xyz, void* packed, size_t packed_bytes, void* stream,
+                poem_handle_t* out) {
+  int rc = check_config(cfg);
+  if (rc != POEM_OK) return rc;
+  if (!raw_host || !bps || !anchor || !anchor_idx || !template_xyz || !packed || !out) return POEM_E_ARG;
+  auto* h = new poem_handle_s();
+  h->cfg = *cfg;
+  h->specs = tensor_table(*cfg);
+  if (n != (int)h->specs.size() || packed_bytes < poem_packed_bytes(cfg)) { delete h; return POEM_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  char* cur = (char*)packed;
+  h->raw.resize(n);
+  h->packed.assign(n, nullptr);
+  for (int i = 0; i < n; ++i) {
+    if (!raw_host[i]) { delete h; return POEM_E_ARG; }
+    h->raw[i] = (const float*)raw_host[i];
+    if (h->specs[i].pack) {
+      hipError_t e = poem_launch_pack_linear(h->raw[i], h->specs[i].rows, h->specs[i].cols, cur, s);
+      if (e != hipSuccess) { g_last_hip_error = (int)e; delete h; return POEM_E_LAUNCH; }
+      h->packed[i] = cur;
+      cur += align_up(packed_bytes_linear(h->specs[i].rows, h->specs[i].cols), 256);
+    }
+  }
+  h->bps = bps; h->anchor = anchor; h->anchor_idx = anchor_idx; h->tmpl = template_xyz;
+  const int C = cfg->embed, hw = cfg->feat_h * cfg->feat_w;
+  h->pe_table = (float*)cur;
+  cur += align_up(pe_views(cfg->max_views) * C * hw * 4, 256);
+  float* sine = (float*)cur;
+  rc = poem_pe_table(h->P(T_ADAPT_W), h->R(T_ADAPT_B), C, cfg->feat_h, cfg->feat_w, cfg->max_views, sine, h->pe_table,
+                     stream);
+  if (rc != POEM_OK) { delete h; return rc; }
+  *out = h;
+  return POEM_OK;
+}
+
+void poem_destroy(poem_handle_t h) { delete h; }
+
+int poem_enable_taps(poem_handle_t h, int enable) {
+  if (!h) return POEM_E_ARG;
+  h->taps = enable != 0;
+  return POEM_OK;
+}
+
+int64_t poem_tap(poem_handle_t h, const char* name, void* dst, int64_t dst_elems, void* stream) {
+  if (!h || !name) return POEM_E_ARG;
+  auto it = h->tapmap.find(name);
+  if (it == h->tapmap.end()) return POEM_E_ARG;
+  if (dst) {
+    if (dst_elems < it->second.elems) return POEM_E_ARG;
+    HIPCHK(hipMemcpyAsync(dst, it->second.p, (size_t)it->second.elems * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  }
+  return it->second.elems;
+}
+
+// ---- individual operators -------------------------------------------------------------------------------------
+int poem_gemm(const float* x, int ldx, const void* w_packed, const float* bias, const float* residual, int ldr, float* y,
+              int ldy, int M, int N, int K, int act, void* stream) {
+  if (!x || !w_packed || !y || M <= 0 || N <= 0 || K <= 0 || K % 8 || ldx % 4 || ((uintptr_t)x & 15)) return POEM_E_ARG;
+  if (act < 0 || act > 2) return POEM_E_ARG;
+  HIPCHK(poem_launch_gemm(x, ldx, w_packed, bias, residual, ldr, y, ldy, M, N, K, act, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int cols, float eps,
+                   void* stream) {
+  if (!x || !gamma || !beta || !y || rows <= 0 || cols <= 0) return POEM_E_ARG;
+  HIPCHK(poem_launch_layernorm(x, gamma, beta, y, rows, cols, eps, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_pe_table(const void* adapt_w_packed, const float* adapt_b, int embed, int fh, int fw, int max_views,
+                  float* scratch_sine, float* table, void* stream) {
+  if (!adapt_w_packed || !adapt_b || !scratch_sine || !table || embed % 2 || (fh * fw) % 32) return POEM_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(poem_launch_sine_pe(scratch_sine, embed / 2, fh, fw, max_views, s));
+  HIPCHK(poem_launch_conv1x1(scratch_sine, adapt_w_packed, adapt_b, nullptr, nullptr, table, (int)pe_views(max_views),
+                             3 * embed / 2, embed, fh * fw, s));
+  return POEM_OK;
+}
+
+int poem_input_proj(const float* feat, const void* w_packed, const float* bias, const float* table,
+                    const int32_t* pe_index, float* x, int views, int in_channels, int embed, int hw, void* stream) {
+  if (!feat || !w_packed || !x || views <= 0 || in_channels % 8 || hw % 32) return POEM_E_ARG;
+  if (table && !pe_index) return POEM_E_ARG;
+  HIPCHK(poem_launch_conv1x1(feat, w_packed, bias, table, pe_index, x, views, in_channels, embed, hw, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_project_sample(const float* x, const float* bps, const float* centre, const int32_t* view_sample,
+                        const float* cam_intr, const float* cam_extr, float* uv_scratch, float* g, int views, int embed,
+                        int fh, int fw, int nsample, int img_w, int img_h, void* stream) {
+  if (!x || !bps || !centre || !view_sample || !cam_intr || !cam_extr || !uv_scratch || !g || views <= 0) return POEM_E_ARG;
+  // the inverse extrinsics live in the tail of the uv scratch: caller provides (views*S*2 + views*16) floats
+  float* inv = uv_scratch + (size_t)views * nsample * 2;
+  HIPCHK(poem_launch_project_sample(x, bps, centre, view_sample, cam_intr, cam_extr, inv, uv_scratch, g, views, embed, fh,
+                                    fw, nsample, img_w, img_h, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_merge_reduce(const float* h2, const int32_t* view_offsets, float* m, int batch, int nsample, int half,
+                      void* stream) {
+  if (!h2 || !view_offsets || !m || half > 512 || batch <= 0) return POEM_E_ARG;
+  HIPCHK(poem_launch_merge_reduce(h2, view_offsets, m, batch, nsample, half, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_merge_finalize(const float* g, const float* y, const int32_t* view_offsets, float* out, int batch, int nsample,
+                        int embed, void* stream) {
+  if (!g || !y || !view_offsets || !out || batch <= 0) return POEM_E_ARG;
+  HIPCHK(poem_launch_merge_finalize(g, y, view_offsets, out, batch, nsample, embed, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_cross_attention(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk, int embed,
+                         int heads, void* stream) {
+  if (!q || !k || !v || !ctx || batch <= 0 || nq <= 0 || nk % 32 || heads <= 0 || embed % heads) return POEM_E_ARG;
+  HIPCHK(poem_launch_cross_attention(q, k, v, ctx, batch, nq, nk, embed, heads, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream) {
+  if (!query_xyz || !src_xyz || !idx || batch <= 0 || nq <= 0 || nsrc < 32 || nsrc > 4096) return POEM_E_ARG;
+  HIPCHK(poem_launch_knn(query_xyz, src_xyz, idx, batch, nq, nsrc, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz, const int32_t* idx,
+                          int shared_idx, const float* q, const float* k, const float* v, int nsrc, const float* wd1,
+                          const float* bd1, const void* wd2_packed, const float* bd2, const void* wg1_packed,
+                          const float* bg1, const void* wg2_packed, const float* bg2, float* out, int batch, int nq,
+                          int embed, void* stream) {
+  if (!query_xyz || (!src_xyz && !anchor_xyz) || !idx || !q || !k || !v || !wd1 || !bd1 || !wd2_packed || !bd2 ||
+      !wg1_packed || !bg1 || !wg2_packed || !bg2 || !out || batch <= 0 || nq <= 0)
+    return POEM_E_ARG;
+  HIPCHK(poem_launch_vector_attention(query_xyz, src_xyz, anchor_xyz, idx, shared_idx, q, k, v, nsrc, wd1, bd1, wd2_packed,
+                                      bd2, wg1_packed, bg1, wg2_packed, bg2, out, batch, nq, embed, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_reg_update(const float* r, const float* w, const float* b, const float* xyz_in, float* xyz_out, int rows,
+                    int embed, void* stream) {
+  if (!r || !w || !b || !xyz_in || !xyz_out || rows <= 0) return POEM_E_ARG;
+  HIPCHK(poem_launch_narrow_linear(r, embed, w, b, xyz_in, xyz_out, rows, embed, 3, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+// ---- whole path (entry points) ------------------------------------------------------------------------------
+
+size_t poem_workspace_bytes(poem_handle_t h, int batch, int total_views) {
+  if (!h || batch <= 0 || total_views < batch || h->cfg.nblocks > 8) return 0;
+  return make_plan(h->cfg, batch, total_views, nullptr).bytes;
+}
+
+int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_intr, const float* cam_extr,
+                      const int32_t* view_offsets_host, int batch, const float* reference_joints, int img_w, int img_h,
+                      float* out_xyz, float* pose_aa, float* betas, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  if (!h || !mlvl_feat || !cam_intr || !cam_extr || !view_offsets_host || batch <= 0 || !reference_joints || !out_xyz ||
+      !workspace || img_w <= 0 || img_h <= 0)
+    return POEM_E_ARG;
+  const poem_config_t& c = h->cfg;
+  if (c.nblocks > 8) return POEM_E_UNSUPPORTED;
+  if (c.parametric && (!pose_aa || !betas)) return POEM_E_ARG;
+  const int B = batch, BN = view_offsets_host[B];
+  if (view_offsets_host[0] != 0 || BN < B) return POEM_E_ARG;
+  std::vector<int32_t> vs(BN), pei(BN);
+  for (int b = 0; b < B; ++b) {
+    const int n = view_offsets_host[b + 1] - view_offsets_host[b];
+    if (n < 1 || n > c.max_views) return POEM_E_ARG;
+    for (int k = 0; k < n; ++k) {
+      vs[view_offsets_host[b] + k] = b;
+      pei[view_offsets_host[b] + k] = n * (n - 1) / 2 + k;
+    }
+  }
+  Plan p = make_plan(c, B, BN, workspace);
+  if (workspace_bytes < p.bytes) return POEM_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int C = c.embed, S = c.nsample, Q = c.nquery, HW = c.feat_h * c.feat_w;
+  const int BS = B * S;
+
+  HIPCHK(hipMemcpyAsync(p.offs, view_offsets_host, (B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(p.view_sample, vs.data(), BN * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(p.pe_index, pei.data(), BN * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  // the host vectors above die at return: pageable H2D copies complete (are staged) before hipMemcpyAsync returns.
+
+#define GEMM(X, LDX, WI, BI, RES, LDR, Y, LDY, M, N, K, ACT) \
+  HIPCHK(poem_launch_gemm(X, LDX, h->P(WI), (BI) >= 0 ? h->R(BI) : nullptr, RES, LDR, Y, LDY, M, N, K, ACT, s))
+
+  // ---- sampling stage ------------------------------------------------------------------------------------------
+  HIPCHK(poem_launch_conv1x1(mlvl_feat, h->P(T_INPROJ_W), h->R(T_INPROJ_B), h->pe_table, p.pe_index, p.x, BN,
+                             c.in_channels, C, HW, s));
+  HIPCHK(poem_launch_prep_xyz(reference_joints, h->bps, h->tmpl, p.centre, p.pt_xyz, p.xyz[0], B, S, Q, c.radius, s));
+  HIPCHK(poem_launch_project_sample(p.x, h->bps, p.centre, p.view_sample, cam_intr, cam_extr, p.uv + (size_t)BN * S * 2,
+                                    p.uv, p.g, BN, C, c.feat_h, c.feat_w, S, img_w, img_h, s));
+  // merge MLP 0 on the Q1 rows == the (BN*S, C) row-major view of g's memory
+  GEMM(p.g, C, T_M00_W, T_M00_B, nullptr, 0, p.h1, C, BN * S, C, C, POEM_ACT_RELU);
+  GEMM(p.h1, C, T_M02_W, T_M02_B, nullptr, 0, p.h2, C / 2, BN * S, C / 2, C, POEM_ACT_NONE);
+  HIPCHK(poem_launch_merge_reduce(p.h2, p.offs, p.mm, B, S, C / 2, s));
+  GEMM(p.mm, C / 2, T_M10_W, T_M10_B, nullptr, 0, p.mh, C / 2, BS, C / 2, C / 2, POEM_ACT_RELU);
+  GEMM(p.mh, C / 2, T_M12_W, T_M12_B, nullptr, 0, p.y, C, BS, C, C / 2, POEM_ACT_NONE);
+  HIPCHK(poem_launch_merge_finalize(p.g, p.y, p.offs, p.bps_feat, B, S, C, s));
+
+  // ---- decoder ---------------------------------------------------------------------------------------------------
+  HIPCHK(poem_launch_broadcast(h->R(T_QEMB), p.feats0, (long)Q * C, B, s));
+#undef GEMM
+  {
+    const int rc = run_decoder(h, p, p.feats0, p.pt_xyz, p.bps_feat, B, pose_aa, betas, s);
+    if (rc != POEM_OK) return rc;
+  }
+  HIPCHK(poem_launch_finalize(p.xyz[1], p.centre, out_xyz, c.nblocks, B, Q, c.radius, s));
+
+  register_taps(h, p, B, BN, true);
+  return POEM_OK;
+}
+
+int poem_decoder_forward(poem_handle_t h, const float* query_xyz, const float* query_feat, const float* pt_xyz,
+                         const float* pt_feats, int batch, float* out_xyz_norm, float* pose_aa, float* betas,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !query_xyz || !query_feat || !pt_xyz || !pt_feats || batch <= 0 || !out_xyz_norm || !workspace)
+    return POEM_E_ARG;
+  const poem_config_t& c = h->cfg;
+  if (c.nblocks > 8) return POEM_E_UNSUPPORTED;
+  if (c.parametric && (!pose_aa || !betas)) return POEM_E_ARG;
+  Plan p = make_plan(c, batch, batch, workspace);
+  if (workspace_bytes < p.bytes) return POEM_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)batch * c.nquery * 3;
+  HIPCHK(hipMemcpyAsync(p.xyz[0], query_xyz, n * 4, hipMemcpyDeviceToDevice, s));
+  const int rc = run_decoder(h, p, query_feat, pt_xyz, pt_feats, batch, pose_aa, betas, s);
+  if (rc != POEM_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out_xyz_norm, p.xyz[1], n * 4 * c.nblocks, hipMemcpyDeviceToDevice, s));
+  register_taps(h, p, batch, batch, false);
+  return POEM_OK;
+}
+
+int poem_finalize_parametric(poem_handle_t h, const float* mano_verts, const float* mano_joints,
+                             const float* reference_joints, int batch, float* out_xyz, void* stream) {
+  if (!h || !mano_verts || !mano_joints || !reference_joints || !out_xyz || batch <= 0) return POEM_E_ARG;
+  const poem_config_t& c = h->cfg;
+  float* last = out_xyz + (size_t)(c.nblocks - 1) * batch * c.nquery * 3;
+  HIPCHK(poem_launch_finalize_param(mano_verts, mano_joints, reference_joints, last, batch, c.nquery, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+// Shared device helpers for the gfx950 kernels of libpoem_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define POEM_WAVE 64
+
+// v_mfma_f32_32x32x2_f32: D(32x32) += A(32x2) * B(2x32), exact fp32 (k-ordered fma chain).
+// Operand layout (lane l): A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31];
+// result layout: col j = l & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5), reg in [0,16).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// exchange with the lane 32 positions away (the other half-wave)
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Packed Linear weight image used by every MFMA kernel here ("fragment order"):
+//   P[(nt * KC + kc) * 64 + lane] = float4( W[32*nt + (lane&31)][8*kc + 4*(lane>>5) + 0..3] ),  KC = K/8,
+// zero-filled for rows >= N.  One wave-wide 1 KiB load yields the operand of four consecutive MFMA k-steps
+// for a 32-row tile: k-step t of chunk kc multiplies channels (8kc+t | 8kc+4+t) held by the two half-waves.
+static inline size_t packed_linear_floats(int N, int K) { return (size_t)((N + 31) / 32) * (size_t)(K / 8) * 64 * 4; }

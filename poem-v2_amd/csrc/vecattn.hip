@@ -1,0 +1,253 @@
+// Fused Point-Transformer vector attention over K = 32 neighbours (the path's dominant cost):
+//   pos_ij = W_d2 relu(W_d1 (xyz_i - nxyz_j) + b_d1) + b_d2
+//   a_ij   = W_g2 relu(W_g1 (q_i - k_j + pos_ij) + b_g1) + b_g2
+//   r_i    = sum_j softmax_j(a_ij / sqrt(C)) * (v_j + pos_ij)          (softmax per channel over the 32 neighbours)
+// (point_transformers.py:88-95 / :144-151 upstream; fc1/w_k/w_v are applied to the source rows beforehand.)
+//
+// One block (NW waves) owns P queries = P*32 neighbour columns.  The three C x C per-neighbour GEMMs are chained
+// through ONE LDS activation buffer X[channel][column] without ever touching HBM, in "transposed" orientation:
+//   D[c'][j] = sum_c W[c'][c] * X[c][j]     A = packed weight fragment (global/L2), B = X row read (lane = column j)
+// whose result layout (lane = column, registers = channels) is exactly what is written back to X for the next
+// GEMM.  The last GEMM is issued with the operands swapped (A = X, B = W) so its result is D[j][c'] -- lane =
+// channel, registers = neighbours -- which makes the softmax over the 32 neighbours register-local (+1 exchange
+// between half-waves) and the v_j gathers coalesced.  Wave w owns output channel tiles [w*TPW, (w+1)*TPW).
+#include "common.h"
+
+struct VecAttnArgs {
+  const float* query_xyz;   // (B,Q,3)
+  const float* src_xyz;     // (B,NS,3) or null when anchor_xyz given
+  const float* anchor_xyz;  // (32,3) or null
+  const int* idx;           // (B,Q,32) or (32) when shared_idx
+  int shared_idx;
+  const float* q;           // (B,Q,C)
+  const float* k;           // (B,NS,C)
+  const float* v;           // (B,NS,C)
+  int NS;
+  const float* wd1;         // (C,3)
+  const float* bd1;
+  const float4* wd2;        // packed (C,C)
+  const float* bd2;
+  const float4* wg1;
+  const float* bg1;
+  const float4* wg2;
+  const float* bg2;
+  float* out;               // (B,Q,C)
+  int B, Q;
+};
+
+template <int C, int P, int NW, int TPW, bool FLIP>
+__device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const float* __restrict__ X,
+                                           f32x16 (&acc)[TPW][P], int wv, int lane) {
+  constexpr int KC = C / 8;
+  constexpr int XS = 32 * P;
+  const int j = lane & 31, h = lane >> 5;
+  const float4* wp = Wp + (size_t)(wv * TPW) * KC * 64 + lane;
+  const float* xc = X + (4 * h) * XS + j;
+  float4 a[TPW];
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp) a[tp] = wp[(size_t)tp * KC * 64];
+#pragma unroll 2
+  for (int kc = 0; kc < KC; ++kc) {
+    const int kn = min(kc + 1, KC - 1);
+    float4 na[TPW];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) na[tp] = wp[((size_t)tp * KC + kn) * 64];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float xb[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) xb[p] = xc[(kc * 8 + t) * XS + 32 * p];
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp) {
+        const float av = (&a[tp].x)[t];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          acc[tp][p] = FLIP ? mfma32(xb[p], av, acc[tp][p]) : mfma32(av, xb[p], acc[tp][p]);
+      }
+    }
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) a[tp] = na[tp];
+  }
+}
+
+template <int C, int P, int NW, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
+  constexpr int TPW = C / 32 / NW;
+  constexpr int XS = 32 * P;
+  constexpr int NT = NW * 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* X = smem;                                   // C * XS
+  float* dl = smem + C * XS;                         // P*32*3 coordinate deltas
+  int* sidx = reinterpret_cast<int*>(dl + P * 32 * 3);  // P*32 neighbour row ids
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int groups = (A.Q + P - 1) / P;
+  const int b = blockIdx.x / groups;
+  const int i0 = (blockIdx.x % groups) * P;
+  const float inv_sqrt_c_den = sqrtf((float)C);
+
+  // ---- stage 0: neighbour ids, coordinate deltas, first-layer activations h = relu(W_d1 delta + b_d1) -> X
+  if (tid < 32 * P) {
+    const int p = tid >> 5, jj = tid & 31;
+    const int qi = min(i0 + p, A.Q - 1);
+    const int id = A.shared_idx ? A.idx[jj] : A.idx[((size_t)b * A.Q + qi) * 32 + jj];
+    const float* qx = A.query_xyz + ((size_t)b * A.Q + qi) * 3;
+    const float* nx = A.anchor_xyz ? A.anchor_xyz + jj * 3 : A.src_xyz + ((size_t)b * A.NS + id) * 3;
+    dl[tid * 3 + 0] = qx[0] - nx[0];
+    dl[tid * 3 + 1] = qx[1] - nx[1];
+    dl[tid * 3 + 2] = qx[2] - nx[2];
+    sidx[tid] = id;
+  }
+  __syncthreads();
+  {
+    const int col = tid % XS;
+    const float dx = dl[col * 3 + 0], dy = dl[col * 3 + 1], dz = dl[col * 3 + 2];
+    for (int c = tid / XS; c < C; c += NT / XS) {
+      const float w0 = A.wd1[c * 3 + 0], w1 = A.wd1[c * 3 + 1], w2 = A.wd1[c * 3 + 2];
+      const float hv = fmaf(dz, w2, fmaf(dy, w1, dx * w0)) + A.bd1[c];
+      X[c * XS + col] = fmaxf(hv, 0.f);
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[TPW][P], pos[TPW][P];
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[tp][p] = zero16();
+
+  // ---- GEMM 1: pos = W_d2 h + b_d2 ;  t = q_i - k_j + pos
+  chain_gemm<C, P, NW, TPW, false>(A.wd2, X, acc, wv, lane);
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp) {
+    const int cbase = (wv * TPW + tp) * 32 + 4 * h;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int qi = min(i0 + p, A.Q - 1);
+      const float* qrow = A.q + ((size_t)b * A.Q + qi) * C + cbase;
+      const float* krow = A.k + ((size_t)b * A.NS + sidx[p * 32 + j]) * C + cbase;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bb = *reinterpret_cast<const float4*>(A.bd2 + cbase + 8 * g);
+        const float4 qq = *reinterpret_cast<const float4*>(qrow + 8 * g);
+        const float4 kk = *reinterpret_cast<const float4*>(krow + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = acc[tp][p][4 * g + e] + (&bb.x)[e];
+          pos[tp][p][4 * g + e] = pv;
+          acc[tp][p][4 * g + e] = ((&qq.x)[e] - (&kk.x)[e]) + pv;
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = acc[tp][p][i];
+        acc[tp][p][i] = 0.f;
+      }
+  __syncthreads();
+
+  // ---- GEMM 2: g = relu(W_g1 t + b_g1)
+  chain_gemm<C, P, NW, TPW, false>(A.wg1, X, acc, wv, lane);
+  __syncthreads();
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp) {
+    const int cbase = (wv * TPW + tp) * 32 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bb = *reinterpret_cast<const float4*>(A.bg1 + cbase + 8 * g);
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = fmaxf(acc[tp][p][i] + (&bb.x)[e], 0.f);
+          acc[tp][p][i] = 0.f;
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---- GEMM 3 (operands swapped): a[j][c'] = W_g2 g + b_g2, lane = channel c', registers = neighbours
+  chain_gemm<C, P, NW, TPW, true>(A.wg2, X, acc, wv, lane);
+  __syncthreads();   // X is dead from here on: reuse it as per-wave transpose scratch
+
+  float* scr = X + wv * (32 * 33);
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp) {
+    const int cch = (wv * TPW + tp) * 32 + j;   // this lane's output channel
+    const float bg = A.bg2[cch];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      // pos tile [c'][j] (lane = neighbour) -> [j][c'] (lane = channel) through the wave-private scratch
+#pragma unroll
+      for (int i = 0; i < 16; ++i) scr[j * 33 + mfma_row(i, h)] = pos[tp][p][i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float val[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int jj = mfma_row(i, h);
+        const float pt = scr[jj * 33 + j];
+        const float vv = A.v[((size_t)b * A.NS + sidx[p * 32 + jj]) * C + cch];
+        val[i] = vv + pt;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        acc[tp][p][i] = (acc[tp][p][i] + bg) / inv_sqrt_c_den;
+        mx = fmaxf(mx, acc[tp][p][i]);
+      }
+      mx = fmaxf(mx, xhalf(mx));
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc[tp][p][i] = expf(acc[tp][p][i] - mx); sum += acc[tp][p][i]; }
+      sum += xhalf(sum);
+      float res = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) res = fmaf(acc[tp][p][i] / sum, val[i], res);
+      res += xhalf(res);
+      if (h == 0 && i0 + p < A.Q) A.out[((size_t)b * A.Q + i0 + p) * C + cch] = res;
+    }
+  }
+}
+
+template <int C, int P, int NW, int MINW>
+static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s) {
+  const int groups = (a.Q + P - 1) / P;
+  const size_t lds = (size_t)C * 32 * P * 4 + P * 32 * 3 * 4 + P * 32 * 4;
+  auto kern = vecattn_kernel<C, P, NW, MINW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * groups)), dim3(NW * 64), lds, s, a);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
+                                                   const int* idx, int shared_idx, const float* q, const float* k,
+                                                   const float* v, int nsrc, const float* wd1, const float* bd1,
+                                                   const void* wd2, const float* bd2, const void* wg1, const float* bg1,
+                                                   const void* wg2, const float* bg2, float* out, int B, int Q, int C,
+                                                   hipStream_t s) {
+  VecAttnArgs a{query_xyz, src_xyz, anchor_xyz, idx, shared_idx, q, k, v, nsrc, wd1, bd1, (const float4*)wd2, bd2,
+                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q};
+  switch (C) {
+    case 32: return launch_va<32, 2, 1, 1>(a, s);
+    case 64: return launch_va<64, 2, 2, 1>(a, s);
+    case 128: return launch_va<128, 4, 4, 2>(a, s);
+    case 256: return launch_va<256, 2, 4, 2>(a, s);
+    case 512: return launch_va<512, 1, 4, 2>(a, s);
+    case 1024: return launch_va<1024, 1, 4, 1>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}

@@ -1,0 +1,141 @@
+"""``POEM_Generalized_Head`` -- MI355X-native drop-in for the reference head of the same name
+(lib/models/heads/ptEmb_head.py:683-964): same registry name, constructor config keys, forward signature
+``forward(mlvl_feat, img_metas, reference_joints, **kwargs) -> {"all_coords_preds", ["pred_pose", "pred_shape"]}``,
+``num_preds`` attribute, side effect on ``img_metas["inp_res"]`` and the same ``state_dict`` key names for every
+tensor the forward reads.  The nn.Modules below only hold parameters; all arithmetic runs in libpoem_hip.so through
+one ``poem_head_forward`` call.  There is no CPU / eager fallback."""
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .builder import HEAD, build_transformer
+from .inputs import synthetic_template
+from .weights import live_key_shapes
+
+
+@HEAD.register_module()
+class POEM_Generalized_Head(nn.Module):
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.nsample = cfg.N_SAMPLE
+        self.radius = cfg.RADIUS_SAMPLE
+        self.pt_feat_dim = cfg.POINTS_FEAT_DIM
+        self.merge_mode = cfg.get("CAM_FEAT_MERGE", "attn")
+        self.query_type = cfg.get("QUERY_TYPE", "POEM")
+        self.PETR_embedding = cfg.get("PETR_EMBEDDING", False)
+        self.parametric_output = cfg.TRANSFORMER.get("PARAMETRIC_OUTPUT", False)
+        self.transformer_center_idx = cfg.TRANSFORMER.get("TRANSFORMER_CENTER_IDX", 9)
+        self.cfg_transformer = cfg.TRANSFORMER
+        self.cfg_position_encoding = cfg.POSITIONAL_ENCODING
+        self.num_query = cfg.NUM_QUERY
+        self.embed_dims = cfg.EMBED_DIMS
+        self.in_channels = cfg.IN_CHANNELS
+        self.num_preds = cfg.NUM_PREDS
+        self.center_shift = cfg.get("CENTER_SHIFT", False)
+        assert self.query_type == "KPT"                                  # ptEmb_head.py:721
+        if self.PETR_embedding:
+            raise NotImplementedError("PETR_EMBEDDING=True is not used by any release config and is not built")
+        if self.cfg_position_encoding.NUM_FEATS * 2 != self.embed_dims:
+            raise ValueError("POSITIONAL_ENCODING.NUM_FEATS must be EMBED_DIMS / 2")
+        C = self.embed_dims
+        # parameter containers with the reference's names (ptEmb_head.py:94,101,701-707,729)
+        self.input_proj = nn.Conv2d(self.in_channels, C, kernel_size=1)
+        self.adapt_pos3d = nn.Conv2d(C * 3 // 2, C, kernel_size=1)
+        self.merge_net_feature = nn.ModuleList([
+            nn.Sequential(nn.Linear(C, C), nn.ReLU(), nn.Linear(C, C // 2)),
+            nn.Sequential(nn.Linear(C // 2, C // 2), nn.ReLU(), nn.Linear(C // 2, C))])
+        self.query_feat_embedding = nn.Embedding(799, self.pt_feat_dim)
+        self.transformer = build_transformer(self.cfg_transformer)
+        self.transformer._engine_owner = None
+        object.__setattr__(self.transformer, "_engine_owner", self)      # plain attribute: no module cycle
+        # zero-pose template (ManoLayer output upstream, ptEmb_head.py:886-892).  MANO assets are licence-gated:
+        # a seeded synthetic template is used until ``set_template`` is called with the real one.
+        self.register_buffer("template", synthetic_template(), persistent=False)
+        self._template_is_synthetic = True
+        self.mano_layer = None    # callable (pose_aa (B,48), betas (B,10)) -> (verts (B,778,3), joints (B,21,3))
+        self.max_views = int(cfg.get("MAX_VIEWS", 10))
+        self._engine = None
+        self._engine_sig = None
+
+    # ---- configuration of external inputs -------------------------------------------------------------------
+    def set_template(self, template_xyz):
+        """(799,3) metres, rows 0..20 joints then 778 vertices, centred at joint TRANSFORMER_CENTER_IDX."""
+        t = torch.as_tensor(template_xyz, dtype=torch.float32).reshape(799, 3)
+        self.template = t.to(self.template.device)
+        self._template_is_synthetic = False
+        self._engine = None
+
+    def set_mano_layer(self, fn):
+        self.mano_layer = fn
+
+    def load_reference_state_dict(self, sd):
+        """Load a reference checkpoint (full model or head-only); dead tensors are ignored."""
+        from .weights import split_state_dict
+        live, ignored = split_state_dict(sd, self.embed_dims, in_channels=self.in_channels,
+                                         nblocks=self.transformer.layer_num, parametric=self.parametric_output)
+        missing, unexpected = self.load_state_dict(live, strict=False)
+        assert not unexpected, unexpected
+        self._engine = None
+        return ignored
+
+    # ---- engine ------------------------------------------------------------------------------------------------
+    def _live_weights(self):
+        sd = self.state_dict()
+        shapes = live_key_shapes(self.embed_dims, self.in_channels, 799, self.transformer.layer_num,
+                                 self.parametric_output)
+        return {k: sd[k].reshape(s) for k, s in shapes.items()}
+
+    def _engine_for(self, device):
+        sig = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._engine is None or self._engine_sig != sig:
+            t = self.transformer
+            cfg = hip.make_config(self.embed_dims, in_channels=self.in_channels, nsample=self.nsample, nquery=799,
+                                  heads=t.num_attention_heads, nblocks=t.layer_num, parametric=self.parametric_output,
+                                  max_views=self.max_views, radius=self.radius, ln_eps=t.layer_norm_eps,
+                                  feat_h=self._feat_hw[0], feat_w=self._feat_hw[1])
+            bps, anchor, aidx = hip.load_assets(self.nsample)
+            self._engine = hip.Engine(cfg, self._live_weights(), bps, anchor, aidx, self.template, device)
+            self._engine_sig = sig
+        return self._engine
+
+    _feat_hw = (16, 16)
+
+    # ---- forward -----------------------------------------------------------------------------------------------
+    def forward(self, mlvl_feat, img_metas, reference_joints, **kwargs):
+        if not mlvl_feat.is_cuda:
+            raise RuntimeError("POEM_Generalized_Head runs on the MI355X HIP path only (no CPU fallback)")
+        assert self.merge_mode == "attn"                                                   # ptEmb_head.py:903
+        assert int(np.sum(np.asarray(img_metas["master_id"]))) == 0, "only support master_id is 0"   # :750-751
+        device = mlvl_feat.device
+        inp_img_w, inp_img_h = img_metas["inp_img_shape"]                                 # upstream naming, :831
+        img_metas["inp_res"] = torch.tensor([inp_img_w, inp_img_h], dtype=torch.float32, device=device)   # :832-833
+        assert mlvl_feat.shape[1] == self.in_channels
+        if tuple(mlvl_feat.shape[-2:]) != self._feat_hw:
+            self._feat_hw = tuple(int(v) for v in mlvl_feat.shape[-2:])
+            self._engine = None
+        views = np.asarray(img_metas["cam_view_num"]).astype(np.int64)
+        if views.max() > self.max_views:
+            self.max_views = int(views.max())
+            self._engine = None
+        if self._template_is_synthetic and not getattr(self, "_warned", False):
+            warnings.warn("POEM_Generalized_Head: using the synthetic hand template (MANO assets absent); "
+                          "call set_template() with ManoLayer's zero-pose output for real checkpoints")
+            self._warned = True
+        eng = self._engine_for(device)
+        f32 = lambda t: t.to(device=device, dtype=torch.float32).contiguous()   # noqa: E731
+        out, pose, betas = eng.head_forward(f32(mlvl_feat), f32(img_metas["cam_intr"]), f32(img_metas["cam_extr"]), views,
+                                            f32(reference_joints), (inp_img_w, inp_img_h))
+        results = {"all_coords_preds": out}
+        if self.parametric_output:
+            if self.mano_layer is None:
+                raise RuntimeError("PARAMETRIC_OUTPUT needs a MANO layer: call set_mano_layer(fn)")
+            m = self.mano_layer(pose, betas)
+            verts, joints = (m.verts, m.joints) if hasattr(m, "verts") else m
+            eng.finalize_parametric(f32(verts), f32(joints), f32(reference_joints), out)
+            results["pred_pose"] = pose.reshape(-1, 16, 3)
+            results["pred_shape"] = betas.reshape(-1, 10)
+        return results

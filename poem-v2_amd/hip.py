@@ -1,0 +1,299 @@
+"""ctypes binding of libpoem_hip.so (include/poem_hip.h).  PyTorch is used only as the owner of device memory and
+streams: every call passes raw ``data_ptr()`` values and the current HIP stream.  There is NO fallback: if the shared
+library is missing or a call fails, a RuntimeError is raised."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch  # noqa: F401  (must be imported before the library so that both share one libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libpoem_hip.so")
+ASSETS = os.path.join(_HERE, "assets")
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+class PoemConfig(ctypes.Structure):
+    _fields_ = [("embed", ctypes.c_int32), ("in_channels", ctypes.c_int32), ("nsample", ctypes.c_int32),
+                ("nquery", ctypes.c_int32), ("heads", ctypes.c_int32), ("nblocks", ctypes.c_int32),
+                ("knn", ctypes.c_int32), ("parametric", ctypes.c_int32), ("feat_h", ctypes.c_int32),
+                ("feat_w", ctypes.c_int32), ("max_views", ctypes.c_int32), ("radius", ctypes.c_float),
+                ("ln_eps", ctypes.c_float)]
+
+
+_vp, _i, _f, _sz, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
+_cfgp = ctypes.POINTER(PoemConfig)
+
+# name -> (restype, argtypes); mirrors include/poem_hip.h one to one (tests check the symbol list against the header)
+SIGNATURES = {
+    "poem_abi_version": (_i, []),
+    "poem_last_hip_error": (_i, []),
+    "poem_error_string": (ctypes.c_char_p, [_i]),
+    "poem_num_weight_tensors": (_i, [_cfgp]),
+    "poem_weight_tensor_numel": (_i64, [_cfgp, _i]),
+    "poem_packed_bytes": (_sz, [_cfgp]),
+    "poem_create": (_i, [_cfgp, ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, ctypes.POINTER(_vp)]),
+    "poem_destroy": (None, [_vp]),
+    "poem_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "poem_head_forward": (_i, [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32), _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
+                               _sz, _vp]),
+    "poem_decoder_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "poem_finalize_parametric": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "poem_tap": (_i64, [_vp, ctypes.c_char_p, _vp, _i64, _vp]),
+    "poem_enable_taps": (_i, [_vp, _i]),
+    "poem_packed_linear_bytes": (_sz, [_i, _i]),
+    "poem_pack_linear": (_i, [_vp, _i, _i, _vp, _vp]),
+    "poem_gemm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "poem_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "poem_pe_table": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "poem_input_proj": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "poem_project_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "poem_merge_reduce": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "poem_merge_finalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "poem_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "poem_knn": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "poem_vector_attention": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _i, _i, _i, _vp]),
+    "poem_reg_update": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+}
+
+_LIB = None
+
+
+def build(verbose=False):
+    """Compile libpoem_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or out.returncode != 0:
+        print(out.stdout[-4000:])
+        print(out.stderr[-4000:])
+    if out.returncode != 0:
+        raise RuntimeError("building libpoem_hip.so failed")
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU/PyTorch fallback for this path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc is not None and rc < 0:
+        L = lib()
+        msg = L.poem_error_string(int(rc)).decode()
+        raise RuntimeError(f"libpoem_hip {what} failed: {msg} (code {rc}, hipError {L.poem_last_hip_error()})")
+    return rc
+
+
+def ptr(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libpoem_hip operates on device tensors only (no CPU path)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"expected contiguous {dtype} tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_config(embed, in_channels=160, nsample=4096, nquery=799, heads=4, nblocks=3, knn=32, parametric=False,
+                feat_h=16, feat_w=16, max_views=10, radius=0.1, ln_eps=1e-12):
+    return PoemConfig(embed, in_channels, nsample, nquery, heads, nblocks, knn, int(bool(parametric)), feat_h, feat_w,
+                      max_views, radius, ln_eps)
+
+
+def load_assets(nsample, root=None):
+    """bps (S,3), anchor (32,3), anchor_idx (32,) -- from ``<root>/assets`` when given/present (the reference reads
+    them relative to cwd: ptEmb_head.py:791, point_transformers.py:12-13), else the copies shipped in the package."""
+    for d in ([os.path.join(root, "assets")] if root else []) + [os.path.join(os.getcwd(), "assets"), ASSETS]:
+        if all(os.path.exists(os.path.join(d, f)) for f in ("bps.npy", "anchor.npy", "anchor_idx.npy")):
+            bps = np.load(os.path.join(d, "bps.npy")).reshape(-1, 3)
+            if bps.shape[0] < nsample:
+                continue
+            anchor = np.load(os.path.join(d, "anchor.npy")).reshape(-1, 3)
+            aidx = np.load(os.path.join(d, "anchor_idx.npy")).reshape(-1)
+            return (torch.from_numpy(bps[:nsample].astype(np.float32).copy()),
+                    torch.from_numpy(anchor.astype(np.float32).copy()), torch.from_numpy(aidx.astype(np.int64).copy()))
+    raise FileNotFoundError("bps.npy / anchor.npy / anchor_idx.npy not found")
+
+
+class Engine:
+    """Owns one ``poem_handle_t``: raw weights, the packed image, constant tables and a grow-only workspace."""
+
+    def __init__(self, cfg: PoemConfig, weights, bps, anchor, anchor_idx, template, device):
+        from .weights import live_key_shapes
+        L = lib()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        shapes = live_key_shapes(cfg.embed, cfg.in_channels, cfg.nquery, cfg.nblocks, bool(cfg.parametric))
+        n = L.poem_num_weight_tensors(ctypes.byref(cfg))
+        check(n, "poem_num_weight_tensors")
+        if n != len(shapes):
+            raise RuntimeError(f"tensor table mismatch: library {n} vs python {len(shapes)}")
+        self.raw = []
+        for i, (key, shape) in enumerate(shapes.items()):
+            t = weights[key].detach().to(self.device, torch.float32).contiguous()
+            if tuple(t.shape) != tuple(shape) or t.numel() != L.poem_weight_tensor_numel(ctypes.byref(cfg), i):
+                raise RuntimeError(f"{key}: shape {tuple(t.shape)} does not match the library's tensor table")
+            self.raw.append(t)
+        self.bps = bps.to(self.device, torch.float32).contiguous()
+        self.anchor = anchor.to(self.device, torch.float32).contiguous()
+        self.anchor_idx = anchor_idx.to(self.device, torch.int32).contiguous()
+        self.template = template.to(self.device, torch.float32).contiguous()
+        assert self.bps.shape == (cfg.nsample, 3) and self.anchor.shape == (32, 3) and self.template.shape == (cfg.nquery, 3)
+        nbytes = L.poem_packed_bytes(ctypes.byref(cfg))
+        if nbytes == 0:
+            raise RuntimeError("unsupported configuration for libpoem_hip")
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        arr = (_vp * n)(*[t.data_ptr() for t in self.raw])
+        h = _vp()
+        with torch.cuda.device(self.device):
+            check(L.poem_create(ctypes.byref(cfg), arr, n, self.bps.data_ptr(), self.anchor.data_ptr(),
+                                self.anchor_idx.data_ptr(), self.template.data_ptr(), self.packed.data_ptr(), nbytes,
+                                stream(), ctypes.byref(h)), "poem_create")
+        self.handle = h
+        self.workspace = None
+        self._taps = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib().poem_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _ws(self, batch, views):
+        need = lib().poem_workspace_bytes(self.handle, batch, views)
+        if need == 0:
+            raise RuntimeError("poem_workspace_bytes failed")
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.workspace, need
+
+    def enable_taps(self, flag=True):
+        self._taps = bool(flag)
+        check(lib().poem_enable_taps(self.handle, int(flag)))
+
+    def head_forward(self, mlvl_feat, cam_intr, cam_extr, cam_view_num, reference_joints, inp_img_shape):
+        c = self.cfg
+        views = [int(v) for v in cam_view_num]
+        B, BN = len(views), int(sum(views))
+        if tuple(mlvl_feat.shape) != (BN, c.in_channels, c.feat_h, c.feat_w):
+            raise RuntimeError(f"mlvl_feat shape {tuple(mlvl_feat.shape)} != {(BN, c.in_channels, c.feat_h, c.feat_w)}")
+        offs = (ctypes.c_int32 * (B + 1))(*np.concatenate([[0], np.cumsum(views)]).astype(np.int32).tolist())
+        ws, need = self._ws(B, BN)
+        out = torch.empty(c.nblocks, B, c.nquery, 3, dtype=torch.float32, device=self.device)
+        pose = torch.empty(B, 48, dtype=torch.float32, device=self.device) if c.parametric else None
+        betas = torch.empty(B, 10, dtype=torch.float32, device=self.device) if c.parametric else None
+        with torch.cuda.device(self.device):
+            check(lib().poem_head_forward(self.handle, ptr(mlvl_feat), ptr(cam_intr), ptr(cam_extr), offs, B,
+                                          ptr(reference_joints), int(inp_img_shape[0]), int(inp_img_shape[1]),
+                                          ptr(out), ptr(pose), ptr(betas), ws.data_ptr(), need, stream()),
+                  "poem_head_forward")
+        return out, pose, betas
+
+    def decoder_forward(self, query_xyz, query_feat, pt_xyz, pt_feats):
+        c = self.cfg
+        B = query_xyz.shape[0]
+        ws, need = self._ws(B, B)
+        out = torch.empty(c.nblocks, B, c.nquery, 3, dtype=torch.float32, device=self.device)
+        pose = torch.empty(B, 48, dtype=torch.float32, device=self.device) if c.parametric else None
+        betas = torch.empty(B, 10, dtype=torch.float32, device=self.device) if c.parametric else None
+        with torch.cuda.device(self.device):
+            check(lib().poem_decoder_forward(self.handle, ptr(query_xyz), ptr(query_feat), ptr(pt_xyz), ptr(pt_feats), B,
+                                             ptr(out), ptr(pose), ptr(betas), ws.data_ptr(), need, stream()),
+                  "poem_decoder_forward")
+        return out, pose, betas
+
+    def finalize_parametric(self, verts, joints, reference_joints, out):
+        with torch.cuda.device(self.device):
+            check(lib().poem_finalize_parametric(self.handle, ptr(verts), ptr(joints), ptr(reference_joints),
+                                                 out.shape[1], ptr(out), stream()), "poem_finalize_parametric")
+        return out
+
+    def tap(self, name, shape, dtype=torch.float32):
+        n = lib().poem_tap(self.handle, name.encode(), None, 0, None)
+        check(n, f"poem_tap({name})")
+        t = torch.empty(int(n), dtype=dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().poem_tap(self.handle, name.encode(), t.data_ptr(), int(n), stream()))
+        return t.view(*shape)
+
+
+# ---- thin operator wrappers (used by the operator-level parity tests) -------------------------------------------
+def pack_linear(w):
+    n, k = w.shape
+    nbytes = lib().poem_packed_linear_bytes(n, k)
+    if nbytes == 0:
+        raise RuntimeError("in_features must be a multiple of 8")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(lib().poem_pack_linear(ptr(w), n, k, out.data_ptr(), stream()), "poem_pack_linear")
+    return out
+
+
+def gemm(x, w_packed, n_out, bias=None, residual=None, act=ACT_NONE):
+    M, K = x.shape
+    y = torch.empty(M, n_out, dtype=torch.float32, device=x.device)
+    check(lib().poem_gemm(ptr(x), K, w_packed.data_ptr(), ptr(bias), ptr(residual), n_out, ptr(y), n_out, M, n_out, K,
+                          act, stream()), "poem_gemm")
+    return y
+
+
+def layernorm(x, g, b, eps):
+    y = torch.empty_like(x)
+    check(lib().poem_layernorm(ptr(x), ptr(g), ptr(b), ptr(y), x.shape[0], x.shape[1], eps, stream()), "poem_layernorm")
+    return y
+
+
+def cross_attention(q, k, v, heads):
+    B, NQ, C = q.shape
+    ctx = torch.empty_like(q)
+    check(lib().poem_cross_attention(ptr(q), ptr(k), ptr(v), ptr(ctx), B, NQ, k.shape[1], C, heads, stream()),
+          "poem_cross_attention")
+    return ctx
+
+
+def knn(query_xyz, src_xyz):
+    B, NQ, _ = query_xyz.shape
+    idx = torch.empty(B, NQ, 32, dtype=torch.int32, device=query_xyz.device)
+    check(lib().poem_knn(ptr(query_xyz), ptr(src_xyz), idx.data_ptr(), B, NQ, src_xyz.shape[1], stream()), "poem_knn")
+    return idx
+
+
+def vector_attention(query_xyz, src_xyz, anchor_xyz, idx, q, k, v, wd1, bd1, wd2p, bd2, wg1p, bg1, wg2p, bg2):
+    B, NQ, C = q.shape
+    out = torch.empty_like(q)
+    shared = 1 if idx.dim() == 1 else 0
+    check(lib().poem_vector_attention(ptr(query_xyz), ptr(src_xyz), ptr(anchor_xyz), idx.data_ptr(), shared, ptr(q), ptr(k),
+                                      ptr(v), k.shape[1], ptr(wd1), ptr(bd1), wd2p.data_ptr(), ptr(bd2), wg1p.data_ptr(),
+                                      ptr(bg1), wg2p.data_ptr(), ptr(bg2), ptr(out), B, NQ, C, stream()),
+          "poem_vector_attention")
+    return out
+
+
+def project_sample(x, bps, centre, view_sample, cam_intr, cam_extr, img_shape):
+    BN, C, fh, fw = x.shape
+    S = bps.shape[0]
+    uv = torch.empty(BN * S * 2 + BN * 16, dtype=torch.float32, device=x.device)
+    g = torch.empty(BN, C, S, dtype=torch.float32, device=x.device)
+    check(lib().poem_project_sample(ptr(x), ptr(bps), ptr(centre), view_sample.data_ptr(), ptr(cam_intr), ptr(cam_extr),
+                                    ptr(uv), ptr(g), BN, C, fh, fw, S, int(img_shape[0]), int(img_shape[1]), stream()),
+          "poem_project_sample")
+    return g, uv[:BN * S * 2].view(BN, S, 2)

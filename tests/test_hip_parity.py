@@ -1,0 +1,234 @@
+"""Parity of the HIP path (through the C ABI of libpoem_hip.so) against the CPU oracle and the golden vectors captured
+from the reference.  All tests need a real MI355X: run with ``-m gpu``."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import poem_oracle as po
+import poem_v2_amd as pk
+from poem_v2_amd import hip
+from util import batch_to, build_hip_head, case_setup, load_golden, oracle_consts, run_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _md(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests must run on the GPU box"
+    hip.lib()   # raises if libpoem_hip.so is missing -- never silently fall back
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 32, 8), (799, 256, 256), (1000, 128, 256), (130, 16, 48), (4096, 1024, 256),
+                                   (257, 256, 1024), (33, 96, 160)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_matches_torch(M, N, K, act):
+    g = torch.Generator().manual_seed(M * 7 + N + K + act)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    ref = [ref, torch.relu(ref), torch.nn.functional.gelu(ref)][act] + r.double()
+    wp = hip.pack_linear(w.to(DEV))
+    y = hip.gemm(x.to(DEV), wp, N, bias=b.to(DEV), residual=r.to(DEV), act=act)
+    assert _md(y, ref) < 2e-5
+    y2 = hip.gemm(x.to(DEV), wp, N, act=0)           # no bias / residual
+    assert _md(y2, torch.nn.functional.linear(x.double(), w.double())) < 2e-5
+
+
+def test_gemm_is_exact_fma_chain_on_small_integers():
+    # integer-valued operands: every partial sum is exactly representable -> bit-exact, catches any k/lane mix-up
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-4, 5, (200, 64), generator=g).float()
+    w = torch.randint(-4, 5, (96, 64), generator=g).float()
+    y = hip.gemm(x.to(DEV), hip.pack_linear(w.to(DEV)), 96)
+    assert torch.equal(y.cpu(), x @ w.t())
+
+
+def test_layernorm():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(799, 256, generator=g) * 3 + 1
+    gm, bt = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (256,), gm.double(), bt.double(), 1e-12)
+    assert _md(hip.layernorm(x.to(DEV), gm.to(DEV), bt.to(DEV), 1e-12), ref) < 1e-5
+
+
+@pytest.mark.parametrize("C,heads,NQ,NK", [(32, 4, 100, 64), (128, 4, 799, 1024), (256, 4, 799, 4096), (512, 4, 257, 512)])
+def test_cross_attention(C, heads, NQ, NK):
+    g = torch.Generator().manual_seed(C + NQ)
+    B = 2
+    q, k, v = (torch.randn(B, n, C, generator=g) for n in (NQ, NK, NK))
+    q = q * 2.0   # sharpen the softmax so the online rescaling path is exercised
+    dh = C // heads
+    sp = lambda t: t.double().view(B, -1, heads, dh).permute(0, 2, 1, 3)   # noqa: E731
+    s = sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(dh)
+    ref = (torch.softmax(s, -1) @ sp(v)).permute(0, 2, 1, 3).reshape(B, NQ, C)
+    out = hip.cross_attention(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    assert _md(out, ref) < 2e-5
+
+
+def test_cross_attention_spiked_key_forces_rescale():
+    # one key dominates late in the sequence: the running max jumps -> alpha-rescale branch must be right
+    g = torch.Generator().manual_seed(9)
+    B, NQ, NK, C, heads = 1, 64, 256, 64, 4
+    q, k, v = (torch.randn(B, n, C, generator=g) for n in (NQ, NK, NK))
+    k[0, 200] = q[0, 5] * 6
+    dh = C // heads
+    sp = lambda t: t.double().view(B, -1, heads, dh).permute(0, 2, 1, 3)   # noqa: E731
+    ref = (torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(dh), -1) @ sp(v)).permute(0, 2, 1, 3).reshape(B, NQ, C)
+    assert _md(hip.cross_attention(q.to(DEV), k.to(DEV), v.to(DEV), heads), ref) < 2e-5
+
+
+@pytest.mark.parametrize("NQ,NS", [(799, 799), (799, 4096), (799, 1024), (40, 33)])
+def test_knn_matches_oracle(NQ, NS):
+    g = torch.Generator().manual_seed(NS)
+    B = 2
+    qx = torch.rand(B, NQ, 3, generator=g) * 2 - 1
+    sx = qx.clone() if NQ == NS else torch.rand(B, NS, 3, generator=g) * 2 - 1
+    ref = po.knn_indices(qx, sx, 32)
+    got = hip.knn(qx.to(DEV), sx.to(DEV)).cpu().long()
+    assert torch.equal(got, ref)
+
+
+def test_knn_ties_take_lower_index():
+    sx = torch.zeros(1, 64, 3)
+    sx[0, :, 0] = torch.arange(64).float() // 2          # every distance appears twice
+    qx = torch.zeros(1, 1, 3)
+    got = hip.knn(qx.to(DEV), sx.to(DEV)).cpu().long()
+    assert got[0, 0].tolist() == list(range(32))
+
+
+@pytest.mark.parametrize("C", [32, 128, 256, 512])
+@pytest.mark.parametrize("anchors", [False, True])
+def test_vector_attention_core(C, anchors):
+    g = torch.Generator().manual_seed(C + anchors)
+    B, Q, NS = 2, 101, 300
+    qxyz = torch.rand(B, Q, 3, generator=g) * 2 - 1
+    sxyz = torch.rand(B, NS, 3, generator=g) * 2 - 1
+    q, k, v = torch.randn(B, Q, C, generator=g), torch.randn(B, NS, C, generator=g), torch.randn(B, NS, C, generator=g)
+    w = {}
+    for n, shp in (("fc_delta.0", (C, 3)), ("fc_delta.2", (C, C)), ("fc_gamma.0", (C, C)), ("fc_gamma.2", (C, C))):
+        w["p." + n + ".weight"] = torch.randn(*shp, generator=g) / math.sqrt(shp[1])
+        w["p." + n + ".bias"] = torch.randn(shp[0], generator=g) * 0.1
+    if anchors:
+        idx = torch.randperm(NS, generator=g)[:32]
+        axyz = torch.rand(32, 3, generator=g) * 2 - 1
+        idx_full = idx.view(1, 1, 32).expand(B, Q, 32)
+        nxyz = axyz.view(1, 1, 32, 3).expand(B, Q, 32, 3)
+    else:
+        idx_full = po.knn_indices(qxyz, sxyz, 32)
+        nxyz = po.gather_xyz(sxyz, idx_full)
+    ref = po._vec_attn_core(w, "p.", q, po.index_points(k, idx_full), po.index_points(v, idx_full),
+                            qxyz[:, :, None] - nxyz, C)
+    d = lambda t: t.to(DEV).contiguous()   # noqa: E731
+    out = hip.vector_attention(d(qxyz), d(sxyz), d(axyz) if anchors else None,
+                               d(idx.int()) if anchors else d(idx_full.int()), d(q), d(k), d(v),
+                               d(w["p.fc_delta.0.weight"]), d(w["p.fc_delta.0.bias"]),
+                               hip.pack_linear(d(w["p.fc_delta.2.weight"])), d(w["p.fc_delta.2.bias"]),
+                               hip.pack_linear(d(w["p.fc_gamma.0.weight"])), d(w["p.fc_gamma.0.bias"]),
+                               hip.pack_linear(d(w["p.fc_gamma.2.weight"])), d(w["p.fc_gamma.2.bias"]))
+    assert _md(out, ref) < 5e-5
+
+
+def test_project_and_sample_matches_oracle():
+    _, meta = load_golden("tiny")
+    cfg, w, consts, batch = case_setup(meta["spec"])
+    g = torch.Generator().manual_seed(1)
+    views = meta["spec"]["views"]
+    BN = sum(views)
+    x = torch.randn(BN, 32, 16, 16, generator=g)
+    m = batch["img_metas"]
+    centre = batch["reference_joints"][:, 9].contiguous()
+    vs = torch.repeat_interleave(torch.arange(len(views)), torch.tensor(views))
+    uv = po.project_points(consts["bps"][None] + centre[:, None], m["cam_intr"], m["cam_extr"], vs)
+    ref = po.grid_sample_bilinear(x, uv * (1.0 / 256.0) * 2 - 1)
+    got, _ = hip.project_sample(x.to(DEV), consts["bps"].to(DEV), centre.to(DEV), vs.int().to(DEV), m["cam_intr"].to(DEV),
+                                m["cam_extr"].to(DEV), (256, 256))
+    assert _md(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["tiny", "tinymano"])
+def test_head_tiny_stage_taps_vs_golden(name):
+    z, meta = load_golden(name)
+    spec = meta["spec"]
+    cfg, w, consts, batch = case_setup(spec)
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    head._engine_for(torch.device(DEV)).enable_taps(True)
+    with torch.no_grad():
+        out = head(feat, metas, rj)
+    eng = head._engine
+    B, BN, C, S, Q = len(spec["views"]), sum(spec["views"]), spec["embed"], spec["nsample"], 799
+    assert _md(eng.tap("x", (BN, C, 16, 16)), torch.from_numpy(z["tap.x"])) < 3e-5
+    assert _md(eng.tap("g", (BN, C, S)), torch.from_numpy(z["tap.g"])) < 3e-5
+    assert _md(eng.tap("bps_feat", (B, S, C)), torch.from_numpy(z["tap.bps_feat"])) < 1e-4
+    assert _md(eng.tap("pt_xyz", (B, S, 3)), torch.from_numpy(z["tap.pt_xyz"])) == 0.0
+    assert _md(eng.tap("query_xyz", (B, Q, 3)), torch.from_numpy(z["tap.query_xyz"])) == 0.0
+    for i in range(3):
+        for k, tol in (("h_cross", 5e-5), ("f_self", 5e-5), ("f_cross", 5e-5), ("feats", 1e-4)):
+            assert _md(eng.tap(f"b{i}.{k}", (B, Q, C))[:, ::9], torch.from_numpy(z[f"tap.b{i}.{k}"])) < tol, (i, k)
+        assert _md(eng.tap(f"b{i}.xyz", (B, Q, 3)), torch.from_numpy(z[f"tap.b{i}.xyz"])) < 5e-5, i
+    ref = torch.from_numpy(z["all_coords_preds"])
+    got = out["all_coords_preds"].cpu()
+    assert got.shape == ref.shape
+    assert _md(got, ref) < 5e-6                                                   # metres
+    if spec["parametric"]:
+        assert _md(out["pred_pose"], torch.from_numpy(z["pred_pose"])) < 2e-4
+        assert _md(out["pred_shape"], torch.from_numpy(z["pred_shape"])) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["small", "medium", "large"])
+def test_head_release_shapes_vs_golden_and_oracle(name):
+    """BASELINE.json bar: MPVPE of the HIP path vs the reference <= 1e-3 mm (1e-6 m), last decoder layer."""
+    z, meta = load_golden(name)
+    spec = meta["spec"]
+    cfg, w, consts, batch = case_setup(spec)
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    with torch.no_grad():
+        got = head(feat, metas, rj)["all_coords_preds"].cpu()
+    ref = torch.from_numpy(z["all_coords_preds"])
+    mpvpe = torch.norm(got[-1, :, 21:] - ref[-1, :, 21:], dim=-1).mean(dim=1)        # metres, per sample
+    assert float(mpvpe.max()) < 1e-6, mpvpe
+    orc = run_oracle(cfg, w, consts, batch)["all_coords_preds"]
+    mp2 = torch.norm(got[-1, :, 21:] - orc[-1, :, 21:], dim=-1).mean(dim=1)
+    assert float(mp2.max()) < 1e-6, mp2
+    assert _md(got, ref) < 1e-4
+
+
+def test_ragged_views_and_batch_independence():
+    """Samples do not interact: a ragged batch equals the per-sample runs (the property the DP shard relies on)."""
+    spec = dict(embed=128, nsample=4096, views=[3, 1, 8, 2], seed=21, parametric=False)
+    cfg, w, consts, batch = case_setup(spec)
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    with torch.no_grad():
+        full = head(feat, metas, rj)["all_coords_preds"].cpu()
+    orc = run_oracle(cfg, w, consts, batch)["all_coords_preds"]
+    assert float(torch.norm(full[-1] - orc[-1], dim=-1).mean()) < 1e-6
+    offs = np.concatenate([[0], np.cumsum(spec["views"])])
+    for i in (1, 2):
+        m = dict(metas)
+        m["cam_intr"] = metas["cam_intr"][offs[i]:offs[i + 1]].contiguous()
+        m["cam_extr"] = metas["cam_extr"][offs[i]:offs[i + 1]].contiguous()
+        m["cam_view_num"] = np.asarray([spec["views"][i]])
+        m["master_id"] = [0]
+        with torch.no_grad():
+            one = head(feat[offs[i]:offs[i + 1]].contiguous(), m, rj[i:i + 1].contiguous())["all_coords_preds"].cpu()
+        assert torch.equal(one[:, 0], full[:, i])
+
+
+def test_errors_are_loud():
+    head = pk.build_head(__import__("util").head_cfg(128), data_preset=pk.CN({}))
+    b = pk.inputs.synthetic_batch([2], seed=0)
+    with pytest.raises(RuntimeError):
+        head(b["mlvl_feat"], b["img_metas"], b["reference_joints"])      # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        hip.gemm(torch.zeros(4, 8), torch.zeros(8, dtype=torch.uint8), 4)
