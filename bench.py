@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark of the hot path: samples/s (multi-view frames) of POEM-medium, 8 views, batch 32 per GPU
+(BASELINE.json configs[1]); one "step" = one poem_head_forward over one resident synthetic batch + the metric feed +
+the 16-byte metric all-reduce.  Prints ONE JSON line on rank 0 (contract in the task statement / DESIGN.md).
+
+  python bench.py                       # 1 GPU, default steps
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT,):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import poem_v2_amd as pk  # noqa: E402
+from poem_v2_amd import dist as pdist  # noqa: E402
+from poem_v2_amd.metrics import MeanEPE  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+
+
+def vecattn_flops_per_launch(B, C, Q=799, K=32):
+    """Algorithmic FLOPs of one fused vector-attention launch: per (query, neighbour) pair three CxC
+    Linears (fc_delta.2, fc_gamma.0, fc_gamma.2) + the 3->C Linear = 6C^2 + 6C (QK(6C + 2C^2) + 4QKC^2)."""
+    return float(B) * Q * K * (6.0 * C * C + 6.0 * C)
+
+
+def physical_cores():
+    """Physical cores visible to this process (SMT siblings counted once)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, phys, core, cpu = set(), None, None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cpu = int(line.split(":")[1])
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+                if cpu in allowed:
+                    seen.add((phys, core))
+        return max(1, len(seen))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(model_embed, batch, n_samples):
+    """The oracle (CPU restatement, as-written arithmetic incl. the un-hoisted cross attention) timed on the host
+    cores on the first ``n_samples`` samples of the very batch the GPU processed -- the CHECKER used as a reported
+    baseline, never as the thing measured on the GPU."""
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import poem_oracle as po
+    from util import oracle_consts
+    cfg = po.PathConfig(embed=model_embed)
+    w = pk.weights.seeded_state_dict(model_embed, seed=0)
+    consts = oracle_consts(4096)
+    m = batch["img_metas"]
+    views = [int(v) for v in m["cam_view_num"]]
+
+    def run(lo, hi):
+        a, b = int(np.sum(views[:lo])), int(np.sum(views[:hi]))
+        with torch.no_grad():
+            return po.head_forward(w, cfg, consts, batch["mlvl_feat"][a:b], m["cam_intr"][a:b], m["cam_extr"][a:b],
+                                   views[lo:hi], batch["reference_joints"][lo:hi],
+                                   inp_img_shape=m["inp_img_shape"])["all_coords_preds"]
+
+    # pick the thread count the host runs this workload fastest with (1 sample each), then time the bounded sample
+    phys = physical_cores()
+    best_t, best_dt = phys, None
+    for t in sorted({min(phys, c) for c in (16, 32, 64, phys)}):
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        run(len(views) - 1, len(views))
+        d = time.perf_counter() - t0
+        if best_dt is None or d < best_dt:
+            best_t, best_dt = t, d
+    torch.set_num_threads(best_t)
+    t0 = time.perf_counter()
+    out = run(0, n_samples)
+    dt = time.perf_counter() - t0
+    return {"value": n_samples / dt, "unit": "samples/s", "cores": best_t, "kind": "port",
+            "sample": f"first {n_samples} samples of the GPU's own batch (POEM-medium, {views[0]} views), one pass in "
+                      f"{dt:.1f} s, torch CPU fp32, {best_t} threads (fastest of 16/32/64/{phys} on this host, "
+                      f"{phys} physical cores)"}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU (weak scaling)")
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--model", default="medium", choices=list(pk.weights.MODEL_EMBED))
+    ap.add_argument("--cpu-samples", type=int, default=4, help="0 disables the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank, local_rank, world = pdist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    C = pk.weights.MODEL_EMBED[args.model]
+    spec = dict(embed=C, nsample=4096, views=[args.views] * args.batch, seed=0, parametric=False)
+    head = pk.build_head(pk.configs.head_cfg(C, max_views=max(10, args.views)), data_preset=pk.CN({}))
+    head.load_state_dict(pk.weights.seeded_state_dict(C, seed=0), strict=False)
+    head.set_template(pk.inputs.synthetic_template(1234))
+    head = head.to(dev).eval()
+    batch = pk.inputs.synthetic_batch(spec["views"], seed=1000 + rank)        # every rank its own shard of samples
+    feat = batch["mlvl_feat"].to(dev)
+    metas = dict(batch["img_metas"])
+    metas["cam_intr"], metas["cam_extr"] = metas["cam_intr"].to(dev), metas["cam_extr"].to(dev)
+    rj = batch["reference_joints"].to(dev)
+    g = torch.Generator().manual_seed(77 + rank)
+    gt_verts = (rj[:, 9:10].cpu() + 0.05 * torch.randn(args.batch, 778, 3, generator=g)).to(dev)   # synthetic GT
+    meter = MeanEPE("verts", device=dev)
+
+    def step():
+        preds = head(feat, metas, rj)
+        meter.feed(preds["all_coords_preds"][-1, :, 21:], gt_verts)
+        meter.reduce()                                   # the path's only collective (16 B all-reduce, RCCL)
+        return preds
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        eng = head._engine
+        eng.profile_enable(6 * args.steps)
+        meter.reset()
+        pdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            preds = step()
+        torch.cuda.synchronize()
+        pdist.barrier()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    pdist.all_reduce_max_(tmax)
+    dt = float(tmax.item())
+    n_launch, va_ms = eng.profile_read()
+    eng.profile_enable(0)
+
+    total_samples = args.batch * world * args.steps
+    value = total_samples / dt
+    res = {
+        "metric": "samples/sec (multi-view frames) POEM-medium 8-view" if (args.model, args.views) == ("medium", 8)
+        else f"samples/sec (multi-view frames) POEM-{args.model} {args.views}-view",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: POEM-{args.model} head (POEM_Generalized_Head + PtEmbedTRv4), "
+                               f"{args.views} views, 160x16x16 backbone features (256x256 input), batch {args.batch} per GPU, "
+                               "seeded weights, inputs resident in HBM",
+                   "batch_per_gpu": args.batch, "views": args.views, "embed": C, "parallelism": f"dp{world}"},
+    }
+    if n_launch > 0:
+        avg_s = va_ms / n_launch * 1e-3
+        ach = vecattn_flops_per_launch(args.batch, C) / avg_s / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_vecattn.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res["roofline"] = {"kernel": "vecattn_kernel (fused vector attention)", "bound": "mfma", "achieved": ach,
+                           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                           "traffic": traffic, "launches_timed": n_launch, "avg_launch_ms": va_ms / n_launch,
+                           "share_of_step": va_ms / (dt * 1e3)}
+    res["mpvpe_synthetic_gt_mm"] = meter.result() * 1e3
+    if rank == 0 and world == 1 and args.cpu_samples > 0:
+        base, ref = cpu_baseline(C, batch, args.cpu_samples)
+        res["cpu_baseline"] = base
+        got = preds["all_coords_preds"][:, :args.cpu_samples].cpu()
+        res["mpvpe_vs_oracle_mm"] = float(torch.norm(got[-1, :, 21:] - ref[-1, :, 21:], dim=-1).mean()) * 1e3
+        res["speedup_vs_cpu"] = value / base["value"]
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

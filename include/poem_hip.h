@@ -106,6 +106,11 @@ int poem_decoder_forward(poem_handle_t h, const float* query_xyz, const float* q
                          void* workspace, size_t workspace_bytes, void* stream);
 int poem_finalize_parametric(poem_handle_t h, const float* mano_verts, const float* mano_joints,
                              const float* reference_joints, int batch, float* out_xyz, void* stream);
+/* Timing of the dominant kernel (the fused vector attention) with HIP events recorded on the launch stream around
+ * each of its launches inside poem_head_forward / poem_decoder_forward.  enable(h, n) allocates n event pairs
+ * (0 disables); read() synchronises the recorded pairs and returns their count and summed duration. */
+int poem_profile_enable(poem_handle_t h, int max_launches);
+int poem_profile_read(poem_handle_t h, int* launches, float* total_ms, int reset);
 /* Debug taps: copies of intermediate tensors of the LAST poem_head_forward on this handle (device->device).
  * name: "x","g","bps_feat","pt_xyz","query_xyz","b<i>.h_cross","b<i>.f_self","b<i>.f_cross","b<i>.xyz",
  * "b<i>.feats","b<i>.idx_self","b<i>.idx_cross".  Returns number of elements or <0. */

@@ -135,6 +135,10 @@ struct poem_handle_s {
   bool taps = false;
   struct Tap { const void* p; int64_t elems; };
   std::map<std::string, Tap> tapmap;
+  // optional HIP-event timing of the dominant kernel (vector attention) on the launch stream
+  std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
+  int prof_used = 0;
+  bool prof_on = false;
   int block_base(int b) const { return T_HEAD_COUNT + b * (cfg.parametric ? B_COUNT_PARAM : B_COUNT); }
   const float* R(int idx) const { return raw[idx]; }
   const void* P(int idx) const { return packed[idx]; }
@@ -251,7 +255,11 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
   const int BS = B * S, BQ = B * Q;
 #define GEMM(X, LDX, WI, BI, RES, LDR, Y, LDY, M, N, K, ACT) \
   HIPCHK(poem_launch_gemm(X, LDX, h->P(WI), (BI) >= 0 ? h->R(BI) : nullptr, RES, LDR, Y, LDY, M, N, K, ACT, s))
-  // ---- decoder ---------------------------------------------------------------------------------------------------
+#define PROF_START()                                                                              \
+  const bool prof_ = h->prof_on && (size_t)(2 * h->prof_used + 1) < h->prof_ev.size();           \
+  if (prof_) HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_used], s))
+#define PROF_STOP()                                                                               \
+  if (prof_) { HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_used + 1], s)); ++h->prof_used; }
   const float* feats = feats_in;
   for (int i = 0; i < c.nblocks; ++i) {
     const int bb = h->block_base(i);
@@ -289,9 +297,13 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     GEMM(p.xs, C, vsb + 12, -1, nullptr, 0, p.qs, C, BQ, C, C, POEM_ACT_NONE);
     GEMM(p.xs, C, vsb + 13, -1, nullptr, 0, p.ks, C, BQ, C, C, POEM_ACT_NONE);
     GEMM(p.xs, C, vsb + 14, -1, nullptr, 0, p.vs, C, BQ, C, C, POEM_ACT_NONE);
+    {
+    PROF_START();
     HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.qs, p.ks, p.vs, Q, h->R(vsb + 4), h->R(vsb + 5),
                                         h->P(vsb + 6), h->R(vsb + 7), h->P(vsb + 8), h->R(vsb + 9), h->P(vsb + 10),
                                         h->R(vsb + 11), p.rs, B, Q, C, s));
+    PROF_STOP();
+    }
     GEMM(p.rs, C, vsb + 2, vsb + 3, hidden, C, p.f_self[i], C, BQ, C, C, POEM_ACT_NONE);
     // vector cross-attention over the basis points (fc1 / w_k / w_v hoisted to the S source rows)
     const int vcb = bb + B_VC;
@@ -299,9 +311,13 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     GEMM(p.ke, C, vcb + 0, vcb + 1, nullptr, 0, p.xk, C, BS, C, C, POEM_ACT_NONE);
     GEMM(p.xk, C, vcb + 13, -1, nullptr, 0, p.kc, C, BS, C, C, POEM_ACT_NONE);
     GEMM(p.xk, C, vcb + 14, -1, nullptr, 0, p.vc, C, BS, C, C, POEM_ACT_NONE);
+    {
+    PROF_START();
     HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.kc, p.vc, S, h->R(vcb + 4),
                                         h->R(vcb + 5), h->P(vcb + 6), h->R(vcb + 7), h->P(vcb + 8), h->R(vcb + 9),
                                         h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, s));
+    PROF_STOP();
+    }
     GEMM(p.rc, C, vcb + 2, vcb + 3, p.f_self[i], C, p.f_cross[i], C, BQ, C, C, POEM_ACT_NONE);
     // xyz update
     GEMM(p.f_cross[i], C, bb + B_REG0_W, bb + B_REG0_B, nullptr, 0, p.regh, C, BQ, C, C, POEM_ACT_RELU);
@@ -318,6 +334,8 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     }
   }
 #undef GEMM
+#undef PROF_START
+#undef PROF_STOP
   return POEM_OK;
 }
 
@@ -436,7 +454,11 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   return POEM_OK;
 }
 
-void poem_destroy(poem_handle_t h) { delete h; }
+void poem_destroy(poem_handle_t h) {
+  if (!h) return;
+  for (auto e : h->prof_ev) (void)hipEventDestroy(e);
+  delete h;
+}
 
 int poem_enable_taps(poem_handle_t h, int enable) {
   if (!h) return POEM_E_ARG;
@@ -633,6 +655,35 @@ int poem_decoder_forward(poem_handle_t h, const float* query_xyz, const float* q
   if (rc != POEM_OK) return rc;
   HIPCHK(hipMemcpyAsync(out_xyz_norm, p.xyz[1], n * 4 * c.nblocks, hipMemcpyDeviceToDevice, s));
   register_taps(h, p, batch, batch, false);
+  return POEM_OK;
+}
+
+int poem_profile_enable(poem_handle_t h, int max_launches) {
+  if (!h || max_launches < 0) return POEM_E_ARG;
+  for (auto e : h->prof_ev) (void)hipEventDestroy(e);
+  h->prof_ev.clear();
+  h->prof_used = 0;
+  h->prof_on = max_launches > 0;
+  for (int i = 0; i < 2 * max_launches; ++i) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    h->prof_ev.push_back(e);
+  }
+  return POEM_OK;
+}
+
+int poem_profile_read(poem_handle_t h, int* launches, float* total_ms, int reset) {
+  if (!h || !launches || !total_ms) return POEM_E_ARG;
+  float tot = 0.f;
+  for (int i = 0; i < h->prof_used; ++i) {
+    HIPCHK(hipEventSynchronize(h->prof_ev[2 * i + 1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+    tot += ms;
+  }
+  *launches = h->prof_used;
+  *total_ms = tot;
+  if (reset) h->prof_used = 0;
   return POEM_OK;
 }
 

@@ -44,6 +44,8 @@ SIGNATURES = {
     "poem_finalize_parametric": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "poem_tap": (_i64, [_vp, ctypes.c_char_p, _vp, _i64, _vp]),
     "poem_enable_taps": (_i, [_vp, _i]),
+    "poem_profile_enable": (_i, [_vp, _i]),
+    "poem_profile_read": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_f), _i]),
     "poem_packed_linear_bytes": (_sz, [_i, _i]),
     "poem_pack_linear": (_i, [_vp, _i, _i, _vp, _vp]),
     "poem_gemm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -190,6 +192,14 @@ class Engine:
     def enable_taps(self, flag=True):
         self._taps = bool(flag)
         check(lib().poem_enable_taps(self.handle, int(flag)))
+
+    def profile_enable(self, max_launches):
+        check(lib().poem_profile_enable(self.handle, int(max_launches)), "poem_profile_enable")
+
+    def profile_read(self, reset=True):
+        n, ms = _i(0), _f(0.0)
+        check(lib().poem_profile_read(self.handle, ctypes.byref(n), ctypes.byref(ms), int(reset)), "poem_profile_read")
+        return n.value, ms.value
 
     def head_forward(self, mlvl_feat, cam_intr, cam_extr, cam_view_num, reference_joints, inp_img_shape):
         c = self.cfg

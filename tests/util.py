@@ -45,18 +45,7 @@ def run_oracle(cfg, w, consts, batch, taps=None, hoist=False):
                                mano_fn=mano_fn)
 
 
-def head_cfg(embed, nsample=4096, parametric=False):
-    """The MODEL.HEAD subtree of config/release/train_*.yaml (upstream) as a CN, sized for ``embed``."""
-    return pk.CN({
-        "TYPE": "POEM_Generalized_Head",
-        "TRANSFORMER": {"TYPE": "PtEmbedTRv4", "N_BLOCKS": 3, "INPUT_FEAT_DIM": embed, "NUM_HIDDEN_LAYERS": 4,
-                        "NUM_ATTENTION_HEADS": 4, "DROPOUT": 0.1, "BPS_FEAT_DIM": nsample, "N_NEIGHBOR": 32,
-                        "N_NEIGHBOR_QUERY": 32, "PARAMETRIC_OUTPUT": parametric},
-        "POSITIONAL_ENCODING": {"TYPE": "SinePositionalEncoding3D", "NUM_FEATS": embed // 2, "NORMALIZE": True},
-        "WITH_POSITION": True, "WITH_MULTIVIEW": True, "NUM_QUERY": 799, "NUM_PREDS": 3, "NUM_REG_FCS": 2,
-        "DEPTH_NUM": 32, "POSITION_RANGE": [-0.6, -0.6, 0.0, 0.6, 0.6, 1.2], "LID": False, "DEPTH_START": 0.0,
-        "DEPTH_END": 1.2, "POINTS_FEAT_DIM": embed, "EMBED_DIMS": embed, "IN_CHANNELS": 160, "CENTER_SHIFT": True,
-        "N_SAMPLE": nsample, "RADIUS_SAMPLE": 0.1, "CAM_FEAT_MERGE": "attn", "QUERY_TYPE": "KPT"})
+from poem_v2_amd.configs import head_cfg  # noqa: E402,F401
 
 
 def build_hip_head(spec, device="cuda:0"):
