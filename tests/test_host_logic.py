@@ -1,0 +1,192 @@
+"""CPU-side tests: plugin boundary, checkpoint surface, C-ABI export list, synthetic inputs, DP glue (gloo, world 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import poem_v2_amd as pk
+from poem_v2_amd import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- plugin boundary ------------------------------------------------------------------------------------------
+def test_registry_and_build_from_cfg():
+    assert pk.HEAD.get("POEM_Generalized_Head") is pk.POEM_Generalized_Head
+    assert pk.TRANSFORMER.get("PtEmbedTRv4") is pk.PtEmbedTRv4
+    reg = pk.Registry("toy")
+
+    @reg.register_module()
+    class Foo:
+        def __init__(self, cfg):
+            self.cfg = cfg
+
+    with pytest.raises(KeyError):
+        reg.register_module(module=Foo)
+    obj = pk.build_from_cfg(pk.CN({"TYPE": "Foo", "A": 1}), reg, data_preset=pk.CN({"X": 2}))
+    assert obj.cfg.A == 1 and obj.cfg.DATA_PRESET.X == 2          # kwargs arrive as UPPER-CASE keys
+    with pytest.raises(KeyError):
+        pk.build_from_cfg(pk.CN({"TYPE": "Nope"}), reg)
+    with pytest.raises(TypeError):
+        reg.register_module(force=1)
+
+
+def test_cn_semantics():
+    c = pk.CN({"A": {"B": 1}, "L": [{"x": 1}]})
+    assert c.A.B == 1 and c.get("Z", 7) == 7 and c.L[0].x == 1
+    d = c.clone()
+    d.A.B = 2
+    assert c.A.B == 1
+    c.freeze()
+    with pytest.raises(AttributeError):
+        c.A.B = 3
+    c.defrost()
+    c.merge_from_other_cfg(pk.CN({"A": {"C": 5}}))
+    assert c.A.B == 1 and c.A.C == 5
+
+
+def test_head_state_dict_keys_and_checkpoint_loading():
+    head = pk.build_head(pk.configs.model_head_cfg("medium"), data_preset=pk.CN({}))
+    want = pk.weights.live_key_shapes(256)
+    sd = head.state_dict()
+    assert list(sd.keys()) == list(want.keys()) or set(sd.keys()) == set(want.keys())
+    assert sum(v.numel() for v in sd.values()) == 7209481          # 7.21 M live parameters
+    assert head.num_preds == 3
+    # a "reference checkpoint": full-model prefixes + dead tensors
+    ref = {"module.ptEmb_head." + k: v for k, v in pk.weights.seeded_state_dict(256, seed=5).items()}
+    ref["module.ptEmb_head.center_shift_layer.0.weight"] = torch.zeros(799, 799)
+    ref["module.ptEmb_head.transformer.pt_metro_encoder.0.embeddings.word_embeddings.weight"] = torch.zeros(8, 256)
+    ref["module.img_backbone.conv1.weight"] = torch.zeros(4)
+    ignored = head.load_reference_state_dict(ref)
+    assert len(ignored) == 3
+    assert torch.equal(head.state_dict()["input_proj.weight"], ref["module.ptEmb_head.input_proj.weight"])
+    bad = dict(ref)
+    bad["module.ptEmb_head.input_proj.bias"] = torch.zeros(3)
+    with pytest.raises(ValueError):
+        head.load_reference_state_dict(bad)
+    del bad["module.ptEmb_head.input_proj.bias"]
+    with pytest.raises(KeyError):
+        head.load_reference_state_dict(bad)
+
+
+def test_parametric_head_has_mano_tail_keys():
+    head = pk.build_head(pk.configs.model_head_cfg("medium_MANO"), data_preset=pk.CN({}))
+    keys = set(head.state_dict().keys())
+    assert "transformer.pt_metro_encoder.2.flat_verts.weight" in keys
+    assert "transformer.pt_metro_encoder.2.mano_linear.bias" in keys
+    assert keys == set(pk.weights.live_key_shapes(256, parametric=True).keys())
+
+
+def test_no_cpu_fallback():
+    head = pk.build_head(pk.configs.model_head_cfg("small"), data_preset=pk.CN({}))
+    b = pk.inputs.synthetic_batch([2], seed=0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        head(b["mlvl_feat"], b["img_metas"], b["reference_joints"])
+    with pytest.raises(RuntimeError):
+        hip.ptr(torch.zeros(3))
+
+
+# ---- C ABI ------------------------------------------------------------------------------------------------------
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "poem_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(poem_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _header_functions()
+    assert len(names) >= 25
+    L = hip.lib()                                   # loads without a GPU
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/poem_hip.h but not exported"
+    assert sorted(hip.SIGNATURES) == names          # the ctypes table mirrors the header one to one
+    assert L.poem_abi_version() == 1
+    assert L.poem_error_string(-2) == b"workspace too small"
+
+
+def test_library_tensor_table_matches_python():
+    import ctypes
+    L = hip.lib()
+    for model, par in (("small", False), ("medium", False), ("large", False), ("medium", True)):
+        C = pk.weights.MODEL_EMBED[model]
+        cfg = hip.make_config(C, parametric=par)
+        shapes = pk.weights.live_key_shapes(C, parametric=par)
+        assert L.poem_num_weight_tensors(ctypes.byref(cfg)) == len(shapes)
+        for i, s in enumerate(shapes.values()):
+            assert L.poem_weight_tensor_numel(ctypes.byref(cfg), i) == int(np.prod(s))
+        assert L.poem_packed_bytes(ctypes.byref(cfg)) > 0
+    bad = hip.make_config(100)
+    assert L.poem_packed_bytes(ctypes.byref(bad)) == 0
+    assert L.poem_num_weight_tensors(ctypes.byref(bad)) < 0
+    assert L.poem_gemm(None, 8, None, None, None, 0, None, 8, 1, 8, 8, 0, None) == -1     # argument check, no launch
+
+
+# ---- synthetic inputs -------------------------------------------------------------------------------------------
+def test_synthetic_rig_projects_inside_the_image():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import poem_oracle as po
+    b = pk.inputs.synthetic_batch([1, 2, 8, 10], seed=3)
+    m = b["img_metas"]
+    assert m["cam_view_num"].tolist() == [1, 2, 8, 10]
+    offs = np.concatenate([[0], np.cumsum(m["cam_view_num"])])
+    for o in offs[:-1]:
+        assert torch.equal(m["cam_extr"][o], torch.eye(4))          # view 0 = master = identity
+    bps = torch.from_numpy(np.load(os.path.join(hip.ASSETS, "bps.npy")))[0]
+    centre = b["reference_joints"][:, 9]
+    vs = torch.repeat_interleave(torch.arange(4), torch.tensor([1, 2, 8, 10]))
+    uv = po.project_points(bps[None] + centre[:, None], m["cam_intr"], m["cam_extr"], vs)
+    assert float(uv.min()) > 0 and float(uv.max()) < 256
+
+
+# ---- DP glue ----------------------------------------------------------------------------------------------------
+def test_shard_ranges_cover_everything():
+    from poem_v2_amd.dist import shard_by_views, shard_range
+    for n, w in ((32, 8), (33, 8), (5, 8), (64, 3)):
+        got = []
+        for r in range(w):
+            lo, hi = shard_range(n, r, w)
+            got += list(range(lo, hi))
+        assert got == list(range(n))
+    views = np.random.RandomState(5).randint(2, 11, size=64)
+    got = []
+    for r in range(8):
+        lo, hi = shard_by_views(views, r, 8)
+        got += list(range(lo, hi))
+    assert got == list(range(64))
+
+
+_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+import poem_v2_amd as pk
+from poem_v2_amd import dist as pdist
+from poem_v2_amd.metrics import MeanEPE
+rank, local, world = pdist.init_from_env(backend="gloo")
+assert world == 2
+g = torch.Generator().manual_seed(0)
+pred = torch.randn(10, 778, 3, generator=g); gt = torch.randn(10, 778, 3, generator=g)
+lo, hi = pdist.shard_range(10, rank, world)
+m = MeanEPE("v"); m.feed(pred[lo:hi], gt[lo:hi]); m.reduce()
+full = MeanEPE("v"); full.feed(pred, gt)
+assert abs(m.result() - full.result()) < 1e-6, (m.result(), full.result())
+t = torch.tensor([float(rank + 1)], dtype=torch.float64); pdist.all_reduce_max_(t); assert t.item() == 2.0
+pdist.barrier()
+if rank == 0: print("DP_OK", m.result())
+dist.destroy_process_group()
+'''
+
+
+def test_dp_metric_allreduce_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "DP_OK" in out.stdout
