@@ -123,6 +123,17 @@ int poem_pack_linear(const float* w, int out_features, int in_features, void* pa
 /* Y[M,N] = act(X[M,K] . W^T + bias) + residual ; ldx/ldr/ldy in floats; bias/residual may be NULL. */
 int poem_gemm(const float* x, int ldx, const void* w_packed, const float* bias, const float* residual, int ldr,
               float* y, int ldy, int M, int N, int K, int act, void* stream);
+/* Layout-aware GEMM.  Layouts: POEM_LAYOUT_RM (row-major, ld* in floats) or POEM_LAYOUT_PA ("packed activation":
+ * the fragment order of poem_pack_linear applied to the activation rows; buffers hold ceil(M/32)*32 rows; the
+ * residual shares the output layout).  PA->PA chains are how the whole path runs its Linears (coalesced 1 KiB
+ * operand loads and result stores). */
+#define POEM_LAYOUT_RM 0
+#define POEM_LAYOUT_PA 1
+int poem_gemm_ex(const float* x, int ldx, const void* w_packed, const float* bias, const float* residual, int ldr,
+                 float* y, int ldy, int M, int N, int K, int act, int in_layout, int out_layout, void* stream);
+/* row-major (rows, cols) <-> PA; poem_packed_linear_bytes(rows, cols) gives the PA size. */
+int poem_pack_rows(const float* x, int rows, int cols, void* packed, void* stream);
+int poem_unpack_rows(const void* packed, int rows, int cols, float* x, void* stream);
 int poem_layernorm(const float* x, const float* gamma, const float* beta, float* y, int rows, int cols, float eps,
                    void* stream);
 /* table: (sum_{N=1..max_views} N, C, H*W) */

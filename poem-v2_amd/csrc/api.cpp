@@ -14,6 +14,9 @@ extern "C" {
 hipError_t poem_launch_pack_linear(const float* w, int N, int K, void* out, hipStream_t s);
 hipError_t poem_launch_gemm(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
                             float* Y, int ldy, int M, int N, int K, int act, hipStream_t s);
+hipError_t poem_launch_gemm2(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
+                             float* Y, int ldy, int M, int N, int K, int act, int in_pa, int out_pa, hipStream_t s);
+hipError_t poem_launch_unpack_rows(const void* pa, int N, int K, float* out, hipStream_t s);
 hipError_t poem_launch_layernorm(const float* x, const float* g, const float* b, float* y, int rows, int cols,
                                  float eps, hipStream_t s);
 hipError_t poem_launch_narrow_linear(const float* x, int ldx, const float* w, const float* b, const float* base,
@@ -483,6 +486,28 @@ int poem_gemm(const float* x, int ldx, const void* w_packed, const float* bias, 
   if (!x || !w_packed || !y || M <= 0 || N <= 0 || K <= 0 || K % 8 || ldx % 4 || ((uintptr_t)x & 15)) return POEM_E_ARG;
   if (act < 0 || act > 2) return POEM_E_ARG;
   HIPCHK(poem_launch_gemm(x, ldx, w_packed, bias, residual, ldr, y, ldy, M, N, K, act, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_gemm_ex(const float* x, int ldx, const void* w_packed, const float* bias, const float* residual, int ldr,
+                 float* y, int ldy, int M, int N, int K, int act, int in_layout, int out_layout, void* stream) {
+  if (!x || !w_packed || !y || M <= 0 || N <= 0 || K <= 0 || K % 8 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
+    return POEM_E_ARG;
+  if (!in_layout && ldx % 4) return POEM_E_ARG;
+  if (out_layout && N % 32) return POEM_E_ARG;
+  if (act < 0 || act > 2 || (in_layout & ~1) || (out_layout & ~1)) return POEM_E_ARG;
+  HIPCHK(poem_launch_gemm2(x, ldx, w_packed, bias, residual, ldr, y, ldy, M, N, K, act, in_layout, out_layout,
+                           (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_pack_rows(const float* x, int rows, int cols, void* packed, void* stream) {
+  return poem_pack_linear(x, rows, cols, packed, stream);
+}
+
+int poem_unpack_rows(const void* packed, int rows, int cols, float* x, void* stream) {
+  if (!packed || !x || rows <= 0 || cols % 8) return POEM_E_ARG;
+  HIPCHK(poem_launch_unpack_rows(packed, rows, cols, x, (hipStream_t)stream));
   return POEM_OK;
 }
 

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_kernel(const float* __res
 #pragma unroll
   for (int d = 0; d < DT; ++d) o[d] = zero16();
   float m_run = -INFINITY, l_run = 0.f;
-  const float sdh = sqrtf((float)DH);
+  const float inv_sdh = 1.0f / sqrtf((float)DH);   // exact for dh in {16, 64, 256}; <= 1 ulp from the division otherwise
 
   const int ntiles = NK / 32;
   POEM_LOAD_TILE(0)
@@ -92,20 +92,22 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_kernel(const float* __res
       }
       float mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = s[i] / sdh; mx = fmaxf(mx, s[i]); }
+      for (int i = 0; i < 16; ++i) { s[i] = s[i] * inv_sdh; mx = fmaxf(mx, s[i]); }
       mx = fmaxf(mx, xhalf(mx));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = expf(m_run - m_new);
+      const float alpha = (m_new == m_run) ? 1.0f : (m_run == -INFINITY ? 0.0f : exp_neg(m_run - m_new));
       float ps = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = expf(s[i] - m_new); ps += s[i]; }
+      for (int i = 0; i < 16; ++i) { s[i] = exp_neg(s[i] - m_new); ps += s[i]; }
       ps += xhalf(ps);
       l_run = l_run * alpha + ps;
       m_run = m_new;
+      if (__any(alpha != 1.0f)) {   // exact skip: alpha == 1 whenever this lane's running max did not move
 #pragma unroll
-      for (int d = 0; d < DT; ++d) {
+        for (int d = 0; d < DT; ++d) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+          for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+        }
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {

@@ -27,6 +27,19 @@ __device__ __forceinline__ f32x16 zero16() {
 // exchange with the lane 32 positions away (the other half-wave)
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 
+// exp(x) for x <= 0 (softmax numerators) with ~1 ulp accuracy in 6 VALU ops: x*log2(e) is split into a rounded head
+// (fed to the hardware exp2) and an fma-recovered tail applied as a first-order correction.
+__device__ __forceinline__ float exp_neg(float x) {
+  const float L2E_HI = 1.44269502162933349609375f;       // fp32(log2 e)
+  const float L2E_LO = 1.925963033500011e-08f;           // log2 e - fp32(log2 e)
+  const float LN2 = 0.693147180559945309417f;
+  const float t = x * L2E_HI;
+  float e = fmaf(x, L2E_HI, -t);
+  e = fmaf(x, L2E_LO, e);
+  const float r = __builtin_amdgcn_exp2f(t);
+  return fmaf(r, e * LN2, r);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // Packed Linear weight image used by every MFMA kernel here ("fragment order"):

@@ -20,110 +20,191 @@ __global__ void pack_linear_kernel(const float* __restrict__ w, int N, int K, fl
   out[i] = v;
 }
 
+// PA -> row-major (inverse of pack_linear_kernel); one float4 fragment per thread
+__global__ void unpack_rows_kernel(const float4* __restrict__ pa, int N, int K, float* __restrict__ out, int total) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lane = i & 63;
+  int kc = (i >> 6) % (K / 8);
+  int nt = (i >> 6) / (K / 8);
+  int row = nt * 32 + (lane & 31);
+  int col = kc * 8 + 4 * (lane >> 5);
+  if (row < N) *reinterpret_cast<float4*>(out + (size_t)row * K + col) = pa[i];
+}
+
+extern "C" hipError_t poem_launch_unpack_rows(const void* pa, int N, int K, float* out, hipStream_t s) {
+  int total = ((N + 31) / 32) * (K / 8) * 64;
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, s, (const float4*)pa, N, K, out, total);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t poem_launch_pack_linear(const float* w, int N, int K, void* out, hipStream_t s) {
   int total = ((N + 31) / 32) * (K / 8) * 64;
   hipLaunchKernelGGL(pack_linear_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, N, K, (float4*)out, total);
   return hipGetLastError();
 }
 
-template <int NT, int ACT, bool RES>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ X, int ldx, const float4* __restrict__ Wp,
-                                                   const float* __restrict__ bias, const float* __restrict__ R,
-                                                   int ldr, float* __restrict__ Y, int ldy, int M, int N, int K,
-                                                   int col_groups) {
-  const int lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int cg = wave % col_groups;
-  const int m0 = (wave / col_groups) * 64;
-  if (m0 >= M) return;
+// ---------------------------------------------------------------------------------------------------------
+// GEMM: activations may live in "packed-activation" (PA) order -- the same fragment order as the packed weights,
+//   PA[(mt * K/8 + kc) * 64 + lane] = float4( X[32*mt + (lane&31)][8*kc + 4*(lane>>5) + 0..3] )
+// so that BOTH operands are fetched with fully coalesced 1 KiB wave loads.  Writing PA output uses the transposed
+// formulation D[n][m] (A = W fragment, B = X fragment): lane = row m, registers = 16 output channels, i.e. exactly
+// four PA float4 fragments of the result -> coalesced 1 KiB stores, no re-layout between chained GEMMs.
+// Row-major (RM) input/output remain available (plain formulation D[m][n]) for tensors that are gathered by row.
+// The 4 waves of a block share one column group (identical W stream -> L1 hits) and own consecutive row groups.
+template <int MT, int NT, bool IN_PA, bool OUT_PA>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(const float* __restrict__ X, int ldx,
+                                                       const float4* __restrict__ Wp, const float* __restrict__ bias,
+                                                       const float* __restrict__ R, int ldr, float* __restrict__ Y,
+                                                       int ldy, int M, int N, int K, int act) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int rg = blockIdx.x * 4 + (threadIdx.x >> 6);     // row group (MT tiles of 32 rows)
+  const int cg = blockIdx.y;                              // column group (NT tiles of 32 columns)
+  const int mt0 = rg * MT;
+  if (mt0 * 32 >= M) return;
   const int KC = K >> 3;
-  const int row0 = min(m0 + r, M - 1), row1 = min(m0 + 32 + r, M - 1);
-  const float4* xa0 = reinterpret_cast<const float4*>(X + (size_t)row0 * ldx + 4 * h);
-  const float4* xa1 = reinterpret_cast<const float4*>(X + (size_t)row1 * ldx + 4 * h);
+  const float4* xp[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    if (IN_PA) {
+      xp[i] = reinterpret_cast<const float4*>(X) + (size_t)(mt0 + i) * KC * 64 + lane;
+    } else {
+      const int row = min((mt0 + i) * 32 + r, M - 1);
+      xp[i] = reinterpret_cast<const float4*>(X + (size_t)row * ldx + 4 * h);
+    }
+  }
+  constexpr int XSTEP = IN_PA ? 64 : 2;   // float4 stride per k-chunk
   const float4* wp = Wp + (size_t)(cg * NT) * KC * 64 + lane;
 
-  f32x16 acc0[NT], acc1[NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) { acc0[n] = zero16(); acc1[n] = zero16(); }
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[i][n] = zero16();
 
-  float4 a0 = xa0[0], a1 = xa1[0];
-  float4 b[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) b[n] = wp[(size_t)n * KC * 64];
+  // software pipeline, two named register sets (no copies for the compiler to rotate away): the loads of chunk kc+1
+  // are in flight while the 4*MT*NT MFMAs of chunk kc issue.
+  float4 a0[MT], b0[NT], a1[MT], b1[NT];
+#define POEM_LOAD(A, B, KCI)                                                        \
+  {                                                                                 \
+    const int kq_ = min((KCI), KC - 1);                                             \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) A[i] = xp[i][(size_t)kq_ * XSTEP]; \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) B[n] = wp[((size_t)n * KC + kq_) * 64]; \
+  }
+#define POEM_MMA(A, B)                                                              \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                   \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                \
+      const float bv = (&B[n].x)[t];                                                \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) {                              \
+        const float av = (&A[i].x)[t];                                              \
+        acc[i][n] = OUT_PA ? mfma32(bv, av, acc[i][n]) : mfma32(av, bv, acc[i][n]); \
+      }                                                                             \
+    }                                                                               \
+  }
+  // sched_barrier(0) pins the order: without it hipcc sinks every load down to its first use (no prefetch distance).
+  POEM_LOAD(a0, b0, 0)
+  int kc = 0;
+  for (; kc + 1 < KC; kc += 2) {
+    POEM_LOAD(a1, b1, kc + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_MMA(a0, b0)
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_LOAD(a0, b0, kc + 2)
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_MMA(a1, b1)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (kc < KC) { POEM_MMA(a0, b0) }   // odd K/8: the last chunk is already in (a0, b0)
+#undef POEM_LOAD
+#undef POEM_MMA
 
-  for (int kc = 0; kc < KC; ++kc) {
-    const int kn = min(kc + 1, KC - 1);
-    float4 na0 = xa0[kn * 2], na1 = xa1[kn * 2];
-    float4 nb[NT];
+  if (OUT_PA) {
+    const int KCO = N >> 3;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) nb[n] = wp[((size_t)n * KC + kn) * 64];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float av0 = (&a0.x)[t], av1 = (&a1.x)[t];
+    for (int i = 0; i < MT; ++i) {
+      if ((mt0 + i) * 32 >= M) break;
+      float4* yp = reinterpret_cast<float4*>(Y) + (size_t)(mt0 + i) * KCO * 64 + lane;
+      const float4* rp = reinterpret_cast<const float4*>(R) + (size_t)(mt0 + i) * KCO * 64 + lane;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const float bv = (&b[n].x)[t];
-        acc0[n] = mfma32(av0, bv, acc0[n]);
-        acc1[n] = mfma32(av1, bv, acc1[n]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = (cg * NT + n) * 32 + 8 * g + 4 * h;
+          const int kco = (cg * NT + n) * 4 + g;
+          float4 v = make_float4(acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+          if (bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(bias + c0);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+          }
+          if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (act == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+          if (R) {
+            const float4 rr = rp[(size_t)kco * 64];
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          yp[(size_t)kco * 64] = v;
+        }
       }
     }
-    a0 = na0; a1 = na1;
+  } else {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) b[n] = nb[n];
-  }
-
+    for (int n = 0; n < NT; ++n) {
+      const int col = (cg * NT + n) * 32 + r;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int col = (cg * NT + n) * 32 + r;
-    if (col >= N) continue;
-    const float bv = bias ? bias[col] : 0.f;
+      for (int i = 0; i < MT; ++i) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = m0 + mi * 32 + mfma_row(i, h);
-        if (row < M) {
-          float v = (mi == 0 ? acc0[n][i] : acc1[n][i]) + bv;
-          if (ACT == 1) v = fmaxf(v, 0.f);
-          if (ACT == 2) v = gelu_erf(v);
-          if (RES) v += R[(size_t)row * ldr + col];
-          Y[(size_t)row * ldy + col] = v;
+        for (int e = 0; e < 16; ++e) {
+          const int row = (mt0 + i) * 32 + mfma_row(e, h);
+          if (row < M) {
+            float v = acc[i][n][e] + bv;
+            if (act == 1) v = fmaxf(v, 0.f);
+            if (act == 2) v = gelu_erf(v);
+            if (R) v += R[(size_t)row * ldr + col];
+            Y[(size_t)row * ldy + col] = v;
+          }
         }
       }
     }
   }
 }
 
-template <int NT>
-static hipError_t launch_gemm_nt(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
-                                 float* Y, int ldy, int M, int N, int K, int act, hipStream_t s) {
-  const int ntiles = (N + 31) / 32;
-  const int col_groups = ntiles / NT;
-  const long waves = (long)((M + 63) / 64) * col_groups;
-  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-#define POEM_GEMM_CASE(A, RS)                                                                                       \
-  hipLaunchKernelGGL((gemm_kernel<NT, A, RS>), grid, block, 0, s, X, ldx, (const float4*)Wp, bias, R, ldr, Y, ldy, \
-                     M, N, K, col_groups)
-  if (R) {
-    if (act == 0) POEM_GEMM_CASE(0, true);
-    else if (act == 1) POEM_GEMM_CASE(1, true);
-    else POEM_GEMM_CASE(2, true);
-  } else {
-    if (act == 0) POEM_GEMM_CASE(0, false);
-    else if (act == 1) POEM_GEMM_CASE(1, false);
-    else POEM_GEMM_CASE(2, false);
-  }
-#undef POEM_GEMM_CASE
+template <int MT, int NT>
+static hipError_t launch_gemm2_t(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
+                                 float* Y, int ldy, int M, int N, int K, int act, int in_pa, int out_pa, hipStream_t s) {
+  const int ntiles = (N + 31) / 32, mtiles = (M + 31) / 32;
+  const int rgroups = (mtiles + MT - 1) / MT;
+  dim3 grid((unsigned)((rgroups + 3) / 4), (unsigned)(ntiles / NT)), block(256);
+#define POEM_G2(IP, OP)                                                                                              \
+  hipLaunchKernelGGL((gemm2_kernel<MT, NT, IP, OP>), grid, block, 0, s, X, ldx, (const float4*)Wp, bias, R, ldr, Y, \
+                     ldy, M, N, K, act)
+  if (in_pa && out_pa) POEM_G2(true, true);
+  else if (in_pa) POEM_G2(true, false);
+  else if (out_pa) POEM_G2(false, true);
+  else POEM_G2(false, false);
+#undef POEM_G2
   return hipGetLastError();
+}
+
+// in_pa / out_pa: operand layouts (0 = row-major with ld*, 1 = packed-activation; PA buffers hold ceil(M/32)*32 rows
+// and the residual shares the output's layout).  PA output needs N % 32 == 0.
+extern "C" hipError_t poem_launch_gemm2(const float* X, int ldx, const void* Wp, const float* bias, const float* R,
+                                        int ldr, float* Y, int ldy, int M, int N, int K, int act, int in_pa, int out_pa,
+                                        hipStream_t s) {
+  const int ntiles = (N + 31) / 32, mtiles = (M + 31) / 32;
+  const bool big = (long)mtiles * ntiles >= 4096 * 4;   // enough 32x32 tiles to fill the chip with 64x128 wave tiles
+  if (ntiles % 4 == 0) {
+    if (big) return launch_gemm2_t<2, 4>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, in_pa, out_pa, s);
+    return launch_gemm2_t<1, 2>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, in_pa, out_pa, s);
+  }
+  if (ntiles % 2 == 0) return launch_gemm2_t<1, 2>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, in_pa, out_pa, s);
+  return launch_gemm2_t<1, 1>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, in_pa, out_pa, s);
 }
 
 extern "C" hipError_t poem_launch_gemm(const float* X, int ldx, const void* Wp, const float* bias, const float* R,
                                        int ldr, float* Y, int ldy, int M, int N, int K, int act, hipStream_t s) {
-  const int ntiles = (N + 31) / 32;
-  if (ntiles % 4 == 0) return launch_gemm_nt<4>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, s);
-  if (ntiles % 2 == 0) return launch_gemm_nt<2>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, s);
-  return launch_gemm_nt<1>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, s);
+  return poem_launch_gemm2(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, 0, 0, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -38,36 +38,51 @@ struct VecAttnArgs {
 template <int C, int P, int NW, int TPW, bool FLIP>
 __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const float* __restrict__ X,
                                            f32x16 (&acc)[TPW][P], int wv, int lane) {
-  constexpr int KC = C / 8;
+  constexpr int KC = C / 8;      // even for every supported C
   constexpr int XS = 32 * P;
   const int j = lane & 31, h = lane >> 5;
   const float4* wp = Wp + (size_t)(wv * TPW) * KC * 64 + lane;
   const float* xc = X + (4 * h) * XS + j;
-  float4 a[TPW];
-#pragma unroll
-  for (int tp = 0; tp < TPW; ++tp) a[tp] = wp[(size_t)tp * KC * 64];
-#pragma unroll 2
-  for (int kc = 0; kc < KC; ++kc) {
-    const int kn = min(kc + 1, KC - 1);
-    float4 na[TPW];
-#pragma unroll
-    for (int tp = 0; tp < TPW; ++tp) na[tp] = wp[((size_t)tp * KC + kn) * 64];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float xb[P];
-#pragma unroll
-      for (int p = 0; p < P; ++p) xb[p] = xc[(kc * 8 + t) * XS + 32 * p];
-#pragma unroll
-      for (int tp = 0; tp < TPW; ++tp) {
-        const float av = (&a[tp].x)[t];
-#pragma unroll
-        for (int p = 0; p < P; ++p)
-          acc[tp][p] = FLIP ? mfma32(xb[p], av, acc[tp][p]) : mfma32(av, xb[p], acc[tp][p]);
-      }
-    }
-#pragma unroll
-    for (int tp = 0; tp < TPW; ++tp) a[tp] = na[tp];
+  // Two-stage software pipeline with pinned order (sched_barrier): the weight fragments of chunk kc+1 and the LDS
+  // operand of k-step t+1 are in flight while the MFMAs of k-step t issue.  Left to itself hipcc sinks every load to
+  // its first use and the wave stalls on L2/LDS latency in front of each MFMA group.
+  float4 a0[TPW], a1[TPW];
+  float xa[P], xb[P];
+#define VA_LOADW(A, KCI)                                                                  \
+  {                                                                                       \
+    const int kq_ = min((KCI), KC - 1);                                                   \
+    _Pragma("unroll") for (int tp = 0; tp < TPW; ++tp) A[tp] = wp[((size_t)tp * KC + kq_) * 64]; \
   }
+#define VA_READX(XR, KCI, T)                                                              \
+  {                                                                                       \
+    const int kq_ = min((KCI), KC - 1);                                                   \
+    _Pragma("unroll") for (int p = 0; p < P; ++p) XR[p] = xc[(kq_ * 8 + (T)) * XS + 32 * p]; \
+  }
+#define VA_MMA(A, T, XR)                                                                  \
+  _Pragma("unroll") for (int tp = 0; tp < TPW; ++tp) {                                    \
+    const float av = (&A[tp].x)[T];                                                       \
+    _Pragma("unroll") for (int p = 0; p < P; ++p)                                         \
+      acc[tp][p] = FLIP ? mfma32(XR[p], av, acc[tp][p]) : mfma32(av, XR[p], acc[tp][p]);  \
+  }
+#define VA_CHUNK(A, KCI)                                                                  \
+  VA_READX(xb, KCI, 1) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 0, xa) __builtin_amdgcn_sched_barrier(0); \
+  VA_READX(xa, KCI, 2) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 1, xb) __builtin_amdgcn_sched_barrier(0); \
+  VA_READX(xb, KCI, 3) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 2, xa) __builtin_amdgcn_sched_barrier(0); \
+  VA_READX(xa, (KCI) + 1, 0) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 3, xb) __builtin_amdgcn_sched_barrier(0);
+  VA_LOADW(a0, 0)
+  VA_READX(xa, 0, 0)
+  for (int kc = 0; kc < KC; kc += 2) {
+    VA_LOADW(a1, kc + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    VA_CHUNK(a0, kc)
+    VA_LOADW(a0, kc + 2)
+    __builtin_amdgcn_sched_barrier(0);
+    VA_CHUNK(a1, kc + 1)
+  }
+#undef VA_LOADW
+#undef VA_READX
+#undef VA_MMA
+#undef VA_CHUNK
 }
 
 template <int C, int P, int NW, int MINW>
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   const int groups = (A.Q + P - 1) / P;
   const int b = blockIdx.x / groups;
   const int i0 = (blockIdx.x % groups) * P;
-  const float inv_sqrt_c_den = sqrtf((float)C);
+  const float inv_sqrt_c = 1.0f / sqrtf((float)C);   // exact for C in {64, 256, 1024}; <= 1 ulp from the division otherwise
 
   // ---- stage 0: neighbour ids, coordinate deltas, first-layer activations h = relu(W_d1 delta + b_d1) -> X
   if (tid < 32 * P) {
@@ -200,17 +215,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       float mx = -INFINITY;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        acc[tp][p][i] = (acc[tp][p][i] + bg) / inv_sqrt_c_den;
+        acc[tp][p][i] = (acc[tp][p][i] + bg) * inv_sqrt_c;
         mx = fmaxf(mx, acc[tp][p][i]);
       }
       mx = fmaxf(mx, xhalf(mx));
       float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { acc[tp][p][i] = expf(acc[tp][p][i] - mx); sum += acc[tp][p][i]; }
+      for (int i = 0; i < 16; ++i) { acc[tp][p][i] = exp_neg(acc[tp][p][i] - mx); sum += acc[tp][p][i]; }
       sum += xhalf(sum);
+      const float inv_sum = 1.0f / sum;
       float res = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) res = fmaf(acc[tp][p][i] / sum, val[i], res);
+      for (int i = 0; i < 16; ++i) res = fmaf(acc[tp][p][i] * inv_sum, val[i], res);
       res += xhalf(res);
       if (h == 0 && i0 + p < A.Q) A.out[((size_t)b * A.Q + i0 + p) * C + cch] = res;
     }

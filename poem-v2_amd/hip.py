@@ -49,6 +49,9 @@ SIGNATURES = {
     "poem_packed_linear_bytes": (_sz, [_i, _i]),
     "poem_pack_linear": (_i, [_vp, _i, _i, _vp, _vp]),
     "poem_gemm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "poem_gemm_ex": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "poem_pack_rows": (_i, [_vp, _i, _i, _vp, _vp]),
+    "poem_unpack_rows": (_i, [_vp, _i, _i, _vp, _vp]),
     "poem_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "poem_pe_table": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "poem_input_proj": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -263,6 +266,29 @@ def gemm(x, w_packed, n_out, bias=None, residual=None, act=ACT_NONE):
     y = torch.empty(M, n_out, dtype=torch.float32, device=x.device)
     check(lib().poem_gemm(ptr(x), K, w_packed.data_ptr(), ptr(bias), ptr(residual), n_out, ptr(y), n_out, M, n_out, K,
                           act, stream()), "poem_gemm")
+    return y
+
+
+def pack_rows(x):
+    """(rows, cols) row-major -> packed-activation image (uint8 buffer)."""
+    return pack_linear(x)
+
+
+def unpack_rows(pa, rows, cols):
+    x = torch.empty(rows, cols, dtype=torch.float32, device=pa.device)
+    check(lib().poem_unpack_rows(pa.data_ptr(), rows, cols, ptr(x), stream()), "poem_unpack_rows")
+    return x
+
+
+def gemm_ex(x, w_packed, M, n_out, K, bias=None, residual=None, act=ACT_NONE, in_pa=False, out_pa=False):
+    """x / residual / result are row-major tensors or PA byte buffers according to the layout flags."""
+    if out_pa:
+        y = torch.empty(lib().poem_packed_linear_bytes(M, n_out), dtype=torch.uint8, device=x.device)
+    else:
+        y = torch.empty(M, n_out, dtype=torch.float32, device=x.device)
+    rptr = None if residual is None else residual.data_ptr()
+    check(lib().poem_gemm_ex(x.data_ptr(), K, w_packed.data_ptr(), ptr(bias), rptr, n_out, y.data_ptr(), n_out, M, n_out,
+                             K, act, int(in_pa), int(out_pa), stream()), "poem_gemm_ex")
     return y
 
 

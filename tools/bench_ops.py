@@ -1,0 +1,48 @@
+"""Operator micro-benchmarks on the GPU box (development tool, not part of the product or the bench contract)."""
+import sys, os, math, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import poem_v2_amd as pk
+from poem_v2_amd import hip
+
+dev = "cuda:0"
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+def gemm_cases():
+    for (M, N, K) in [(131072, 256, 256), (25568, 256, 256), (1048576, 256, 256), (25568, 1024, 256), (25568, 256, 1024),
+                      (1048576, 128, 256)]:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev) / math.sqrt(K)
+        b = torch.randn(N, device=dev)
+        wp = hip.pack_linear(w)
+        xp = hip.pack_rows(x)
+        ref = torch.nn.functional.linear(x[:4096].double(), w.double(), b.double())
+        fl = 2.0 * M * N * K
+        t0 = timeit(lambda: hip.gemm(x, wp, N, bias=b))
+        line = f"M={M:8d} N={N:5d} K={K:5d}  v1 RM->RM {t0*1e3:8.1f}us {fl/t0/1e9:6.1f}TF"
+        for ip in (False, True):
+            for op in (False, True):
+                xin = xp if ip else x
+                y = hip.gemm_ex(xin, wp, M, N, K, bias=b, in_pa=ip, out_pa=op)
+                yy = hip.unpack_rows(y, M, N) if op else y
+                err = float((yy[:4096].double() - ref).abs().max())
+                t = timeit(lambda: hip.gemm_ex(xin, wp, M, N, K, bias=b, in_pa=ip, out_pa=op))
+                line += f" | {'PA' if ip else 'RM'}->{'PA' if op else 'RM'} {t*1e3:7.1f}us {fl/t/1e9:6.1f}TF e={err:.0e}"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    gemm_cases()
