@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--model", default="medium", choices=list(pk.weights.MODEL_EMBED))
     ap.add_argument("--cpu-samples", type=int, default=4, help="0 disables the CPU baseline leg")
+    ap.add_argument("--overlap", type=int, default=1, help="0: issue every kernel on one stream (A/B of the side streams)")
     args = ap.parse_args()
 
     rank, local_rank, world = pdist.init_from_env()
@@ -139,6 +140,10 @@ def main():
         for _ in range(args.warmup):
             step()
         eng = head._engine
+        if not args.overlap:
+            eng.set_overlap(False)
+            for _ in range(args.warmup):
+                step()
         eng.profile_enable(6 * args.steps)
         meter.reset()
         pdist.barrier()

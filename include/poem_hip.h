@@ -104,6 +104,10 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
 int poem_decoder_forward(poem_handle_t h, const float* query_xyz, const float* query_feat, const float* pt_xyz,
                          const float* pt_feats, int batch, float* out_xyz_norm, float* pose_aa, float* betas,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Stream overlap (default on): the basis-point-side projections of all blocks and the neighbour searches run on two
+ * internal side streams ordered against `stream` by events; everything is joined back before the call returns its
+ * last launch, so the caller only ever synchronises its own stream.  0 = issue everything on `stream` in order. */
+int poem_set_overlap(poem_handle_t h, int enable);
 int poem_finalize_parametric(poem_handle_t h, const float* mano_verts, const float* mano_joints,
                              const float* reference_joints, int batch, float* out_xyz, void* stream);
 /* Timing of the dominant kernel (the fused vector attention) with HIP events recorded on the launch stream around

@@ -142,6 +142,12 @@ struct poem_handle_s {
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
   int prof_used = 0;
   bool prof_on = false;
+  // Side streams: the basis-point-side projections of every block (they depend only on bps_feat and the weights) and
+  // the neighbour searches run beside the query-side chain; events order them against the caller's stream.
+  hipStream_t bps_stream = nullptr, knn_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join_bps = nullptr, ev_join_knn = nullptr;
+  hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {};
+  bool overlap = true;
   int block_base(int b) const { return T_HEAD_COUNT + b * (cfg.parametric ? B_COUNT_PARAM : B_COUNT); }
   const float* R(int idx) const { return raw[idx]; }
   const void* P(int idx) const { return packed[idx]; }
@@ -183,8 +189,9 @@ struct Plan {
   // sampling stage
   float *x, *uv, *g, *h1, *h2, *mm, *mh, *y, *bps_feat, *centre, *pt_xyz, *xyz[9];
   // decoder (per call scratch)
-  float *feats0, *qe, *ke, *qp, *kp, *vp, *ctx, *att, *h_attn, *xs, *qs, *ks, *vs, *rs, *qc, *xk, *kc, *vc, *rc, *regh,
-      *ffh, *ffo;
+  float *feats0, *qe, *qp, *ctx, *att, *h_attn, *xs, *qs, *ks, *vs, *rs, *qc, *rc, *regh, *ffh, *ffo;
+  // basis-point side, one set per block (produced ahead of time on the side stream)
+  float *ke[8], *kp[8][2], *vp[8][2], *xk[8], *kc[8], *vc[8];
   // per block kept tensors (taps)
   float *h_cross[8], *f_self[8], *f_cross[8], *feats[8];
   float *q3t, *par;
@@ -215,10 +222,7 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   for (int i = 0; i <= c.nblocks; ++i) p.xyz[i] = xyz_all ? xyz_all + (size_t)i * BQ * 3 : nullptr;
   p.feats0 = a.take<float>(BQ * C);
   p.qe = a.take<float>(BQ * C);
-  p.ke = a.take<float>(BS * C);
   p.qp = a.take<float>(BQ * C);
-  p.kp = a.take<float>(BS * C);
-  p.vp = a.take<float>(BS * C);
   p.ctx = a.take<float>(BQ * C);
   p.att = a.take<float>(BQ * C);
   p.h_attn = a.take<float>(BQ * C);
@@ -228,9 +232,6 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   p.vs = a.take<float>(BQ * C);
   p.rs = a.take<float>(BQ * C);
   p.qc = a.take<float>(BQ * C);
-  p.xk = a.take<float>(BS * C);
-  p.kc = a.take<float>(BS * C);
-  p.vc = a.take<float>(BS * C);
   p.rc = a.take<float>(BQ * C);
   p.regh = a.take<float>(BQ * C);
   p.ffh = a.take<float>(BQ * C * 4);
@@ -242,6 +243,11 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
     p.feats[i] = a.take<float>(BQ * C);
     p.idx_self[i] = a.take<int32_t>(BQ * 32);
     p.idx_cross[i] = a.take<int32_t>(BQ * 32);
+    p.ke[i] = a.take<float>(BS * C);
+    for (int k = 0; k < 2; ++k) { p.kp[i][k] = a.take<float>(BS * C); p.vp[i][k] = a.take<float>(BS * C); }
+    p.xk[i] = a.take<float>(BS * C);
+    p.kc[i] = a.take<float>(BS * C);
+    p.vc[i] = a.take<float>(BS * C);
   }
   p.q3t = a.take<float>((size_t)B * C);
   p.par = a.take<float>((size_t)B * 106);
@@ -251,48 +257,95 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
 }  // namespace
 
 // Decoder (PtEmbedTRv4.forward): p.xyz[0] holds the initial normalised query coordinates; writes p.xyz[1..nblocks].
+//
+// Three HIP streams.  The caller's stream `s` carries the query-side chain (the critical path).  Everything that
+// depends only on the basis-point features -- ke = embedding(pt_feats) and the key/value projections of both BERT
+// cross attentions and of the vector cross attention, for EVERY block -- is issued up front on `bps_stream`; the
+// neighbour searches of block i (they need only xyz_i) go to `knn_stream`.  The small, latency-bound query-side
+// kernels thereby share the chip with the large basis-point GEMMs instead of leaving it half empty.
 static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const float* pt_xyz, const float* pt_feats, int B,
                        float* pose_aa, float* betas, hipStream_t s) {
   const poem_config_t& c = h->cfg;
   const int C = c.embed, S = c.nsample, Q = c.nquery;
   const int BS = B * S, BQ = B * Q;
-#define GEMM(X, LDX, WI, BI, RES, LDR, Y, LDY, M, N, K, ACT) \
-  HIPCHK(poem_launch_gemm(X, LDX, h->P(WI), (BI) >= 0 ? h->R(BI) : nullptr, RES, LDR, Y, LDY, M, N, K, ACT, s))
+  const bool ov = h->overlap && h->bps_stream && h->knn_stream;
+  hipStream_t sb = ov ? h->bps_stream : s;     // basis-point side
+  hipStream_t sk = ov ? h->knn_stream : s;     // neighbour searches
+#define GEMM_ON(ST, X, LDX, WI, BI, RES, LDR, Y, LDY, M, N, K, ACT) \
+  HIPCHK(poem_launch_gemm(X, LDX, h->P(WI), (BI) >= 0 ? h->R(BI) : nullptr, RES, LDR, Y, LDY, M, N, K, ACT, ST))
+#define GEMM(...) GEMM_ON(s, __VA_ARGS__)
 #define PROF_START()                                                                              \
   const bool prof_ = h->prof_on && (size_t)(2 * h->prof_used + 1) < h->prof_ev.size();           \
   if (prof_) HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_used], s))
 #define PROF_STOP()                                                                               \
   if (prof_) { HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_used + 1], s)); ++h->prof_used; }
+
+  // ---- basis-point side of every block (side stream) -------------------------------------------------------------
+  if (ov) {
+    HIPCHK(hipEventRecord(h->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(sb, h->ev_fork, 0));
+    HIPCHK(hipStreamWaitEvent(sk, h->ev_fork, 0));
+  }
+  auto bps_side = [&](int i) -> int {
+    const int bb = h->block_base(i);
+    GEMM_ON(sb, pt_feats, C, bb + B_EMB_W, bb + B_EMB_B, nullptr, 0, p.ke[i], C, BS, C, C, POEM_ACT_NONE);
+    for (int a = 0; a < 2; ++a) {
+      const int ab = bb + (a == 0 ? B_A1 : B_A2);
+      GEMM_ON(sb, p.ke[i], C, ab + 2, ab + 3, nullptr, 0, p.kp[i][a], C, BS, C, C, POEM_ACT_NONE);
+      GEMM_ON(sb, p.ke[i], C, ab + 4, ab + 5, nullptr, 0, p.vp[i][a], C, BS, C, C, POEM_ACT_NONE);
+    }
+    // vector cross-attention sources: fc1 / w_k / w_v hoisted from the gathered rows to the S source rows
+    const int vcb = bb + B_VC;
+    GEMM_ON(sb, p.ke[i], C, vcb + 0, vcb + 1, nullptr, 0, p.xk[i], C, BS, C, C, POEM_ACT_NONE);
+    GEMM_ON(sb, p.xk[i], C, vcb + 13, -1, nullptr, 0, p.kc[i], C, BS, C, C, POEM_ACT_NONE);
+    GEMM_ON(sb, p.xk[i], C, vcb + 14, -1, nullptr, 0, p.vc[i], C, BS, C, C, POEM_ACT_NONE);
+    if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));
+    return POEM_OK;
+  };
+  if (ov) {
+    for (int i = 0; i < c.nblocks; ++i) {
+      const int rc = bps_side(i);
+      if (rc != POEM_OK) return rc;
+    }
+  }
+
   const float* feats = feats_in;
   for (int i = 0; i < c.nblocks; ++i) {
     const int bb = h->block_base(i);
     const float* xyz = p.xyz[i];
-    GEMM(feats, C, bb + B_EMB_W, bb + B_EMB_B, nullptr, 0, p.qe, C, BQ, C, C, POEM_ACT_NONE);
-    GEMM(pt_feats, C, bb + B_EMB_W, bb + B_EMB_B, nullptr, 0, p.ke, C, BS, C, C, POEM_ACT_NONE);
-    const float* hidden = p.qe;
-    for (int a = 0; a < 2; ++a) {
-      const int ab = bb + (a == 0 ? B_A1 : B_A2);
-      float* hout = a == 0 ? p.h_attn : p.h_cross[i];
-      GEMM(hidden, C, ab + 0, ab + 1, nullptr, 0, p.qp, C, BQ, C, C, POEM_ACT_NONE);
-      GEMM(p.ke, C, ab + 2, ab + 3, nullptr, 0, p.kp, C, BS, C, C, POEM_ACT_NONE);
-      GEMM(p.ke, C, ab + 4, ab + 5, nullptr, 0, p.vp, C, BS, C, C, POEM_ACT_NONE);
-      HIPCHK(poem_launch_cross_attention(p.qp, p.kp, p.vp, p.ctx, B, Q, S, C, c.heads, s));
-      GEMM(p.ctx, C, ab + 6, ab + 7, hidden, C, p.att, C, BQ, C, C, POEM_ACT_NONE);
-      HIPCHK(poem_launch_layernorm(p.att, h->R(ab + 8), h->R(ab + 9), hout, BQ, C, c.ln_eps, s));
-      hidden = hout;
-    }
     // neighbours (block 0: the fixed anchors for both attentions -- Q2)
     const int* idx_s = h->anchor_idx;
     const int* idx_c = h->anchor_idx;
     const float* anchor = h->anchor;
     int shared = 1;
     if (i > 0) {
-      HIPCHK(poem_launch_knn(xyz, xyz, p.idx_self[i], B, Q, Q, s));
-      HIPCHK(poem_launch_knn(xyz, pt_xyz, p.idx_cross[i], B, Q, S, s));
+      if (ov) {
+        HIPCHK(hipEventRecord(h->ev_xyz[i], s));          // xyz_i is final here (written at the end of block i-1)
+        HIPCHK(hipStreamWaitEvent(sk, h->ev_xyz[i], 0));
+      }
+      HIPCHK(poem_launch_knn(xyz, xyz, p.idx_self[i], B, Q, Q, sk));
+      HIPCHK(poem_launch_knn(xyz, pt_xyz, p.idx_cross[i], B, Q, S, sk));
+      if (ov) HIPCHK(hipEventRecord(h->ev_knn[i], sk));
       idx_s = p.idx_self[i];
       idx_c = p.idx_cross[i];
       anchor = nullptr;
       shared = 0;
+    }
+    if (!ov) {
+      const int rc = bps_side(i);
+      if (rc != POEM_OK) return rc;
+    }
+    GEMM(feats, C, bb + B_EMB_W, bb + B_EMB_B, nullptr, 0, p.qe, C, BQ, C, C, POEM_ACT_NONE);
+    const float* hidden = p.qe;
+    for (int a = 0; a < 2; ++a) {
+      const int ab = bb + (a == 0 ? B_A1 : B_A2);
+      float* hout = a == 0 ? p.h_attn : p.h_cross[i];
+      GEMM(hidden, C, ab + 0, ab + 1, nullptr, 0, p.qp, C, BQ, C, C, POEM_ACT_NONE);
+      if (ov && a == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
+      HIPCHK(poem_launch_cross_attention(p.qp, p.kp[i][a], p.vp[i][a], p.ctx, B, Q, S, C, c.heads, s));
+      GEMM(p.ctx, C, ab + 6, ab + 7, hidden, C, p.att, C, BQ, C, C, POEM_ACT_NONE);
+      HIPCHK(poem_launch_layernorm(p.att, h->R(ab + 8), h->R(ab + 9), hout, BQ, C, c.ln_eps, s));
+      hidden = hout;
     }
     // vector self-attention over the queries
     const int vsb = bb + B_VS;
@@ -300,6 +353,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     GEMM(p.xs, C, vsb + 12, -1, nullptr, 0, p.qs, C, BQ, C, C, POEM_ACT_NONE);
     GEMM(p.xs, C, vsb + 13, -1, nullptr, 0, p.ks, C, BQ, C, C, POEM_ACT_NONE);
     GEMM(p.xs, C, vsb + 14, -1, nullptr, 0, p.vs, C, BQ, C, C, POEM_ACT_NONE);
+    if (ov && i > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
     {
     PROF_START();
     HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.qs, p.ks, p.vs, Q, h->R(vsb + 4), h->R(vsb + 5),
@@ -308,15 +362,12 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     PROF_STOP();
     }
     GEMM(p.rs, C, vsb + 2, vsb + 3, hidden, C, p.f_self[i], C, BQ, C, C, POEM_ACT_NONE);
-    // vector cross-attention over the basis points (fc1 / w_k / w_v hoisted to the S source rows)
+    // vector cross-attention over the basis points
     const int vcb = bb + B_VC;
     GEMM(p.f_self[i], C, vcb + 12, -1, nullptr, 0, p.qc, C, BQ, C, C, POEM_ACT_NONE);
-    GEMM(p.ke, C, vcb + 0, vcb + 1, nullptr, 0, p.xk, C, BS, C, C, POEM_ACT_NONE);
-    GEMM(p.xk, C, vcb + 13, -1, nullptr, 0, p.kc, C, BS, C, C, POEM_ACT_NONE);
-    GEMM(p.xk, C, vcb + 14, -1, nullptr, 0, p.vc, C, BS, C, C, POEM_ACT_NONE);
     {
     PROF_START();
-    HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.kc, p.vc, S, h->R(vcb + 4),
+    HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.kc[i], p.vc[i], S, h->R(vcb + 4),
                                         h->R(vcb + 5), h->P(vcb + 6), h->R(vcb + 7), h->P(vcb + 8), h->R(vcb + 9),
                                         h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, s));
     PROF_STOP();
@@ -336,7 +387,14 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       HIPCHK(poem_launch_rot6d_to_aa(p.par, pose_aa, betas, B, s));
     }
   }
+  if (ov) {   // every side-stream product has been consumed behind an event; join so the caller's stream owns the tail
+    HIPCHK(hipEventRecord(h->ev_join_bps, sb));
+    HIPCHK(hipEventRecord(h->ev_join_knn, sk));
+    HIPCHK(hipStreamWaitEvent(s, h->ev_join_bps, 0));
+    HIPCHK(hipStreamWaitEvent(s, h->ev_join_knn, 0));
+  }
 #undef GEMM
+#undef GEMM_ON
 #undef PROF_START
 #undef PROF_STOP
   return POEM_OK;
@@ -453,6 +511,14 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   rc = poem_pe_table(h->P(T_ADAPT_W), h->R(T_ADAPT_B), C, cfg->feat_h, cfg->feat_w, cfg->max_views, sine, h->pe_table,
                      stream);
   if (rc != POEM_OK) { delete h; return rc; }
+  {
+    bool ok = hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess;
+    auto mk = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
+    mk(&h->ev_fork); mk(&h->ev_join_bps); mk(&h->ev_join_knn);
+    for (int i = 0; i < 8; ++i) { mk(&h->ev_bps[i]); mk(&h->ev_xyz[i]); mk(&h->ev_knn[i]); }
+    if (!ok) { poem_destroy(h); return POEM_E_LAUNCH; }
+  }
   *out = h;
   return POEM_OK;
 }
@@ -460,7 +526,18 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
 void poem_destroy(poem_handle_t h) {
   if (!h) return;
   for (auto e : h->prof_ev) (void)hipEventDestroy(e);
+  auto de = [](hipEvent_t e) { if (e) (void)hipEventDestroy(e); };
+  de(h->ev_fork); de(h->ev_join_bps); de(h->ev_join_knn);
+  for (int i = 0; i < 8; ++i) { de(h->ev_bps[i]); de(h->ev_xyz[i]); de(h->ev_knn[i]); }
+  if (h->bps_stream) (void)hipStreamDestroy(h->bps_stream);
+  if (h->knn_stream) (void)hipStreamDestroy(h->knn_stream);
   delete h;
+}
+
+int poem_set_overlap(poem_handle_t h, int enable) {
+  if (!h) return POEM_E_ARG;
+  h->overlap = enable != 0;
+  return POEM_OK;
 }
 
 int poem_enable_taps(poem_handle_t h, int enable) {

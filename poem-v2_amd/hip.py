@@ -48,6 +48,7 @@ SIGNATURES = {
     "poem_profile_read": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_f), _i]),
     "poem_packed_linear_bytes": (_sz, [_i, _i]),
     "poem_pack_linear": (_i, [_vp, _i, _i, _vp, _vp]),
+    "poem_set_overlap": (_i, [_vp, _i]),
     "poem_gemm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_gemm_ex": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "poem_pack_rows": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -195,6 +196,9 @@ class Engine:
     def enable_taps(self, flag=True):
         self._taps = bool(flag)
         check(lib().poem_enable_taps(self.handle, int(flag)))
+
+    def set_overlap(self, flag=True):
+        check(lib().poem_set_overlap(self.handle, int(flag)), "poem_set_overlap")
 
     def profile_enable(self, max_launches):
         check(lib().poem_profile_enable(self.handle, int(max_launches)), "poem_profile_enable")

@@ -1,0 +1,238 @@
+// Development lab (not product): fp32-MFMA GEMM variants timed with HIP events on random data.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o gemm_lab gemm_lab.hip
+#include "../../poem-v2_amd/csrc/gemm.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <vector>
+#include <cmath>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+// W panel resident in LDS, persistent waves streaming X in packed-activation order.
+// block = NWV waves, one block per CU.  Panel = NT column tiles (NT*32 columns) x K.
+// MODE bit0: never store (runtime-opaque predicate), bit1: X from an L2-resident window, bit2: skip MFMAs of odd chunks
+template <int K, int NT, int MT, int NWV, int MODE>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_wres_kernel(const float4* __restrict__ X, const float4* __restrict__ Wp,
+                                                          const float* __restrict__ bias, float4* __restrict__ Y,
+                                                          int M, int N, int act, int blocks_per_panel, long long* dbg) {
+  constexpr int KC = K / 8;
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];   // NT*KC*64 float4
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
+  const int panel = blockIdx.x / blocks_per_panel, bip = blockIdx.x % blocks_per_panel;
+  {
+    const float4* src = Wp + (size_t)panel * NT * KC * 64;
+    for (int i = tid; i < NT * KC * 64; i += NWV * 64) wl[i] = src[i];
+  }
+  __syncthreads();
+  const int mtiles = (M + 31) / 32;
+  const int rgroups = (mtiles + MT - 1) / MT;
+  const int KCO = N >> 3;
+  for (int rg = bip * NWV + wv; rg < rgroups; rg += blocks_per_panel * NWV) {
+    const int mt0 = rg * MT;
+    const float4* xp[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      xp[i] = X + (size_t)((MODE & 2) ? (wv * MT + i) : min(mt0 + i, mtiles - 1)) * KC * 64 + lane;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[i][n] = zero16();
+    float4 a0[MT], a1[MT], b0[NT], b1[NT];
+#define LOADA(A, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) A[i] = xp[i][(size_t)kq_ * 64]; }
+#define LOADB(B, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int n = 0; n < NT; ++n) B[n] = wl[(n * KC + kq_) * 64 + lane]; }
+#define MMA(A, B) _Pragma("unroll") for (int t = 0; t < 4; ++t) { _Pragma("unroll") for (int n = 0; n < NT; ++n) { const float bv = (&B[n].x)[t]; \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][n] = mfma32(bv, (&A[i].x)[t], acc[i][n]); } }
+    long long t0 = 0, t1 = 0, t2 = 0;
+    if (MODE & 8) t0 = clock64();
+    LOADA(a0, 0) LOADB(b0, 0)
+    for (int kc = 0; kc < KC; kc += 2) {
+      LOADA(a1, kc + 1) LOADB(b1, kc + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      MMA(a0, b0)
+      __builtin_amdgcn_sched_barrier(0);
+      LOADA(a0, kc + 2) LOADB(b0, kc + 2)
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(MODE & 4)) { MMA(a1, b1) }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef LOADA
+#undef LOADB
+#undef MMA
+    if (MODE & 8) t1 = clock64();
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (mt0 + i >= mtiles) break;
+      float4* yp = Y + (size_t)(mt0 + i) * KCO * 64 + lane;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c0 = (panel * NT + n) * 32 + 8 * g + 4 * h;
+          const int kco = (panel * NT + n) * 4 + g;
+          float4 v = make_float4(acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+          if (bias) { const float4 bb = *reinterpret_cast<const float4*>(bias + c0); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+          if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (!(MODE & 1) || v.x == 1.2345e30f) yp[(size_t)kco * 64] = v;
+        }
+      }
+    }
+    if (MODE & 8) { t2 = clock64(); if (blockIdx.x == 3 && lane == 0) { const int slot = ((rg - bip * NWV - wv) / (blocks_per_panel * NWV)) * NWV + wv; if (slot < 256) { dbg[slot * 3] = t0; dbg[slot * 3 + 1] = t1; dbg[slot * 3 + 2] = t2; } } }
+  }
+}
+
+
+// ---- V4: W panel resident, waves own contiguous tile ranges, partner waves (w >= NWV/2) start with a single tile so the
+// two waves of a SIMD run half a period apart: one wave's epilogue stores overlap the other's MFMAs.
+template <int K, int NT, int MT>
+__device__ __forceinline__ void panel_rowgroup(const float4* __restrict__ X, const float4* wl, const float* __restrict__ bias,
+                                               float4* __restrict__ Y, int mt0, int N, int panel, int act, int lane) {
+  constexpr int KC = K / 8;
+  const int h = lane >> 5;
+  const int KCO = N >> 3;
+  const float4* xp[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) xp[i] = X + (size_t)(mt0 + i) * KC * 64 + lane;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[i][n] = zero16();
+  float4 a0[MT], a1[MT], b0[NT], b1[NT];
+#define LOADA(A, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) A[i] = xp[i][(size_t)kq_ * 64]; }
+#define LOADB(B, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int n = 0; n < NT; ++n) B[n] = wl[(n * KC + kq_) * 64 + lane]; }
+#define MMA(A, B) _Pragma("unroll") for (int t = 0; t < 4; ++t) { _Pragma("unroll") for (int n = 0; n < NT; ++n) { const float bv = (&B[n].x)[t]; \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][n] = mfma32(bv, (&A[i].x)[t], acc[i][n]); } }
+  LOADA(a0, 0) LOADB(b0, 0)
+  for (int kc = 0; kc < KC; kc += 2) {
+    LOADA(a1, kc + 1) LOADB(b1, kc + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    MMA(a0, b0)
+    __builtin_amdgcn_sched_barrier(0);
+    LOADA(a0, kc + 2) LOADB(b0, kc + 2)
+    __builtin_amdgcn_sched_barrier(0);
+    MMA(a1, b1)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef LOADA
+#undef LOADB
+#undef MMA
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    float4* yp = Y + (size_t)(mt0 + i) * KCO * 64 + lane;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = (panel * NT + n) * 32 + 8 * g + 4 * h;
+        const int kco = (panel * NT + n) * 4 + g;
+        float4 v = make_float4(acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+        if (bias) { const float4 bb = *reinterpret_cast<const float4*>(bias + c0); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+        if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        yp[(size_t)kco * 64] = v;
+      }
+    }
+  }
+}
+
+template <int K, int NT, int NWV, int STAG>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_panel_kernel(const float4* __restrict__ X, const float4* __restrict__ Wp,
+                                                          const float* __restrict__ bias, float4* __restrict__ Y,
+                                                          int M, int N, int act, int blocks_per_panel, long long* dbg) {
+  constexpr int KC = K / 8;
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];   // NT*KC*64 float4
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int panel = blockIdx.x / blocks_per_panel, bip = blockIdx.x % blocks_per_panel;
+  {
+    const float4* src = Wp + (size_t)panel * NT * KC * 64;
+    for (int i = tid; i < NT * KC * 64; i += NWV * 64) wl[i] = src[i];
+  }
+  __syncthreads();
+  const int mtiles = (M + 31) / 32;
+  const int nwaves = blocks_per_panel * NWV;
+  const int widx = bip * NWV + wv;
+  // contiguous, balanced tile ranges
+  const int base = mtiles / nwaves, rem = mtiles % nwaves;
+  int mt = widx * base + min(widx, rem);
+  const int end = mt + base + (widx < rem ? 1 : 0);
+  if (STAG && wv >= NWV / 2 && mt < end && ((end - mt) & 1) == 0) {   // even count: 1 + 2.. + 1 ; odd count: 2.. + 1 vs 1 + 2..
+    panel_rowgroup<K, NT, 1>(X, wl, bias, Y, mt, N, panel, act, lane);
+    mt += 1;
+  }
+  if (STAG && wv < NWV / 2 && mt < end && ((end - mt) & 1) == 1) {
+    panel_rowgroup<K, NT, 1>(X, wl, bias, Y, mt, N, panel, act, lane);
+    mt += 1;
+  }
+  for (; mt + 2 <= end; mt += 2) panel_rowgroup<K, NT, 2>(X, wl, bias, Y, mt, N, panel, act, lane);
+  if (mt < end) panel_rowgroup<K, NT, 1>(X, wl, bias, Y, mt, N, panel, act, lane);
+}
+
+static float time_it(std::function<void()> fn, int n = 10) {
+  hipEvent_t s, e; CK(hipEventCreate(&s)); CK(hipEventCreate(&e));
+  for (int i = 0; i < 2; ++i) fn();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(s));
+  for (int i = 0; i < n; ++i) fn();
+  CK(hipEventRecord(e)); CK(hipEventSynchronize(e));
+  float ms; CK(hipEventElapsedTime(&ms, s, e));
+  return ms / n;
+}
+
+int main() {
+  const int K = 256;
+  for (int M : {131072, 25568, 1048576}) {
+    for (int N : {256}) {
+      size_t xb = packed_linear_floats(M, K) * 4, yb = packed_linear_floats(M, N) * 4;
+      float *x, *xpa, *w, *wp, *b, *y1, *y2;
+      CK(hipMalloc(&x, (size_t)((M + 31) / 32 * 32) * K * 4)); CK(hipMalloc(&xpa, xb)); CK(hipMalloc(&w, (size_t)N * K * 4));
+      CK(hipMalloc(&wp, packed_linear_floats(N, K) * 4)); CK(hipMalloc(&b, N * 4)); CK(hipMalloc(&y1, yb)); CK(hipMalloc(&y2, yb));
+      {
+        std::vector<float> hx((size_t)M * K), hw((size_t)N * K), hb(N);
+        for (auto& v : hx) v = (float)rand() / (float)RAND_MAX - 0.5f;
+        for (auto& v : hw) v = ((float)rand() / (float)RAND_MAX - 0.5f) / 8;
+        for (auto& v : hb) v = (float)rand() / (float)RAND_MAX - 0.5f;
+        CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+      }
+      CK(poem_launch_pack_linear(x, M, K, xpa, 0));
+      CK(poem_launch_pack_linear(w, N, K, wp, 0));
+      CK(hipMemset(y1, 0, yb)); CK(hipMemset(y2, 0, yb));
+      const double fl = 2.0 * M * N * K;
+      float ms = time_it([&] { (void)poem_launch_gemm2(xpa, K, wp, b, nullptr, 0, y1, N, M, N, K, 0, 1, 1, 0); });
+      printf("M=%8d N=%d  gemm2 PA->PA          %8.1f us %6.1f TF\n", M, N, ms * 1e3, fl / ms / 1e9);
+      long long* dbg; CK(hipMalloc(&dbg, 256 * 3 * 8)); CK(hipMemset(dbg, 0, 256 * 3 * 8));
+      auto run_wres = [&](auto kern, int NT, int NWV, const char* name) {
+        const int panels = N / (32 * NT);
+        const int bpp = 256 / panels;
+        const size_t lds = (size_t)NT * (K / 8) * 64 * 16;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipMemset(y2, 0, yb));
+        float t = time_it([&] { hipLaunchKernelGGL(kern, dim3(256), dim3(NWV * 64), lds, 0, (const float4*)xpa, (const float4*)wp, b, (float4*)y2, M, N, 0, bpp, dbg); });
+        CK(hipGetLastError());
+        std::vector<float> h1(yb / 4), h2(yb / 4);
+        CK(hipMemcpy(h1.data(), y1, yb, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), y2, yb, hipMemcpyDeviceToHost));
+        size_t bad = 0; for (size_t i = 0; i < h1.size(); ++i) if (h1[i] != h2[i]) ++bad;
+        printf("M=%8d N=%d  %-22s %8.1f us %6.1f TF  mismatches=%zu\n", M, N, name, t * 1e3, fl / t / 1e9, bad);
+      };
+      run_wres(gemm_wres_kernel<256, 4, 2, 8, 0>, 4, 8, "wres MT2 8w");
+      run_wres(gemm_wres_kernel<256, 4, 2, 4, 0>, 4, 4, "wres MT2 4w");
+      run_wres(gemm_wres_kernel<256, 4, 2, 8, 1>, 4, 8, "wres MT2 8w nostore");
+      run_wres(gemm_wres_kernel<256, 4, 2, 8, 2>, 4, 8, "wres MT2 8w L2X");
+      run_wres(gemm_wres_kernel<256, 4, 2, 8, 3>, 4, 8, "wres MT2 8w nost+L2X");
+      run_wres(gemm_wres_kernel<256, 4, 2, 8, 7>, 4, 8, "wres MT2 8w ..+halfmma");
+      run_wres(gemm_wres_kernel<256, 4, 2, 4, 3>, 4, 4, "wres MT2 4w nost+L2X");
+      run_wres(gemm_panel_kernel<256, 4, 8, 0>, 4, 8, "panel 8w nostagger");
+      run_wres(gemm_panel_kernel<256, 4, 8, 1>, 4, 8, "panel 8w stagger");
+      run_wres(gemm_wres_kernel<256, 4, 2, 8, 8>, 4, 8, "wres MT2 8w timed");
+      {
+        std::vector<long long> hd(256 * 3); CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
+        long long base = hd[0];
+        for (int s = 0; s < 32; ++s) if (hd[s * 3]) printf("   slot %2d (wave %d): start %8lld  loop %7lld  epi %6lld\n", s, s % 8, hd[s * 3] - base, hd[s * 3 + 1] - hd[s * 3], hd[s * 3 + 2] - hd[s * 3 + 1]);
+      }
+      CK(hipFree(x)); CK(hipFree(xpa)); CK(hipFree(w)); CK(hipFree(wp)); CK(hipFree(b)); CK(hipFree(y1)); CK(hipFree(y2));
+    }
+  }
+  return 0;
+}
