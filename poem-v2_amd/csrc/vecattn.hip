@@ -13,6 +13,13 @@
 // between half-waves) and the v_j gathers coalesced.  Wave w owns output channel tiles [w*TPW, (w+1)*TPW).
 #include "common.h"
 
+#ifdef POEM_VA_DBG   // tools/lab only: per-phase cycle stamps of a few blocks
+__device__ long long va_dbg[64 * 4 * 8];
+#define VA_STAMP(k) do { if (blockIdx.x >= 6000 && blockIdx.x < 6064 && lane == 0) va_dbg[((blockIdx.x - 6000) * 4 + wv) * 8 + (k)] = clock64(); } while (0)
+#else
+#define VA_STAMP(k) do { } while (0)
+#endif
+
 struct VecAttnArgs {
   const float* query_xyz;   // (B,Q,3)
   const float* src_xyz;     // (B,NS,3) or null when anchor_xyz given
@@ -94,6 +101,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   float* X = smem;                                   // C * XS
   float* dl = smem + C * XS;                         // P*32*3 coordinate deltas
   int* sidx = reinterpret_cast<int*>(dl + P * 32 * 3);  // P*32 neighbour row ids
+  float* qs = reinterpret_cast<float*>(sidx + P * 32);  // P*C query rows
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
   const int groups = (A.Q + P - 1) / P;
@@ -101,6 +109,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   const int i0 = (blockIdx.x % groups) * P;
   const float inv_sqrt_c = 1.0f / sqrtf((float)C);   // exact for C in {64, 256, 1024}; <= 1 ulp from the division otherwise
 
+  VA_STAMP(0);
   // ---- stage 0: neighbour ids, coordinate deltas, first-layer activations h = relu(W_d1 delta + b_d1) -> X
   if (tid < 32 * P) {
     const int p = tid >> 5, jj = tid & 31;
@@ -113,14 +122,43 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
     dl[tid * 3 + 2] = qx[2] - nx[2];
     sidx[tid] = id;
   }
+  for (int f = tid; f < P * C / 4; f += NT) {           // query rows -> LDS (read back as broadcasts in epilogue 1)
+    const int p = f / (C / 4), c4 = f % (C / 4);
+    const int qi = min(i0 + p, A.Q - 1);
+    reinterpret_cast<float4*>(qs)[f] = *reinterpret_cast<const float4*>(A.q + ((size_t)b * A.Q + qi) * C + 4 * c4);
+  }
   __syncthreads();
+  // h = relu(W_d1 delta + b_d1) as two MFMA k-steps per tile (K = 3 zero-padded to 4): the same k-ordered fma chain
+  // fma(dz, w2, fma(dy, w1, dx * w0)) as a scalar loop, with the result already in the layout X wants
+  // (lane = column, registers = channels; conflict-free stores).
   {
-    const int col = tid % XS;
-    const float dx = dl[col * 3 + 0], dy = dl[col * 3 + 1], dz = dl[col * 3 + 2];
-    for (int c = tid / XS; c < C; c += NT / XS) {
-      const float w0 = A.wd1[c * 3 + 0], w1 = A.wd1[c * 3 + 1], w2 = A.wd1[c * 3 + 2];
-      const float hv = fmaf(dz, w2, fmaf(dy, w1, dx * w0)) + A.bd1[c];
-      X[c * XS + col] = fmaxf(hv, 0.f);
+    float db0[P], db1[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      db0[p] = dl[(p * 32 + j) * 3 + h];                    // k-step 0: (dx | dy) by half-wave
+      db1[p] = h == 0 ? dl[(p * 32 + j) * 3 + 2] : 0.f;     // k-step 1: (dz | 0)
+    }
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      const int crow = (wv * TPW + tp) * 32 + j;            // A operand: lane = channel row of the tile
+      const float wa0 = A.wd1[crow * 3 + h];
+      const float wa1 = h == 0 ? A.wd1[crow * 3 + 2] : 0.f;
+      const int cbase = (wv * TPW + tp) * 32 + 4 * h;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        f32x16 hh = zero16();
+        hh = mfma32(wa0, db0[p], hh);
+        hh = mfma32(wa1, db1[p], hh);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bb = *reinterpret_cast<const float4*>(A.bd1 + cbase + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g + e;
+            X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = fmaxf(hh[i] + (&bb.x)[e], 0.f);
+          }
+        }
+      }
     }
   }
   __syncthreads();
@@ -131,26 +169,42 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
 #pragma unroll
     for (int p = 0; p < P; ++p) acc[tp][p] = zero16();
 
-  // ---- GEMM 1: pos = W_d2 h + b_d2 ;  t = q_i - k_j + pos
-  chain_gemm<C, P, NW, TPW, false>(A.wd2, X, acc, wv, lane);
+  // k_j for this lane's (channel tile, neighbour) cells: 16-byte row gathers issued BEFORE the first GEMM so their
+  // L2/HBM latency hides under its MFMAs; they wait in the registers that become `pos` in the epilogue.
 #pragma unroll
   for (int tp = 0; tp < TPW; ++tp) {
     const int cbase = (wv * TPW + tp) * 32 + 4 * h;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const int qi = min(i0 + p, A.Q - 1);
-      const float* qrow = A.q + ((size_t)b * A.Q + qi) * C + cbase;
       const float* krow = A.k + ((size_t)b * A.NS + sidx[p * 32 + j]) * C + cbase;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 bb = *reinterpret_cast<const float4*>(A.bd2 + cbase + 8 * g);
-        const float4 qq = *reinterpret_cast<const float4*>(qrow + 8 * g);
         const float4 kk = *reinterpret_cast<const float4*>(krow + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pos[tp][p][4 * g + e] = (&kk.x)[e];
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  VA_STAMP(1);
+  // ---- GEMM 1: pos = W_d2 h + b_d2 ;  t = q_i - k_j + pos
+  chain_gemm<C, P, NW, TPW, false>(A.wd2, X, acc, wv, lane);
+  VA_STAMP(2);
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp) {
+    const int cbase = (wv * TPW + tp) * 32 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bb = *reinterpret_cast<const float4*>(A.bd2 + cbase + 8 * g);
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const float4 qq = *reinterpret_cast<const float4*>(qs + p * C + cbase + 8 * g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float pv = acc[tp][p][4 * g + e] + (&bb.x)[e];
+          acc[tp][p][4 * g + e] = ((&qq.x)[e] - pos[tp][p][4 * g + e]) + pv;
           pos[tp][p][4 * g + e] = pv;
-          acc[tp][p][4 * g + e] = ((&qq.x)[e] - (&kk.x)[e]) + pv;
         }
       }
     }
@@ -167,8 +221,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       }
   __syncthreads();
 
+  VA_STAMP(3);
   // ---- GEMM 2: g = relu(W_g1 t + b_g1)
   chain_gemm<C, P, NW, TPW, false>(A.wg1, X, acc, wv, lane);
+  VA_STAMP(4);
   __syncthreads();
 #pragma unroll
   for (int tp = 0; tp < TPW; ++tp) {
@@ -189,7 +245,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   __syncthreads();
 
   // ---- GEMM 3 (operands swapped): a[j][c'] = W_g2 g + b_g2, lane = channel c', registers = neighbours
+  VA_STAMP(5);
   chain_gemm<C, P, NW, TPW, true>(A.wg2, X, acc, wv, lane);
+  VA_STAMP(6);
   __syncthreads();   // X is dead from here on: reuse it as per-wave transpose scratch
 
   float* scr = X + wv * (32 * 33);
@@ -208,8 +266,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       for (int i = 0; i < 16; ++i) {
         const int jj = mfma_row(i, h);
         const float pt = scr[jj * 33 + j];
-        const float vv = A.v[((size_t)b * A.NS + sidx[p * 32 + jj]) * C + cch];
-        val[i] = vv + pt;
+        const float vg = A.v[((size_t)b * A.NS + sidx[p * 32 + jj]) * C + cch];
+        val[i] = vg + pt;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       float mx = -INFINITY;
@@ -231,12 +289,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       if (h == 0 && i0 + p < A.Q) A.out[((size_t)b * A.Q + i0 + p) * C + cch] = res;
     }
   }
+  VA_STAMP(7);
 }
 
 template <int C, int P, int NW, int MINW>
 static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s) {
   const int groups = (a.Q + P - 1) / P;
-  const size_t lds = (size_t)C * 32 * P * 4 + P * 32 * 3 * 4 + P * 32 * 4;
+  const size_t lds = (size_t)C * 32 * P * 4 + P * 32 * 3 * 4 + P * 32 * 4 + (size_t)P * C * 4;
   auto kern = vecattn_kernel<C, P, NW, MINW>;
   static bool attr_done = false;
   if (!attr_done) {

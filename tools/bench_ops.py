@@ -44,5 +44,43 @@ def gemm_cases():
         print(line, flush=True)
 
 
+def vecattn_case(B=32, Q=799, NS=4096, C=256):
+    import poem_oracle as po
+    g = torch.Generator().manual_seed(0)
+    qxyz = (torch.rand(B, Q, 3, generator=g) * 2 - 1).to(dev)
+    sxyz = (torch.rand(B, NS, 3, generator=g) * 2 - 1).to(dev)
+    q, k, v = (torch.randn(B, n, C, generator=g).to(dev) for n in (Q, NS, NS))
+    idx = hip.knn(qxyz, sxyz)
+    w = lambda *shp: (torch.randn(*shp, generator=g) / math.sqrt(shp[-1])).to(dev)
+    wd1, bd1 = w(C, 3), w(C) * 0.1
+    packs = [hip.pack_linear(w(C, C)) for _ in range(3)]
+    bs = [w(C) * 0.1 for _ in range(3)]
+    fn = lambda: hip.vector_attention(qxyz, sxyz, None, idx, q, k, v, wd1, bd1, packs[0], bs[0], packs[1], bs[1], packs[2], bs[2])
+    t = timeit(fn, 10)
+    fl = B * Q * 32 * (6.0 * C * C + 6.0 * C)
+    print(f"vecattn B={B} Q={Q} NS={NS} C={C}: {t*1e3:8.1f} us  {fl/t/1e9:6.1f} TF", flush=True)
+
+
+def attn_case(B=32, Q=799, NS=4096, C=256, heads=4):
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(B, n, C, generator=g).to(dev) for n in (Q, NS, NS))
+    t = timeit(lambda: hip.cross_attention(q, k, v, heads), 10)
+    fl = 4.0 * B * Q * NS * C
+    print(f"cross_attn B={B} Q={Q} NS={NS} C={C}: {t*1e3:8.1f} us  {fl/t/1e9:6.1f} TF", flush=True)
+
+
+def knn_case(B=32, Q=799, NS=4096):
+    g = torch.Generator().manual_seed(0)
+    qxyz = (torch.rand(B, Q, 3, generator=g) * 2 - 1).to(dev)
+    sxyz = (torch.rand(B, NS, 3, generator=g) * 2 - 1).to(dev)
+    t = timeit(lambda: hip.knn(qxyz, sxyz), 10)
+    print(f"knn B={B} Q={Q} NS={NS}: {t*1e3:8.1f} us", flush=True)
+    t = timeit(lambda: hip.knn(qxyz, qxyz), 10)
+    print(f"knn B={B} Q={Q} NS={Q}: {t*1e3:8.1f} us", flush=True)
+
+
 if __name__ == "__main__":
-    gemm_cases()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    which = sys.argv[1:] or ["gemm"]
+    for wname in which:
+        {"gemm": gemm_cases, "vecattn": vecattn_case, "attn": attn_case, "knn": knn_case}[wname]()
