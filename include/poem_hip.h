@@ -155,9 +155,12 @@ int poem_merge_reduce(const float* h2, const int32_t* view_offsets, float* m, in
                       void* stream);
 int poem_merge_finalize(const float* g, const float* y, const int32_t* view_offsets, float* out, int batch,
                         int nsample, int embed, void* stream);
-/* q (B,Q,C) k,v (B,S,C) -> ctx (B,Q,C); softmax(q k^T / sqrt(C/heads)) v per head. */
+/* q (B,Q,C) k,v (B,S,C) -> ctx (B,Q,C); softmax(q k^T / sqrt(C/heads)) v per head.
+ * The kernel splits the key axis over blocks when that balances the chip better; the partial (O, m, l) triples live in
+ * `scratch` (poem_cross_attention_scratch_bytes() bytes, may be 0 -> scratch may be NULL). */
+size_t poem_cross_attention_scratch_bytes(int batch, int nq, int nk, int embed, int heads);
 int poem_cross_attention(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk,
-                         int embed, int heads, void* stream);
+                         int embed, int heads, void* scratch, size_t scratch_bytes, void* stream);
 /* idx (B,Q,32) int32: 32 nearest src points per query, ascending squared L2, ties -> lower index. */
 int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream);
 /* Vector attention core.  q (B,Q,C); k,v (B,NS,C) gathered by idx; idx (B,Q,32) or (32) when shared_idx!=0;

@@ -31,7 +31,8 @@ hipError_t poem_launch_merge_reduce(const float* h2, const int* offs, float* m, 
 hipError_t poem_launch_merge_finalize(const float* g, const float* y, const int* offs, float* out, int B, int S, int C,
                                       hipStream_t s);
 hipError_t poem_launch_cross_attention(const float* q, const float* k, const float* v, float* ctx, int B, int NQ, int NK,
-                                       int C, int heads, hipStream_t s);
+                                       int C, int heads, int ldkv, float* scratch, hipStream_t s);
+size_t poem_cross_attention_scratch_floats(int B, int NQ, int NK, int C, int heads, int* ksplit_out);
 hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS, hipStream_t s);
 hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                         const int* idx, int shared_idx, const float* q, const float* k, const float* v,
@@ -194,7 +195,7 @@ struct Plan {
   float *ke[8], *kp[8][2], *vp[8][2], *xk[8], *kc[8], *vc[8];
   // per block kept tensors (taps)
   float *h_cross[8], *f_self[8], *f_cross[8], *feats[8];
-  float *q3t, *par;
+  float *q3t, *par, *attn_scratch;
   size_t bytes;
 };
 
@@ -251,6 +252,7 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   }
   p.q3t = a.take<float>((size_t)B * C);
   p.par = a.take<float>((size_t)B * 106);
+  p.attn_scratch = a.take<float>(poem_cross_attention_scratch_floats(B, (int)Q, (int)S, (int)C, c.heads, nullptr) + 4);
   p.bytes = align_up(a.off, 256);
   return p;
 }
@@ -342,7 +344,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       float* hout = a == 0 ? p.h_attn : p.h_cross[i];
       GEMM(hidden, C, ab + 0, ab + 1, nullptr, 0, p.qp, C, BQ, C, C, POEM_ACT_NONE);
       if (ov && a == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
-      HIPCHK(poem_launch_cross_attention(p.qp, p.kp[i][a], p.vp[i][a], p.ctx, B, Q, S, C, c.heads, s));
+      HIPCHK(poem_launch_cross_attention(p.qp, p.kp[i][a], p.vp[i][a], p.ctx, B, Q, S, C, c.heads, C, p.attn_scratch, s));
       GEMM(p.ctx, C, ab + 6, ab + 7, hidden, C, p.att, C, BQ, C, C, POEM_ACT_NONE);
       HIPCHK(poem_launch_layernorm(p.att, h->R(ab + 8), h->R(ab + 9), hout, BQ, C, c.ln_eps, s));
       hidden = hout;
@@ -638,10 +640,18 @@ int poem_merge_finalize(const float* g, const float* y, const int32_t* view_offs
   return POEM_OK;
 }
 
+size_t poem_cross_attention_scratch_bytes(int batch, int nq, int nk, int embed, int heads) {
+  if (batch <= 0 || nq <= 0 || nk % 32 || heads <= 0 || embed % heads) return 0;
+  return poem_cross_attention_scratch_floats(batch, nq, nk, embed, heads, nullptr) * sizeof(float);
+}
+
 int poem_cross_attention(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk, int embed,
-                         int heads, void* stream) {
+                         int heads, void* scratch, size_t scratch_bytes, void* stream) {
   if (!q || !k || !v || !ctx || batch <= 0 || nq <= 0 || nk % 32 || heads <= 0 || embed % heads) return POEM_E_ARG;
-  HIPCHK(poem_launch_cross_attention(q, k, v, ctx, batch, nq, nk, embed, heads, (hipStream_t)stream));
+  const size_t need = poem_cross_attention_scratch_bytes(batch, nq, nk, embed, heads);
+  if (need && (!scratch || scratch_bytes < need || ((uintptr_t)scratch & 15))) return POEM_E_WORKSPACE;
+  HIPCHK(poem_launch_cross_attention(q, k, v, ctx, batch, nq, nk, embed, heads, embed, (float*)scratch,
+                                     (hipStream_t)stream));
   return POEM_OK;
 }
 

@@ -12,10 +12,12 @@
 // channel, registers = neighbours -- which makes the softmax over the 32 neighbours register-local (+1 exchange
 // between half-waves) and the v_j gathers coalesced.  Wave w owns output channel tiles [w*TPW, (w+1)*TPW).
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
 
 #ifdef POEM_VA_DBG   // tools/lab only: per-phase cycle stamps of a few blocks
 __device__ long long va_dbg[64 * 4 * 8];
-#define VA_STAMP(k) do { if (blockIdx.x >= 6000 && blockIdx.x < 6064 && lane == 0) va_dbg[((blockIdx.x - 6000) * 4 + wv) * 8 + (k)] = clock64(); } while (0)
+#define VA_STAMP(k) do { if (item >= 6000 && item < 6064 && lane == 0) va_dbg[((item - 6000) * 4 + wv) * 8 + (k)] = clock64(); } while (0)
 #else
 #define VA_STAMP(k) do { } while (0)
 #endif
@@ -40,7 +42,12 @@ struct VecAttnArgs {
   const float* bg2;
   float* out;               // (B,Q,C)
   int B, Q;
+  int stagger;              // > 0: persistent launch, second block of each CU starts `stagger` cycles late
 };
+
+// arrival parity per CU (key: XCC id, HW_ID[15:8]); atomicInc wraps 0 -> 1 -> 0, so the table resets itself when
+// every CU hosts two blocks.  Used for speed only: a wrong parity costs overlap, never correctness.
+__device__ unsigned int va_cu_slot[8 * 256];
 
 template <int C, int P, int NW, int TPW, bool FLIP>
 __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const float* __restrict__ X,
@@ -105,9 +112,30 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
   const int groups = (A.Q + P - 1) / P;
-  const int b = blockIdx.x / groups;
-  const int i0 = (blockIdx.x % groups) * P;
+  const int total = A.B * groups;
   const float inv_sqrt_c = 1.0f / sqrtf((float)C);   // exact for C in {64, 256, 1024}; <= 1 ulp from the division otherwise
+
+  if (A.stagger > 0) {
+    // Two blocks share a CU (LDS-limited).  Left alone they run in lockstep -- both in their MFMA-free phases at the
+    // same time -- so the second arrival on each CU starts half a period late: its prologue/epilogue phases then fall
+    // inside the partner's GEMM phases and the matrix pipe never idles.
+    if (tid == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+      const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));    // HW_REG_XCC_ID[3:0]
+      const unsigned key = ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);
+      sidx[0] = (int)atomicInc(&va_cu_slot[key], 1u);
+    }
+    __syncthreads();
+    if (sidx[0] & 1) {
+      const long long t0 = clock64();
+      while (clock64() - t0 < (long long)A.stagger) __builtin_amdgcn_s_sleep(64);
+    }
+  }
+
+  for (int item = blockIdx.x; item < total; item += gridDim.x) {
+  const int b = item / groups;
+  const int i0 = (item % groups) * P;
+  __syncthreads();   // previous item's epilogue still reads sidx / the scratch inside X
 
   VA_STAMP(0);
   // ---- stage 0: neighbour ids, coordinate deltas, first-layer activations h = relu(W_d1 delta + b_d1) -> X
@@ -290,12 +318,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
     }
   }
   VA_STAMP(7);
+  }   // item loop
 }
 
 template <int C, int P, int NW, int MINW>
 static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s) {
   const int groups = (a.Q + P - 1) / P;
-  const size_t lds = (size_t)C * 32 * P * 4 + P * 32 * 3 * 4 + P * 32 * 4 + (size_t)P * C * 4;
+  size_t lds = (size_t)C * 32 * P * 4 + P * 32 * 3 * 4 + P * 32 * 4 + (size_t)P * C * 4;
+#ifdef POEM_VA_DBG
+  if (const char* e = getenv("POEM_VA_LDSPAD")) lds += atoi(e);
+#endif
   auto kern = vecattn_kernel<C, P, NW, MINW>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -304,7 +336,17 @@ static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * groups)), dim3(NW * 64), lds, s, a);
+  unsigned grid = (unsigned)(a.B * groups);
+  if (a.stagger > 0) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    }
+    grid = std::min(grid, (unsigned)(2 * cus));
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
 }
 
@@ -315,7 +357,8 @@ extern "C" hipError_t poem_launch_vector_attention(const float* query_xyz, const
                                                    const void* wg2, const float* bg2, float* out, int B, int Q, int C,
                                                    hipStream_t s) {
   VecAttnArgs a{query_xyz, src_xyz, anchor_xyz, idx, shared_idx, q, k, v, nsrc, wd1, bd1, (const float4*)wd2, bd2,
-                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q};
+                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q, 0};
+  if (const char* e = getenv("POEM_VA_STAGGER")) a.stagger = atoi(e);
   switch (C) {
     case 32: return launch_va<32, 2, 1, 1>(a, s);
     case 64: return launch_va<64, 2, 2, 1>(a, s);

@@ -59,7 +59,8 @@ SIGNATURES = {
     "poem_project_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "poem_merge_reduce": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "poem_merge_finalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "poem_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "poem_cross_attention_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "poem_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "poem_knn": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "poem_vector_attention": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _i, _i, _i, _vp]),
@@ -305,8 +306,10 @@ def layernorm(x, g, b, eps):
 def cross_attention(q, k, v, heads):
     B, NQ, C = q.shape
     ctx = torch.empty_like(q)
-    check(lib().poem_cross_attention(ptr(q), ptr(k), ptr(v), ptr(ctx), B, NQ, k.shape[1], C, heads, stream()),
-          "poem_cross_attention")
+    need = lib().poem_cross_attention_scratch_bytes(B, NQ, k.shape[1], C, heads)
+    scratch = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    check(lib().poem_cross_attention(ptr(q), ptr(k), ptr(v), ptr(ctx), B, NQ, k.shape[1], C, heads, scratch.data_ptr(),
+                                     need, stream()), "poem_cross_attention")
     return ctx
 
 
