@@ -3,6 +3,7 @@
 // straight from global/L2 (fp32 MFMA needs only 8 B/lane per 64 cycles, so no LDS staging is required);
 // operands for the next K-chunk are prefetched into registers while the current chunk's MFMAs issue.
 #include "common.h"
+#include <algorithm>
 
 __global__ void pack_linear_kernel(const float* __restrict__ w, int N, int K, float4* __restrict__ out, int total) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,9 +203,152 @@ extern "C" hipError_t poem_launch_gemm2(const float* X, int ldx, const void* Wp,
   return launch_gemm2_t<1, 1>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, in_pa, out_pa, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Panel GEMM (the workhorse for K <= 512): one persistent block per CU keeps a W panel of NT column tiles x K resident
+// in LDS (fragment order, conflict-free ds_read_b128) and its 8 waves (2 per SIMD) stream row groups of MT x 32 rows:
+// the only global traffic of the main loop is the X operand (16-byte fragment loads, one chunk ahead), so L2 carries
+// 1/3 of what the operands-from-L2 kernel above needs, and a fused wide N (several Linears that share the input,
+// weights concatenated along N) reads X from HBM once per panel pass.  Plain formulation D[m][n] (lane = output column):
+// every store instruction writes two full 128-byte row segments.
+// act2 applies to columns >= act_split (two Linears with different activations fused along N).
+template <int NT, int MT>
+__global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restrict__ X, int ldx,
+                                                            const float4* __restrict__ Wp, const float* __restrict__ bias,
+                                                            const float* __restrict__ R, int ldr, float* __restrict__ Y,
+                                                            int ldy, int M, int N, int K, int act, int act_split, int act2) {
+  constexpr int NWV = 8;
+  const int KC = K >> 3;
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];   // NT * KC * 64 float4
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int panels = N / (32 * NT);
+  const int panel = blockIdx.x % panels, bip = blockIdx.x / panels;
+  const int blocks_in_panel = ((int)gridDim.x - panel + panels - 1) / panels;
+  {
+    const float4* src = Wp + (size_t)panel * NT * KC * 64;
+    for (int i = tid; i < NT * KC * 64; i += NWV * 64) wl[i] = src[i];
+  }
+  __syncthreads();
+  const int mtiles = (M + 31) / 32;
+  const int rgroups = (mtiles + MT - 1) / MT;
+  const int pact = (panel * NT * 32 >= act_split) ? act2 : act;
+  for (int rg = bip * NWV + wv; rg < rgroups; rg += blocks_in_panel * NWV) {
+    const int mt0 = rg * MT;
+    const float4* xp[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      xp[i] = reinterpret_cast<const float4*>(X + (size_t)min((mt0 + i) * 32 + r, M - 1) * ldx + 4 * h);
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[i][n] = zero16();
+    float4 a0[MT], a1[MT], b0[NT], b1[NT];
+#define POEM_LOADA(A, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) A[i] = xp[i][(size_t)kq_ * 2]; }
+#define POEM_LOADB(B, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int n = 0; n < NT; ++n) B[n] = wl[(n * KC + kq_) * 64 + lane]; }
+#define POEM_MMA(A, B)                                                          \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t) {                               \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) {                            \
+      const float bv = (&B[n].x)[t];                                            \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][n] = mfma32((&A[i].x)[t], bv, acc[i][n]); \
+    }                                                                           \
+  }
+    POEM_LOADA(a0, 0) POEM_LOADB(b0, 0)
+    int kc = 0;
+    for (; kc + 1 < KC; kc += 2) {
+      POEM_LOADA(a1, kc + 1) POEM_LOADB(b1, kc + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      POEM_MMA(a0, b0)
+      __builtin_amdgcn_sched_barrier(0);
+      POEM_LOADA(a0, kc + 2) POEM_LOADB(b0, kc + 2)
+      __builtin_amdgcn_sched_barrier(0);
+      POEM_MMA(a1, b1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kc < KC) { POEM_MMA(a0, b0) }
+#undef POEM_LOADA
+#undef POEM_LOADB
+#undef POEM_MMA
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = (panel * NT + n) * 32 + r;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (mt0 + i) * 32 + mfma_row(e, h);
+          if (row < M) {
+            float v = acc[i][n][e] + bv;
+            if (pact == 1) v = fmaxf(v, 0.f);
+            if (pact == 2) v = gelu_erf(v);
+            if (R) v += R[(size_t)row * ldr + col];
+            Y[(size_t)row * ldy + col] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+static int poem_num_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+
+template <int NT, int MT>
+static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
+                                 float* Y, int ldy, int M, int N, int K, int act, int act_split, int act2,
+                                 hipStream_t s) {
+  const size_t lds = (size_t)NT * (K / 8) * 64 * 16;
+  auto kern = gemm_panel_kernel<NT, MT>;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(128 * 1024));
+    if (e != hipSuccess) return e;
+    lds_set = 128 * 1024;
+  }
+  const int panels = N / (32 * NT);
+  const int grid = std::max(poem_num_cus(), panels);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, X, ldx, (const float4*)Wp, bias, R, ldr, Y, ldy, M, N, K, act,
+                     act_split, act2);
+  return hipGetLastError();
+}
+
+// Fused-N aware GEMM entry: columns [0, act_split) use `act`, columns [act_split, N) use `act2`.
+extern "C" hipError_t poem_launch_gemm_split(const float* X, int ldx, const void* Wp, const float* bias, const float* R,
+                                             int ldr, float* Y, int ldy, int M, int N, int K, int act, int act_split,
+                                             int act2, hipStream_t s) {
+  // panel kernel: N a multiple of 32*NT, panel (NT*K*128 B) within 128 KiB of LDS, the split on a panel boundary
+  int NT = 0;
+  for (int c : {4, 2, 1})
+    if (N % (32 * c) == 0 && (size_t)c * K * 128 <= 128 * 1024 && (act_split >= N || act_split % (32 * c) == 0)) { NT = c; break; }
+  if (NT == 0 || K % 8 || ((uintptr_t)X & 15) || ldx % 4) {
+    if (act_split < N && act2 != act) return hipErrorInvalidValue;
+    return poem_launch_gemm2(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, 0, 0, s);
+  }
+  const int mtiles = (M + 31) / 32, panels = N / (32 * NT);
+  const int wpp = std::max(1, std::max(poem_num_cus(), panels) / panels) * 8;       // waves per panel
+  auto cost = [&](int mt) { return (long)(((mtiles + mt - 1) / mt + wpp - 1) / wpp) * mt; };
+  const bool mt2 = cost(2) <= cost(1);
+#define POEM_PANEL(NTV)                                                                                            \
+  return mt2 ? launch_panel_t<NTV, 2>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)           \
+             : launch_panel_t<NTV, 1>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)
+  if (NT == 4) { POEM_PANEL(4); }
+  if (NT == 2) { POEM_PANEL(2); }
+  POEM_PANEL(1);
+#undef POEM_PANEL
+}
+
 extern "C" hipError_t poem_launch_gemm(const float* X, int ldx, const void* Wp, const float* bias, const float* R,
                                        int ldr, float* Y, int ldy, int M, int N, int K, int act, hipStream_t s) {
-  return poem_launch_gemm2(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, 0, 0, s);
+  return poem_launch_gemm_split(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, N, act, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -19,7 +19,18 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_wres_kernel(const floa
   constexpr int KC = K / 8;
   extern __shared__ __attribute__((aligned(16))) float4 wl[];   // NT*KC*64 float4
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5;
-  const int panel = blockIdx.x / blocks_per_panel, bip = blockIdx.x % blocks_per_panel;
+  const int panels = N / (32 * NT);
+  int panel = blockIdx.x % panels, bip = blockIdx.x / panels;
+  blocks_per_panel = ((int)gridDim.x - panel + panels - 1) / panels;
+  if (MODE & 16) {   // XCD-aware: the `panels` blocks that stream the same rows sit on one XCD (shared L2)
+    const int xcd = blockIdx.x % 8, slot = blockIdx.x / 8, per = (int)gridDim.x / 8;
+    const int parts = per / panels;
+    panel = slot % panels;
+    const int part = slot / panels;
+    if (part >= parts) return;
+    bip = xcd * parts + part;
+    blocks_per_panel = 8 * parts;
+  }
   {
     const float4* src = Wp + (size_t)panel * NT * KC * 64;
     for (int i = tid; i < NT * KC * 64; i += NWV * 64) wl[i] = src[i];
@@ -168,6 +179,75 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_panel_kernel(const flo
   if (mt < end) panel_rowgroup<K, NT, 1>(X, wl, bias, Y, mt, N, panel, act, lane);
 }
 
+
+// ---- V5: W panel resident in LDS; X row-major straight to registers (fragment-shaped 16-B loads), Y row-major via the
+// plain formulation D[m][n] (lane = column: 128-B row segments per store).
+template <int K, int NT, int MT, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_wres_rm_kernel(const float* __restrict__ X, const float4* __restrict__ Wp,
+                                                          const float* __restrict__ bias, float* __restrict__ Y,
+                                                          int M, int N, int act, int blocks_per_panel, long long* dbg) {
+  constexpr int KC = K / 8;
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int panels = N / (32 * NT);
+  const int panel = blockIdx.x % panels, bip = blockIdx.x / panels;
+  blocks_per_panel = ((int)gridDim.x - panel + panels - 1) / panels;
+  {
+    const float4* src = Wp + (size_t)panel * NT * KC * 64;
+    for (int i = tid; i < NT * KC * 64; i += NWV * 64) wl[i] = src[i];
+  }
+  __syncthreads();
+  const int mtiles = (M + 31) / 32;
+  const int rgroups = (mtiles + MT - 1) / MT;
+  for (int rg = bip * NWV + wv; rg < rgroups; rg += blocks_per_panel * NWV) {
+    const int mt0 = rg * MT;
+    const float4* xp[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xp[i] = reinterpret_cast<const float4*>(X + (size_t)min((mt0 + i) * 32 + r, M - 1) * K + 4 * h);
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[i][n] = zero16();
+    float4 a0[MT], a1[MT], b0[NT], b1[NT];
+#define LOADA(A, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) A[i] = xp[i][(size_t)kq_ * 2]; }
+#define LOADB(B, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int n = 0; n < NT; ++n) B[n] = wl[(n * KC + kq_) * 64 + lane]; }
+#define MMA(A, B) _Pragma("unroll") for (int t = 0; t < 4; ++t) { _Pragma("unroll") for (int n = 0; n < NT; ++n) { const float bv = (&B[n].x)[t]; \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][n] = mfma32((&A[i].x)[t], bv, acc[i][n]); } }
+    LOADA(a0, 0) LOADB(b0, 0)
+    for (int kc = 0; kc < KC; kc += 2) {
+      LOADA(a1, kc + 1) LOADB(b1, kc + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      MMA(a0, b0)
+      __builtin_amdgcn_sched_barrier(0);
+      LOADA(a0, kc + 2) LOADB(b0, kc + 2)
+      __builtin_amdgcn_sched_barrier(0);
+      MMA(a1, b1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef LOADA
+#undef LOADB
+#undef MMA
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int col = (panel * NT + n) * 32 + r;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (mt0 + i) * 32 + mfma_row(e, h);
+          if (row < M) {
+            float v = acc[i][n][e] + bv;
+            if (act == 1) v = fmaxf(v, 0.f);
+            Y[(size_t)row * N + col] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 static float time_it(std::function<void()> fn, int n = 10) {
   hipEvent_t s, e; CK(hipEventCreate(&s)); CK(hipEventCreate(&e));
   for (int i = 0; i < 2; ++i) fn();
@@ -182,7 +262,8 @@ static float time_it(std::function<void()> fn, int n = 10) {
 int main() {
   const int K = 256;
   for (int M : {131072, 25568, 1048576}) {
-    for (int N : {256}) {
+    for (int N : {256, 512, 768, 1280}) {
+      if (M > 200000 && N > 256) continue;
       size_t xb = packed_linear_floats(M, K) * 4, yb = packed_linear_floats(M, N) * 4;
       float *x, *xpa, *w, *wp, *b, *y1, *y2;
       CK(hipMalloc(&x, (size_t)((M + 31) / 32 * 32) * K * 4)); CK(hipMalloc(&xpa, xb)); CK(hipMalloc(&w, (size_t)N * K * 4));
@@ -218,18 +299,22 @@ int main() {
       };
       run_wres(gemm_wres_kernel<256, 4, 2, 8, 0>, 4, 8, "wres MT2 8w");
       run_wres(gemm_wres_kernel<256, 4, 2, 4, 0>, 4, 4, "wres MT2 4w");
-      run_wres(gemm_wres_kernel<256, 4, 2, 8, 1>, 4, 8, "wres MT2 8w nostore");
-      run_wres(gemm_wres_kernel<256, 4, 2, 8, 2>, 4, 8, "wres MT2 8w L2X");
-      run_wres(gemm_wres_kernel<256, 4, 2, 8, 3>, 4, 8, "wres MT2 8w nost+L2X");
-      run_wres(gemm_wres_kernel<256, 4, 2, 8, 7>, 4, 8, "wres MT2 8w ..+halfmma");
-      run_wres(gemm_wres_kernel<256, 4, 2, 4, 3>, 4, 4, "wres MT2 4w nost+L2X");
-      run_wres(gemm_panel_kernel<256, 4, 8, 0>, 4, 8, "panel 8w nostagger");
-      run_wres(gemm_panel_kernel<256, 4, 8, 1>, 4, 8, "panel 8w stagger");
-      run_wres(gemm_wres_kernel<256, 4, 2, 8, 8>, 4, 8, "wres MT2 8w timed");
+      run_wres(gemm_wres_kernel<256, 4, 1, 8, 0>, 4, 8, "wres MT1 8w");
       {
-        std::vector<long long> hd(256 * 3); CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
-        long long base = hd[0];
-        for (int s = 0; s < 32; ++s) if (hd[s * 3]) printf("   slot %2d (wave %d): start %8lld  loop %7lld  epi %6lld\n", s, s % 8, hd[s * 3] - base, hd[s * 3 + 1] - hd[s * 3], hd[s * 3 + 2] - hd[s * 3 + 1]);
+        float* yr1; float* yr2; const size_t rb = (size_t)((M + 31) / 32 * 32) * N * 4;
+        CK(hipMalloc(&yr1, rb)); CK(hipMalloc(&yr2, rb)); CK(hipMemset(yr2, 0, rb));
+        float t0 = time_it([&] { (void)poem_launch_gemm2(x, K, wp, b, nullptr, 0, yr1, N, M, N, K, 0, 0, 0, 0); });
+        printf("M=%8d N=%d  gemm2 RM->RM          %8.1f us %6.1f TF\n", M, N, t0 * 1e3, fl / t0 / 1e9);
+        auto kern = gemm_wres_rm_kernel<256, 4, 2, 8>;
+        const size_t lds = (size_t)4 * (K / 8) * 64 * 16;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        float t = time_it([&] { hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, (const float*)x, (const float4*)wp, b, yr2, M, N, 0, 0, dbg); });
+        CK(hipGetLastError());
+        std::vector<float> h1((size_t)M * N), h2((size_t)M * N);
+        CK(hipMemcpy(h1.data(), yr1, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), yr2, h2.size() * 4, hipMemcpyDeviceToHost));
+        size_t bad = 0; for (size_t i = 0; i < h1.size(); ++i) if (h1[i] != h2[i]) ++bad;
+        printf("M=%8d N=%d  %-22s %8.1f us %6.1f TF  mismatches=%zu\n", M, N, "wres RM->RM MT2 8w", t * 1e3, fl / t / 1e9, bad);
+        CK(hipFree(yr1)); CK(hipFree(yr2));
       }
       CK(hipFree(x)); CK(hipFree(xpa)); CK(hipFree(w)); CK(hipFree(wp)); CK(hipFree(b)); CK(hipFree(y1)); CK(hipFree(y2));
     }
