@@ -38,7 +38,9 @@ hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src
                                         const int* idx, int shared_idx, const float* q, const float* k, const float* v,
                                         int nsrc, const float* wd1, const float* bd1, const void* wd2, const float* bd2,
                                         const void* wg1, const float* bg1, const void* wg2, const float* bg2, float* out,
-                                        int B, int Q, int C, hipStream_t s);
+                                        int B, int Q, int C, int ldq, int ldk, int ldv, hipStream_t s);
+hipError_t poem_launch_gemm_split(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
+                                  float* Y, int ldy, int M, int N, int K, int act, int act_split, int act2, hipStream_t s);
 hipError_t poem_launch_prep_xyz(const float* ref_joints, const float* bps, const float* tmpl, float* centre,
                                 float* pt_xyz, float* query_xyz, int B, int S, int Q, float radius, hipStream_t s);
 hipError_t poem_launch_broadcast(const float* src, float* dst, long per, int copies, hipStream_t s);
@@ -136,6 +138,14 @@ struct poem_handle_s {
   const int32_t* anchor_idx = nullptr;
   const float* tmpl = nullptr;
   float* pe_table = nullptr;         // (sum N, C, HW)
+  // Linears that share their input are fused along N (packed images concatenate tile-wise; results are bit-identical
+  // to the separate GEMMs -- every output column is its own fma chain):
+  //   F1 (5C x C): attn.key | attn.value | cross_attn.key | cross_attn.value | query_cross_attn.fc1      input ke
+  //   F2 (2C x C): query_cross_attn.w_ks | w_vs                                                          input xk
+  //   F3 (3C x C): query_self_attn.w_qs | w_ks | w_vs                                                    input xs
+  //   F4 (5C x C): reg_branch.0 (relu) | intermediate.dense (gelu)                                       input f_cross
+  struct Fused { const void* w[4]; const float* b[4]; };
+  std::vector<Fused> fused;
   bool taps = false;
   struct Tap { const void* p; int64_t elems; };
   std::map<std::string, Tap> tapmap;
@@ -190,9 +200,10 @@ struct Plan {
   // sampling stage
   float *x, *uv, *g, *h1, *h2, *mm, *mh, *y, *bps_feat, *centre, *pt_xyz, *xyz[9];
   // decoder (per call scratch)
-  float *feats0, *qe, *qp, *ctx, *att, *h_attn, *xs, *qs, *ks, *vs, *rs, *qc, *rc, *regh, *ffh, *ffo;
-  // basis-point side, one set per block (produced ahead of time on the side stream)
-  float *ke[8], *kp[8][2], *vp[8][2], *xk[8], *kc[8], *vc[8];
+  float *feats0, *qe, *qp, *ctx, *att, *h_attn, *xs, *y3, *rs, *qc, *rc, *y4, *ffo;
+  // basis-point side, one set per block (produced ahead of time on the side stream):
+  // y1 = (BS, 5C) [kp1 | vp1 | kp2 | vp2 | xk], y2 = (BS, 2C) [kc | vc]
+  float *ke[8], *y1[8], *y2[8];
   // per block kept tensors (taps)
   float *h_cross[8], *f_self[8], *f_cross[8], *feats[8];
   float *q3t, *par, *attn_scratch;
@@ -228,14 +239,11 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   p.att = a.take<float>(BQ * C);
   p.h_attn = a.take<float>(BQ * C);
   p.xs = a.take<float>(BQ * C);
-  p.qs = a.take<float>(BQ * C);
-  p.ks = a.take<float>(BQ * C);
-  p.vs = a.take<float>(BQ * C);
+  p.y3 = a.take<float>(BQ * C * 3);
   p.rs = a.take<float>(BQ * C);
   p.qc = a.take<float>(BQ * C);
   p.rc = a.take<float>(BQ * C);
-  p.regh = a.take<float>(BQ * C);
-  p.ffh = a.take<float>(BQ * C * 4);
+  p.y4 = a.take<float>(BQ * C * 5);
   p.ffo = a.take<float>(BQ * C);
   for (int i = 0; i < c.nblocks; ++i) {
     p.h_cross[i] = a.take<float>(BQ * C);
@@ -245,10 +253,8 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
     p.idx_self[i] = a.take<int32_t>(BQ * 32);
     p.idx_cross[i] = a.take<int32_t>(BQ * 32);
     p.ke[i] = a.take<float>(BS * C);
-    for (int k = 0; k < 2; ++k) { p.kp[i][k] = a.take<float>(BS * C); p.vp[i][k] = a.take<float>(BS * C); }
-    p.xk[i] = a.take<float>(BS * C);
-    p.kc[i] = a.take<float>(BS * C);
-    p.vc[i] = a.take<float>(BS * C);
+    p.y1[i] = a.take<float>(BS * C * 5);
+    p.y2[i] = a.take<float>(BS * C * 2);
   }
   p.q3t = a.take<float>((size_t)B * C);
   p.par = a.take<float>((size_t)B * 106);
@@ -291,16 +297,13 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
   auto bps_side = [&](int i) -> int {
     const int bb = h->block_base(i);
     GEMM_ON(sb, pt_feats, C, bb + B_EMB_W, bb + B_EMB_B, nullptr, 0, p.ke[i], C, BS, C, C, POEM_ACT_NONE);
-    for (int a = 0; a < 2; ++a) {
-      const int ab = bb + (a == 0 ? B_A1 : B_A2);
-      GEMM_ON(sb, p.ke[i], C, ab + 2, ab + 3, nullptr, 0, p.kp[i][a], C, BS, C, C, POEM_ACT_NONE);
-      GEMM_ON(sb, p.ke[i], C, ab + 4, ab + 5, nullptr, 0, p.vp[i][a], C, BS, C, C, POEM_ACT_NONE);
-    }
-    // vector cross-attention sources: fc1 / w_k / w_v hoisted from the gathered rows to the S source rows
-    const int vcb = bb + B_VC;
-    GEMM_ON(sb, p.ke[i], C, vcb + 0, vcb + 1, nullptr, 0, p.xk[i], C, BS, C, C, POEM_ACT_NONE);
-    GEMM_ON(sb, p.xk[i], C, vcb + 13, -1, nullptr, 0, p.kc[i], C, BS, C, C, POEM_ACT_NONE);
-    GEMM_ON(sb, p.xk[i], C, vcb + 14, -1, nullptr, 0, p.vc[i], C, BS, C, C, POEM_ACT_NONE);
+    const auto& f = h->fused[i];
+    // F1: keys/values of both BERT cross attentions + fc1 of the vector cross attention (hoisted to the S source rows)
+    HIPCHK(poem_launch_gemm_split(p.ke[i], C, f.w[0], f.b[0], nullptr, 0, p.y1[i], 5 * C, BS, 5 * C, C, POEM_ACT_NONE,
+                                  5 * C, POEM_ACT_NONE, sb));
+    // F2: w_ks | w_vs of the vector cross attention on xk = y1[:, 4C:5C]
+    HIPCHK(poem_launch_gemm_split(p.y1[i] + 4 * C, 5 * C, f.w[1], nullptr, nullptr, 0, p.y2[i], 2 * C, BS, 2 * C, C,
+                                  POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, sb));
     if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));
     return POEM_OK;
   };
@@ -344,7 +347,8 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       float* hout = a == 0 ? p.h_attn : p.h_cross[i];
       GEMM(hidden, C, ab + 0, ab + 1, nullptr, 0, p.qp, C, BQ, C, C, POEM_ACT_NONE);
       if (ov && a == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
-      HIPCHK(poem_launch_cross_attention(p.qp, p.kp[i][a], p.vp[i][a], p.ctx, B, Q, S, C, c.heads, C, p.attn_scratch, s));
+      HIPCHK(poem_launch_cross_attention(p.qp, p.y1[i] + (2 * a) * C, p.y1[i] + (2 * a + 1) * C, p.ctx, B, Q, S, C, c.heads,
+                                         5 * C, p.attn_scratch, s));
       GEMM(p.ctx, C, ab + 6, ab + 7, hidden, C, p.att, C, BQ, C, C, POEM_ACT_NONE);
       HIPCHK(poem_launch_layernorm(p.att, h->R(ab + 8), h->R(ab + 9), hout, BQ, C, c.ln_eps, s));
       hidden = hout;
@@ -352,15 +356,15 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     // vector self-attention over the queries
     const int vsb = bb + B_VS;
     GEMM(hidden, C, vsb + 0, vsb + 1, nullptr, 0, p.xs, C, BQ, C, C, POEM_ACT_NONE);
-    GEMM(p.xs, C, vsb + 12, -1, nullptr, 0, p.qs, C, BQ, C, C, POEM_ACT_NONE);
-    GEMM(p.xs, C, vsb + 13, -1, nullptr, 0, p.ks, C, BQ, C, C, POEM_ACT_NONE);
-    GEMM(p.xs, C, vsb + 14, -1, nullptr, 0, p.vs, C, BQ, C, C, POEM_ACT_NONE);
+    // F3: w_qs | w_ks | w_vs
+    HIPCHK(poem_launch_gemm_split(p.xs, C, h->fused[i].w[2], nullptr, nullptr, 0, p.y3, 3 * C, BQ, 3 * C, C, POEM_ACT_NONE,
+                                  3 * C, POEM_ACT_NONE, s));
     if (ov && i > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
     {
     PROF_START();
-    HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.qs, p.ks, p.vs, Q, h->R(vsb + 4), h->R(vsb + 5),
-                                        h->P(vsb + 6), h->R(vsb + 7), h->P(vsb + 8), h->R(vsb + 9), h->P(vsb + 10),
-                                        h->R(vsb + 11), p.rs, B, Q, C, s));
+    HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
+                                        h->R(vsb + 5), h->P(vsb + 6), h->R(vsb + 7), h->P(vsb + 8), h->R(vsb + 9),
+                                        h->P(vsb + 10), h->R(vsb + 11), p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, s));
     PROF_STOP();
     }
     GEMM(p.rs, C, vsb + 2, vsb + 3, hidden, C, p.f_self[i], C, BQ, C, C, POEM_ACT_NONE);
@@ -369,18 +373,19 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     GEMM(p.f_self[i], C, vcb + 12, -1, nullptr, 0, p.qc, C, BQ, C, C, POEM_ACT_NONE);
     {
     PROF_START();
-    HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.kc[i], p.vc[i], S, h->R(vcb + 4),
+    HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y2[i], p.y2[i] + C, S, h->R(vcb + 4),
                                         h->R(vcb + 5), h->P(vcb + 6), h->R(vcb + 7), h->P(vcb + 8), h->R(vcb + 9),
-                                        h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, s));
+                                        h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, C, 2 * C, 2 * C, s));
     PROF_STOP();
     }
     GEMM(p.rc, C, vcb + 2, vcb + 3, p.f_self[i], C, p.f_cross[i], C, BQ, C, C, POEM_ACT_NONE);
     // xyz update
-    GEMM(p.f_cross[i], C, bb + B_REG0_W, bb + B_REG0_B, nullptr, 0, p.regh, C, BQ, C, C, POEM_ACT_RELU);
-    HIPCHK(poem_launch_narrow_linear(p.regh, C, h->R(bb + B_REG2_W), h->R(bb + B_REG2_B), xyz, p.xyz[i + 1], BQ, C, 3, s));
-    // feed forward
-    GEMM(p.f_cross[i], C, bb + B_INT_W, bb + B_INT_B, nullptr, 0, p.ffh, 4 * C, BQ, 4 * C, C, POEM_ACT_GELU);
-    GEMM(p.ffh, 4 * C, bb + B_OUT_W, bb + B_OUT_B, p.f_cross[i], C, p.ffo, C, BQ, C, 4 * C, POEM_ACT_NONE);
+    // F4: reg_branch.0 (relu) | intermediate.dense (gelu) share f_cross
+    HIPCHK(poem_launch_gemm_split(p.f_cross[i], C, h->fused[i].w[3], h->fused[i].b[3], nullptr, 0, p.y4, 5 * C, BQ, 5 * C, C,
+                                  POEM_ACT_RELU, C, POEM_ACT_GELU, s));
+    HIPCHK(poem_launch_narrow_linear(p.y4, 5 * C, h->R(bb + B_REG2_W), h->R(bb + B_REG2_B), xyz, p.xyz[i + 1], BQ, C, 3, s));
+    // feed forward (second Linear; its input is y4[:, C:5C])
+    GEMM(p.y4 + C, 5 * C, bb + B_OUT_W, bb + B_OUT_B, p.f_cross[i], C, p.ffo, C, BQ, C, 4 * C, POEM_ACT_NONE);
     HIPCHK(poem_launch_layernorm(p.ffo, h->R(bb + B_LN_W), h->R(bb + B_LN_B), p.feats[i], BQ, C, c.ln_eps, s));
     feats = p.feats[i];
     if (c.parametric && i == c.nblocks - 1) {
@@ -465,6 +470,13 @@ size_t poem_packed_bytes(const poem_config_t* cfg) {
   for (auto& s : tensor_table(*cfg))
     if (s.pack) total += align_up(packed_bytes_linear(s.rows, s.cols), 256);
   const size_t hw = (size_t)cfg->feat_h * cfg->feat_w;
+  {   // fused images F1..F4 per block + their concatenated biases (F1, F4)
+    const size_t C = cfg->embed;
+    const size_t per = align_up(packed_bytes_linear(5 * C, C), 256) + align_up(packed_bytes_linear(2 * C, C), 256) +
+                       align_up(packed_bytes_linear(3 * C, C), 256) + align_up(packed_bytes_linear(5 * C, C), 256) +
+                       2 * align_up(5 * C * 4, 256);
+    total += per * cfg->nblocks;
+  }
   total += align_up(pe_views(cfg->max_views) * cfg->embed * hw * 4, 256);              // folded positional table
   total += align_up(pe_views(cfg->max_views) * (3 * cfg->embed / 2) * hw * 4, 256);    // sine scratch (init only)
   return total;
@@ -507,6 +519,47 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   }
   h->bps = bps; h->anchor = anchor; h->anchor_idx = anchor_idx; h->tmpl = template_xyz;
   const int C = cfg->embed, hw = cfg->feat_h * cfg->feat_w;
+  {
+    h->fused.resize(cfg->nblocks);
+    auto fuse = [&](const std::vector<int>& widx, const std::vector<int>& bidx, const void** wout, const float** bout) -> bool {
+      *wout = cur;
+      for (int wi : widx) {
+        if (poem_launch_pack_linear(h->raw[wi], C, C, cur, s) != hipSuccess) return false;
+        cur += packed_bytes_linear(C, C);
+      }
+      cur = (char*)packed + align_up((size_t)(cur - (char*)packed), 256);
+      *bout = nullptr;
+      if (!bidx.empty()) {
+        *bout = (const float*)cur;
+        for (size_t k = 0; k < bidx.size(); ++k)
+          if (hipMemcpyAsync(cur + k * C * 4, h->raw[bidx[k]], (size_t)C * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return false;
+        cur += align_up(bidx.size() * (size_t)C * 4, 256);
+      }
+      return true;
+    };
+    bool ok = true;
+    for (int b = 0; b < cfg->nblocks && ok; ++b) {
+      const int bb = h->block_base(b);
+      const int a1 = bb + B_A1, a2 = bb + B_A2, vs = bb + B_VS, vc = bb + B_VC;
+      auto& f = h->fused[b];
+      ok = ok && fuse({a1 + 2, a1 + 4, a2 + 2, a2 + 4, vc + 0}, {a1 + 3, a1 + 5, a2 + 3, a2 + 5, vc + 1}, &f.w[0], &f.b[0]);
+      ok = ok && fuse({vc + 13, vc + 14}, {}, &f.w[1], &f.b[1]);
+      ok = ok && fuse({vs + 12, vs + 13, vs + 14}, {}, &f.w[2], &f.b[2]);
+      // intermediate.dense is (4C, C): four C-row slabs of the raw tensor
+      f.w[3] = cur;
+      ok = ok && poem_launch_pack_linear(h->raw[bb + B_REG0_W], C, C, cur, s) == hipSuccess;
+      cur += packed_bytes_linear(C, C);
+      ok = ok && poem_launch_pack_linear(h->raw[bb + B_INT_W], 4 * C, C, cur, s) == hipSuccess;
+      cur += packed_bytes_linear(4 * C, C);
+      cur = (char*)packed + align_up((size_t)(cur - (char*)packed), 256);
+      f.b[3] = (const float*)cur;
+      ok = ok && hipMemcpyAsync(cur, h->raw[bb + B_REG0_B], (size_t)C * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
+      ok = ok && hipMemcpyAsync(cur + (size_t)C * 4, h->raw[bb + B_INT_B], (size_t)4 * C * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
+      cur += align_up((size_t)5 * C * 4, 256);
+    }
+    if (!ok) { g_last_hip_error = (int)hipGetLastError(); delete h; return POEM_E_LAUNCH; }
+  }
   h->pe_table = (float*)cur;
   cur += align_up(pe_views(cfg->max_views) * C * hw * 4, 256);
   float* sine = (float*)cur;
@@ -670,7 +723,8 @@ int poem_vector_attention(const float* query_xyz, const float* src_xyz, const fl
       !wg1_packed || !bg1 || !wg2_packed || !bg2 || !out || batch <= 0 || nq <= 0)
     return POEM_E_ARG;
   HIPCHK(poem_launch_vector_attention(query_xyz, src_xyz, anchor_xyz, idx, shared_idx, q, k, v, nsrc, wd1, bd1, wd2_packed,
-                                      bd2, wg1_packed, bg1, wg2_packed, bg2, out, batch, nq, embed, (hipStream_t)stream));
+                                      bd2, wg1_packed, bg1, wg2_packed, bg2, out, batch, nq, embed, embed, embed, embed,
+                                      (hipStream_t)stream));
   return POEM_OK;
 }
 

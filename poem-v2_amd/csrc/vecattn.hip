@@ -42,6 +42,7 @@ struct VecAttnArgs {
   const float* bg2;
   float* out;               // (B,Q,C)
   int B, Q;
+  int ldq, ldk, ldv;        // row strides (floats) of q, k, v: they may be column blocks of a fused projection
   int stagger;              // > 0: persistent launch, second block of each CU starts `stagger` cycles late
 };
 
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   for (int f = tid; f < P * C / 4; f += NT) {           // query rows -> LDS (read back as broadcasts in epilogue 1)
     const int p = f / (C / 4), c4 = f % (C / 4);
     const int qi = min(i0 + p, A.Q - 1);
-    reinterpret_cast<float4*>(qs)[f] = *reinterpret_cast<const float4*>(A.q + ((size_t)b * A.Q + qi) * C + 4 * c4);
+    reinterpret_cast<float4*>(qs)[f] = *reinterpret_cast<const float4*>(A.q + ((size_t)b * A.Q + qi) * A.ldq + 4 * c4);
   }
   __syncthreads();
   // h = relu(W_d1 delta + b_d1) as two MFMA k-steps per tile (K = 3 zero-padded to 4): the same k-ordered fma chain
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
     const int cbase = (wv * TPW + tp) * 32 + 4 * h;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const float* krow = A.k + ((size_t)b * A.NS + sidx[p * 32 + j]) * C + cbase;
+      const float* krow = A.k + ((size_t)b * A.NS + sidx[p * 32 + j]) * A.ldk + cbase;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 kk = *reinterpret_cast<const float4*>(krow + 8 * g);
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       for (int i = 0; i < 16; ++i) {
         const int jj = mfma_row(i, h);
         const float pt = scr[jj * 33 + j];
-        const float vg = A.v[((size_t)b * A.NS + sidx[p * 32 + jj]) * C + cch];
+        const float vg = A.v[((size_t)b * A.NS + sidx[p * 32 + jj]) * A.ldv + cch];
         val[i] = vg + pt;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -355,9 +356,9 @@ extern "C" hipError_t poem_launch_vector_attention(const float* query_xyz, const
                                                    const float* v, int nsrc, const float* wd1, const float* bd1,
                                                    const void* wd2, const float* bd2, const void* wg1, const float* bg1,
                                                    const void* wg2, const float* bg2, float* out, int B, int Q, int C,
-                                                   hipStream_t s) {
+                                                   int ldq, int ldk, int ldv, hipStream_t s) {
   VecAttnArgs a{query_xyz, src_xyz, anchor_xyz, idx, shared_idx, q, k, v, nsrc, wd1, bd1, (const float4*)wd2, bd2,
-                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q, 0};
+                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q, ldq, ldk, ldv, 0};
   if (const char* e = getenv("POEM_VA_STAGGER")) a.stagger = atoi(e);
   switch (C) {
     case 32: return launch_va<32, 2, 1, 1>(a, s);
