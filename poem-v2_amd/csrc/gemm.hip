@@ -336,7 +336,7 @@ extern "C" hipError_t poem_launch_gemm_split(const float* X, int ldx, const void
   const int mtiles = (M + 31) / 32, panels = N / (32 * NT);
   const int wpp = std::max(1, std::max(poem_num_cus(), panels) / panels) * 8;       // waves per panel
   auto cost = [&](int mt) { return (long)(((mtiles + mt - 1) / mt + wpp - 1) / wpp) * mt; };
-  const bool mt2 = cost(2) <= cost(1);
+  const bool mt2 = 5 * cost(2) <= 6 * cost(1);   // 64-row wave tiles unless the 32-row split balances >= 20 % better
 #define POEM_PANEL(NTV)                                                                                            \
   return mt2 ? launch_panel_t<NTV, 2>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)           \
              : launch_panel_t<NTV, 1>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)

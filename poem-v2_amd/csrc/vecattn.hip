@@ -364,7 +364,20 @@ extern "C" hipError_t poem_launch_vector_attention(const float* query_xyz, const
     case 32: return launch_va<32, 2, 1, 1>(a, s);
     case 64: return launch_va<64, 2, 2, 1>(a, s);
     case 128: return launch_va<128, 4, 4, 2>(a, s);
-    case 256: return launch_va<256, 2, 4, 2>(a, s);
+    case 256:
+#ifdef POEM_VA_DBG
+      if (const char* e = getenv("POEM_VA_CFG")) {
+        switch (atoi(e)) {
+          case 1: return launch_va<256, 1, 4, 4>(a, s);
+          case 2: return launch_va<256, 1, 4, 3>(a, s);
+          case 3: return launch_va<256, 2, 8, 4>(a, s);
+          case 4: return launch_va<256, 1, 8, 4>(a, s);
+          case 5: return launch_va<256, 1, 2, 2>(a, s);
+          default: break;
+        }
+      }
+#endif
+      return launch_va<256, 2, 4, 2>(a, s);
     case 512: return launch_va<512, 1, 4, 2>(a, s);
     case 1024: return launch_va<1024, 1, 4, 1>(a, s);
     default: return hipErrorInvalidValue;

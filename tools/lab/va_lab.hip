@@ -35,7 +35,7 @@ int main() {
   CK(hipMemcpyFromSymbol(d.data(), HIP_SYMBOL(va_dbg), d.size() * 8));
   const char* names[7] = {"stage0", "kpre", "gemm1", "epi1", "gemm2", "epi2+vpre", "gemm3"};
   for (int blk = 0; blk < 6; ++blk) {
-    for (int wv = 0; wv < 4; wv += 3) {
+    for (int wv = 0; wv < 0; wv += 3) {
       long long* t = &d[(blk * 4 + wv) * 8];
       printf("blk %d wave %d start %lld:", blk, wv, t[0] - d[0]);
       for (int i = 0; i < 7; ++i) printf(" %s %lld", names[i], t[i + 1] - t[i]);
