@@ -243,11 +243,11 @@ extern "C" size_t poem_cross_attention_scratch_floats(int B, int NQ, int NK, int
   const int dh = C / heads;
   const int qtiles = (NQ + 31) / 32;
   const int ktiles = NK / 32;
-  // 4-wave blocks, 4 resident per CU (1024 slots): split the keys until the grid is >= 1.5 rounds (measured optimum on
-  // the headline shape: 896 blocks x 2), never below 16 key tiles per split
-  const long base_blocks = (long)((qtiles + 3) / 4) * heads * B;
-  int ks = 1;
-  while (ks < 16 && base_blocks * ks < 1536 && ktiles % (ks * 2) == 0 && ktiles / (ks * 2) >= 16) ks *= 2;
+  // 4-wave blocks, 4 resident per CU (1024 slots).  Two key splits measured best on the headline shape (896 x 2 blocks);
+  // the split count deliberately does NOT depend on the batch size: a sample's result is then bit-identical whatever
+  // batch it travels in (the property data-parallel sharding relies on).
+  (void)B; (void)heads; (void)qtiles;
+  const int ks = (ktiles % 2 == 0 && ktiles / 2 >= 16) ? 2 : 1;
   if (ksplit_out) *ksplit_out = ks;
   if (ks == 1) return 0;
   const int DT = (dh + 31) / 32;

@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Single-setting evaluation of the hot path -- the drop-in counterpart of the reference's ``scripts/eval_single.py``.
+
+Same command line (``--cfg --dataset --view_min --view_max --model -g --reload -p --draw``) and the same YAML edits
+(scripts/eval_single.py:63-86 upstream: dataset URL / epoch size / view range, the four size fields derived from the
+model category, PARAMETRIC_OUTPUT for medium_MANO), written back to ``--cfg`` exactly as upstream does.  What differs:
+
+* the reference shells out to ``./ddp_python scripts/eval.py`` (full model: HRNet + heat-map stage + DLT + head).  This
+  build owns the head / decoder path only, so the evaluation loop here feeds the head the tensors
+  the reference's ``_forward_impl`` would hand it (lib/models/POEM.py:306-332): backbone features, cameras and
+  triangulated reference joints;
+* the dataset tars are not available offline: the source is the seeded synthetic generator of ``poem_v2_amd.inputs``
+  with views per sample drawn from ``[view_min, view_max]`` the way ``collation_random_n_views`` does
+  (lib/utils/collation.py:7-25 upstream).  ``--epoch_size`` bounds the run (default: 64 samples, not the dataset's).
+
+One process per GPU: run directly (``-g 0``) or under ``python -m torch.distributed.run --nproc-per-node N``; ranks take
+contiguous sample shards and the metric sums meet in one all-reduce (RCCL)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import poem_v2_amd as pk  # noqa: E402
+from poem_v2_amd import dist as pdist  # noqa: E402
+from poem_v2_amd.metrics import MeanEPE  # noqa: E402
+
+# scripts/eval_single.py:5-36 upstream (urls kept for the record; the tars are not shipped)
+DATASET_META = {
+    "HO3D": {"url": "data/dataset_tars/HO3D_mv_test/HO3D_mv_test-{000000..000002}.tar", "max_view": 5, "epoch_size": 2706},
+    "DexYCB": {"url": "data/dataset_tars/DexYCB_mv/DexYCB_mv_test-{000000..000003}.tar", "max_view": 8, "epoch_size": 4950},
+    "Arctic": {"url": "data/dataset_tars/Arctic_mv/Arctic_mv_val_p1-{000000..000045}.tar", "max_view": 8, "epoch_size": 17392},
+    "Interhand": {"url": "data/dataset_tars/Interhand_mv/Interhand_mv_val-{000000..000022}.tar", "max_view": 8, "epoch_size": 85255},
+    "Oakink": {"url": "data/dataset_tars/Oakink_mv/Oakink_mv_test-{000000..000045}.tar", "max_view": 4, "epoch_size": 21351},
+    "Freihand": {"url": "data/dataset_tars/Freihand_mv/Freihand_mv_test-{000000..000000}.tar", "max_view": 1, "epoch_size": 3960},
+}
+MODEL_CATEGORY = ["small", "medium", "large", "huge", "medium_MANO"]
+EMBED_SIZE = [128, 256, 512, 1024, 256]
+
+
+def edit_cfg(cfg, dataset, model_type, view_range):
+    """The in-place YAML edits of scripts/eval_single.py:63-86 upstream.  Returns the (possibly adjusted) view range."""
+    if dataset not in DATASET_META:
+        raise AssertionError(f"Dataset {dataset} not found in dataset_info.")
+    if model_type not in MODEL_CATEGORY:
+        raise AssertionError(f"Model category {model_type} not found in model_category.")
+    meta = DATASET_META[dataset]
+    test = cfg.setdefault("DATASET", {}).setdefault("TEST", {})
+    tgt = test.setdefault("TARGET", {})
+    tgt["URLS"] = meta["url"]
+    test["EPOCH_SIZE"] = meta["epoch_size"]
+    tgt["EPOCH_SIZE"] = meta["epoch_size"]
+    if dataset == "Freihand":
+        view_range = [1, 1]
+        print("Setting view range to 1 for Freihand dataset.")
+    tgt["VIEW_RANGE"] = list(view_range)
+    embed = EMBED_SIZE[MODEL_CATEGORY.index(model_type)]
+    head = cfg.setdefault("MODEL", {}).setdefault("HEAD", {})
+    head.setdefault("POSITIONAL_ENCODING", {})["NUM_FEATS"] = embed // 2
+    head.setdefault("TRANSFORMER", {})["INPUT_FEAT_DIM"] = embed
+    head["POINTS_FEAT_DIM"] = embed
+    head["EMBED_DIMS"] = embed
+    head["TRANSFORMER"]["PARAMETRIC_OUTPUT"] = model_type == "medium_MANO"
+    return view_range
+
+
+def default_cfg():
+    """A config tree with the release MODEL.HEAD subtree (config/release/train_medium.yaml:185-225 upstream)."""
+    def plain(node):
+        return {k: plain(v) if isinstance(v, dict) else v for k, v in dict(node).items()}
+    head = plain(pk.configs.head_cfg(256))
+    head.pop("MAX_VIEWS", None)
+    return {"DATASET": {"TEST": {"TARGET": {}}}, "MODEL": {"TYPE": "PtEmbedMultiviewStereoV2", "HEAD": head}}
+
+
+def random_views(n_samples, view_range, seed):
+    rng = np.random.RandomState(seed)
+    lo, hi = view_range
+    return rng.randint(lo, hi + 1, size=n_samples).tolist()
+
+
+def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, batch_size=2, seed=0, verbose=True):
+    rank, _, world = pdist.env_world()
+    head_node = pk.CN(cfg["MODEL"]["HEAD"])
+    head_node["MAX_VIEWS"] = max(10, int(view_range[1]))
+    head = pk.build_head(head_node, data_preset=pk.CN({}))
+    embed = head.embed_dims
+    if reload:
+        sd = torch.load(reload, map_location="cpu")
+        sd = sd.get("state_dict", sd.get("model", sd)) if isinstance(sd, dict) else sd
+        ignored = head.load_reference_state_dict(sd)
+        if verbose and rank == 0:
+            print(f"reloaded {reload}: {len(ignored)} dead tensors ignored")
+    else:
+        head.load_state_dict(pk.weights.seeded_state_dict(embed, seed=0, parametric=head.parametric_output), strict=False)
+    head.set_template(pk.inputs.synthetic_template(1234))
+    if head.parametric_output:
+        raise SystemExit("medium_MANO needs a MANO layer (licence-gated assets): call head.set_mano_layer(fn) from "
+                         "Python; this script evaluates the non-parametric categories")
+    head = head.to(device).eval()
+    views_all = random_views(epoch_size, view_range, seed)
+    lo, hi = pdist.shard_by_views(views_all, rank, world)
+    mpvpe, mpjpe = MeanEPE("verts", device=device), MeanEPE("joints", device=device)
+    n_done, t0 = 0, None
+    with torch.no_grad():
+        for it, s in enumerate(range(lo, hi, batch_size)):
+            views = views_all[s:min(s + batch_size, hi)]
+            b = pk.inputs.synthetic_batch(views, seed=seed * 100003 + s)
+            metas = dict(b["img_metas"])
+            metas["cam_intr"], metas["cam_extr"] = metas["cam_intr"].to(device), metas["cam_extr"].to(device)
+            rj = b["reference_joints"].to(device)
+            preds = head(b["mlvl_feat"].to(device), metas, rj)["all_coords_preds"]
+            g = torch.Generator().manual_seed(seed * 7919 + s)
+            gt = (b["reference_joints"][:, 9:10] + 0.05 * torch.randn(len(views), 799, 3, generator=g)).to(device)
+            mpjpe.feed(preds[-1, :, :21], gt[:, :21])      # lib/models/POEM.py:443-444 upstream: joints then verts
+            mpvpe.feed(preds[-1, :, 21:], gt[:, 21:])
+            if it == 0:                                    # first batch builds the engine; time from the second on
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+            else:
+                n_done += len(views)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0 if t0 else 0.0
+    mpvpe.reduce(), mpjpe.reduce()
+    res = {"dataset_source": "synthetic", "model": model_type, "embed": embed, "view_range": list(view_range),
+           "samples": int(mpvpe.acc[1].item()), "MPVPE_mm_vs_synthetic_gt": mpvpe.result() * 1e3,
+           "MPJPE_mm_vs_synthetic_gt": mpjpe.result() * 1e3,
+           "samples_per_s_rank0": (n_done / dt) if dt > 0 and n_done else None, "world_size": world}
+    return res
+
+
+def main(args):
+    view_range = [args.view_min, args.view_max]
+    if args.cfg and os.path.exists(args.cfg):
+        with open(args.cfg, "r") as f:
+            cfg = yaml.load(f, Loader=yaml.FullLoader)
+    else:
+        cfg = default_cfg()
+    view_range = edit_cfg(cfg, args.dataset, args.model, view_range)
+    if args.cfg:
+        with open(args.cfg, "w") as f:            # upstream dumps the edited tree back to the same path
+            yaml.dump(cfg, f)
+    rank, local_rank, world = pdist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("eval_single.py needs a GPU: the head runs on the MI355X HIP path only (no CPU fallback)")
+    device = torch.device("cuda", local_rank if world > 1 else args.gpu_id)
+    torch.cuda.set_device(device)
+    if args.draw and rank == 0:
+        print("--draw: rendering is outside the hot path and not built (DESIGN.md section 0); metrics only")
+    res = evaluate(cfg, view_range, args.model, device, reload=args.reload, epoch_size=args.epoch_size,
+                   batch_size=args.batch_size)
+    if rank == 0:
+        exp_id = f"{args.dataset}_view_{view_range[0]}_{view_range[1]}_{args.model}"
+        print(json.dumps({"exp_id": exp_id, **res}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser(description="Eval Single Setting")
+    parser.add_argument("--cfg", type=str, required=True, help="Path to the configuration file.")
+    parser.add_argument("--dataset", type=str, required=True, help="Dataset name.")
+    parser.add_argument("--view_min", type=int, required=True, help="Minimum view range.")
+    parser.add_argument("--view_max", type=int, required=True, help="Maximum view range.")
+    parser.add_argument("--model", type=str, required=True, help="Model category.")
+    parser.add_argument("--gpu_id", "-g", type=int, default=0, required=True, help="GPU ID to run the evaluation.")
+    parser.add_argument("--reload", type=str, default=None, help="Path to the checkpoint to reload.")
+    parser.add_argument("--port", "-p", type=int, default=60000, help="Port to run the evaluation.")
+    parser.add_argument("--draw", "-d", action="store_true", help="Visualize the results.")
+    parser.add_argument("--epoch_size", type=int, default=64, help="Synthetic samples to evaluate (this build).")
+    parser.add_argument("--batch_size", type=int, default=2, help="--val_batch_size of the reference (lib/opt.py:27-30).")
+    main(parser.parse_args())

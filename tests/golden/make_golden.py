@@ -38,6 +38,10 @@ CASES = {
     "small": dict(model="small", embed=128, nsample=4096, views=[2], seed=1, parametric=False, full=False),
     "medium": dict(model="medium", embed=256, nsample=4096, views=[2, 8], seed=2, parametric=False, full=False),
     "large": dict(model="large", embed=512, nsample=4096, views=[10], seed=3, parametric=False, full=False),
+    # BASELINE config c5 in miniature: ragged view counts at the medium release shape
+    "ragged": dict(model="medium", embed=256, nsample=4096, views=[3, 10, 1, 6], seed=4, parametric=False, full=False),
+    # BASELINE config c3's model: medium_MANO release shape (parametric tail with the toy MANO stand-in)
+    "mediummano": dict(model="medium_MANO", embed=256, nsample=4096, views=[8], seed=5, parametric=True, full=False),
 }
 
 
@@ -168,11 +172,50 @@ def run_mepe():
     os.chdir(ROOT)
 
 
+def run_evalcfg():
+    """The YAML edits and the command line of the reference's scripts/eval_single.py (main(), :41-100) for a few
+    settings, recorded as data: the build's scripts/eval_single.py must reproduce them."""
+    import importlib.util
+    import types
+    import yaml
+    spec = importlib.util.spec_from_file_location("ref_eval_single", os.path.join(rh.REF_ROOT, "scripts", "eval_single.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = []
+    for dataset, model, vmin, vmax in (("DexYCB", "medium", 2, 8), ("HO3D", "small", 1, 5), ("Freihand", "large", 3, 4),
+                                       ("Arctic", "medium_MANO", 8, 8), ("Oakink", "huge", 1, 4)):
+        d = tempfile.mkdtemp(prefix="poem_evalcfg_")
+        cfgp = os.path.join(d, "cfg.yaml")
+        shutil.copy(os.path.join(rh.REF_ROOT, "config", "release", "eval_single.yaml"), cfgp)
+        cmds = []
+        mod.subprocess = types.SimpleNamespace(run=lambda c, shell: (cmds.append(c), types.SimpleNamespace(returncode=0))[1])
+        args = types.SimpleNamespace(cfg=cfgp, dataset=dataset, model=model, gpu_id=0, view_min=vmin, view_max=vmax,
+                                     reload="ckpt.pth", port=60000, draw=False)
+        mod.main(args)
+        with open(cfgp) as f:
+            y = yaml.load(f, Loader=yaml.FullLoader)
+        h = y["MODEL"]["HEAD"]
+        out.append(dict(dataset=dataset, model=model, view_min=vmin, view_max=vmax,
+                        urls=y["DATASET"]["TEST"]["TARGET"]["URLS"], epoch_size=y["DATASET"]["TEST"]["EPOCH_SIZE"],
+                        target_epoch_size=y["DATASET"]["TEST"]["TARGET"]["EPOCH_SIZE"],
+                        view_range=y["DATASET"]["TEST"]["TARGET"]["VIEW_RANGE"],
+                        num_feats=h["POSITIONAL_ENCODING"]["NUM_FEATS"], input_feat_dim=h["TRANSFORMER"]["INPUT_FEAT_DIM"],
+                        points_feat_dim=h["POINTS_FEAT_DIM"], embed_dims=h["EMBED_DIMS"],
+                        parametric=h["TRANSFORMER"]["PARAMETRIC_OUTPUT"],
+                        exp_id=cmds[0].split("--exp_id ")[1].split(" ")[0]))
+        shutil.rmtree(d, ignore_errors=True)
+    with open(os.path.join(HERE, "evalcfg.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("evalcfg:", len(out), "settings")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or list(CASES) + ["mepe"]
+    which = sys.argv[1:] or list(CASES) + ["mepe", "evalcfg"]
     torch.set_num_threads(8)
     for n in which:
         if n == "mepe":
             run_mepe()
+        elif n == "evalcfg":
+            run_evalcfg()
         else:
             run_case(n, CASES[n])

@@ -190,3 +190,28 @@ def test_dp_metric_allreduce_gloo_world2(tmp_path):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "DP_OK" in out.stdout
+
+
+def test_eval_single_cfg_edits_match_reference():
+    """scripts/eval_single.py reproduces the reference script's YAML edits and exp_id (golden: tests/golden/evalcfg.json,
+    recorded by running the reference's own main() with the shell-out stubbed)."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("eval_single", os.path.join(root, "scripts", "eval_single.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for g in json.load(open(os.path.join(root, "tests", "golden", "evalcfg.json"))):
+        cfg = m.default_cfg()
+        vr = m.edit_cfg(cfg, g["dataset"], g["model"], [g["view_min"], g["view_max"]])
+        t, h = cfg["DATASET"]["TEST"], cfg["MODEL"]["HEAD"]
+        assert t["TARGET"]["URLS"] == g["urls"] and t["EPOCH_SIZE"] == g["epoch_size"]
+        assert t["TARGET"]["EPOCH_SIZE"] == g["target_epoch_size"] and t["TARGET"]["VIEW_RANGE"] == g["view_range"]
+        assert h["POSITIONAL_ENCODING"]["NUM_FEATS"] == g["num_feats"] and h["EMBED_DIMS"] == g["embed_dims"]
+        assert h["TRANSFORMER"]["INPUT_FEAT_DIM"] == g["input_feat_dim"] and h["POINTS_FEAT_DIM"] == g["points_feat_dim"]
+        assert h["TRANSFORMER"]["PARAMETRIC_OUTPUT"] == g["parametric"]
+        assert f"{g['dataset']}_view_{vr[0]}_{vr[1]}_{g['model']}" == g["exp_id"]
+    import pytest
+    with pytest.raises(AssertionError):
+        m.edit_cfg(m.default_cfg(), "NoSuchSet", "medium", [1, 2])

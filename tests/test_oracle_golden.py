@@ -33,7 +33,7 @@ def test_tiny_stage_taps(name):
         assert _maxdiff(out["pred_shape"], z["pred_shape"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["small", "medium", "large"])
+@pytest.mark.parametrize("name", ["small", "medium", "large", "ragged", "mediummano"])
 def test_release_shapes(name):
     z, meta = load_golden(name)
     cfg, w, consts, batch = case_setup(meta["spec"])
@@ -46,6 +46,9 @@ def test_release_shapes(name):
     # MPVPE-vs-reference bar of BASELINE.json: 1e-3 mm = 1e-6 m
     assert err.mean() < 1e-6, err.mean()
     assert _maxdiff(got, ref) < 5e-5
+    if meta["spec"]["parametric"]:     # medium_MANO tail (Q3 + rot6d -> axis-angle), toy MANO stand-in on both sides
+        assert _maxdiff(out["pred_pose"], z["pred_pose"]) < 1e-4
+        assert _maxdiff(out["pred_shape"], z["pred_shape"]) < 1e-5
 
 
 def test_hoisted_cross_attention_is_equivalent():
