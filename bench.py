@@ -176,13 +176,19 @@ def main():
     if n_launch > 0:
         avg_s = va_ms / n_launch * 1e-3
         ach = vecattn_flops_per_launch(args.batch, C) / avg_s / 1e12
+        # HBM bytes per launch from the committed PMC passes (tools/collect_profiles.sh; FETCH_SIZE x2 correction applied
+        # by tools/pmc_summary.py) -- the counters need their own rocprofv3 runs, so the newest profile on disk is quoted
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_vecattn.json")
-        if os.path.exists(pmc):
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                ks = json.load(open(pmc))["kernels"]
+                va = [v for k, v in ks.items() if k.startswith("vecattn_kernel") and "hbm_bytes_per_launch" in v]
+                if va:
+                    traffic = va[0]["hbm_bytes_per_launch"]
+                    break
             except Exception:
-                traffic = None
+                continue
         res["roofline"] = {"kernel": "vecattn_kernel (fused vector attention)", "bound": "mfma", "achieved": ach,
                            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
                            "traffic": traffic, "launches_timed": n_launch, "avg_launch_ms": va_ms / n_launch,
