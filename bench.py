@@ -95,6 +95,39 @@ def cpu_baseline(model_embed, batch, n_samples):
                       f"{phys} physical cores)"}, out
 
 
+def eager_baseline(model_embed, batch, n_samples, dev):
+    """BASELINE.json configs[1] names a "PyTorch-ROCm baseline": the same restatement (the oracle) run eagerly on the
+    GPU through PyTorch-ROCm's own kernels, on the same bounded sample as the CPU leg.  Reported, never shipped."""
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import poem_oracle as po
+    from util import oracle_consts
+    cfg = po.PathConfig(embed=model_embed)
+    w = {k: v.to(dev) for k, v in pk.weights.seeded_state_dict(model_embed, seed=0).items()}
+    consts = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in oracle_consts(4096).items()}
+    m = batch["img_metas"]
+    views = [int(v) for v in m["cam_view_num"]][:n_samples]
+    bn = int(np.sum(views))
+    args = (batch["mlvl_feat"][:bn].to(dev), m["cam_intr"][:bn].to(dev), m["cam_extr"][:bn].to(dev), views,
+            batch["reference_joints"][:n_samples].to(dev))
+
+    def run():
+        with torch.no_grad():
+            return po.head_forward(w, cfg, consts, *args, inp_img_shape=m["inp_img_shape"])["all_coords_preds"]
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": n_samples / dt, "unit": "samples/s", "kind": "port on PyTorch-ROCm eager (same GPU)",
+            "sample": f"{n_samples} samples x {views[0]} views per pass, mean of {reps} passes"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +233,11 @@ def main():
         got = preds["all_coords_preds"][:, :args.cpu_samples].cpu()
         res["mpvpe_vs_oracle_mm"] = float(torch.norm(got[-1, :, 21:] - ref[-1, :, 21:], dim=-1).mean()) * 1e3
         res["speedup_vs_cpu"] = value / base["value"]
+        try:
+            res["eager_baseline"] = eager_baseline(C, batch, args.cpu_samples, dev)
+            res["speedup_vs_eager"] = value / res["eager_baseline"]["value"]
+        except Exception as e:   # the eager leg is informational: never fail the bench line on it
+            res["eager_baseline"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

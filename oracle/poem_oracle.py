@@ -71,7 +71,7 @@ def sine_pe_3d(n_views, H, W, num_feats, temperature=10000.0, scale=2 * math.pi,
 
 def positional_table(w, n_views, H, W, embed):
     """adapt_pos3d(sine PE) for a sample with n_views views -> (N, C, H, W) (ptEmb_head.py:857-858)."""
-    pe = sine_pe_3d(n_views, H, W, embed // 2)
+    pe = sine_pe_3d(n_views, H, W, embed // 2).to(w["adapt_pos3d.weight"].device)
     return F.conv2d(pe, w["adapt_pos3d.weight"], w["adapt_pos3d.bias"])
 
 
@@ -355,9 +355,9 @@ def head_forward(w, cfg, consts, mlvl_feat, cam_intr, cam_extr, cam_view_num, re
     x = x + pe                                                                                   # :870
     centre = reference_joints[:, 9, :]                                                           # :873 (always joint 9)
     bps_world = consts["bps"][None] + centre[:, None, :]                                         # :874,790-809
-    view_sample = torch.repeat_interleave(torch.arange(B), torch.tensor(views))
+    view_sample = torch.repeat_interleave(torch.arange(B), torch.tensor(views)).to(mlvl_feat.device)
     uv = project_points(bps_world, cam_intr, cam_extr, view_sample)                              # :878
-    inp_res = torch.tensor([inp_w, inp_h], dtype=torch.float32)
+    inp_res = torch.tensor([inp_w, inp_h], dtype=torch.float32, device=mlvl_feat.device)
     grid = uv * (1.0 / inp_res) * 2 - 1                                                          # :880-883
     g = grid_sample_bilinear(x, grid)                                                            # :900-901 (BN,C,S)
     offs = np.concatenate([[0], np.cumsum(views)])
