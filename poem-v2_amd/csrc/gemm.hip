@@ -211,7 +211,7 @@ extern "C" hipError_t poem_launch_gemm2(const float* X, int ldx, const void* Wp,
 // weights concatenated along N) reads X from HBM once per panel pass.  Plain formulation D[m][n] (lane = output column):
 // every store instruction writes two full 128-byte row segments.
 // act2 applies to columns >= act_split (two Linears with different activations fused along N).
-template <int NT, int MT>
+template <int NT, int MT, bool GELU>
 __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restrict__ X, int ldx,
                                                             const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                             const float* __restrict__ R, int ldr, float* __restrict__ Y,
@@ -231,6 +231,10 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
   const int mtiles = (M + 31) / 32;
   const int rgroups = (mtiles + MT - 1) / MT;
   const int pact = (panel * NT * 32 >= act_split) ? act2 : act;
+  float bv[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) bv[n] = bias ? bias[(panel * NT + n) * 32 + r] : 0.f;
+  const size_t lane_yo = (size_t)(4 * h) * ldy + r, lane_ro = (size_t)(4 * h) * ldr + r;
   for (int rg = bip * NWV + wv; rg < rgroups; rg += blocks_in_panel * NWV) {
     const int mt0 = rg * MT;
     const float4* xp[MT];
@@ -268,23 +272,65 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
 #undef POEM_LOADA
 #undef POEM_LOADB
 #undef POEM_MMA
+    // Epilogue.  The partner wave on this SIMD is usually inside its MFMA loop and the two compete for issue slots, so
+    // every instruction here costs several times its nominal latency: bias lives in registers for the whole block, the
+    // store address is a wave-uniform (scalar) row base + one per-lane offset, and in-bounds tiles skip the row checks.
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int col = (panel * NT + n) * 32 + r;
-      const float bv = bias ? bias[col] : 0.f;
+    for (int i = 0; i < MT; ++i) {
+      const int trow0 = (mt0 + i) * 32;
+      if (trow0 >= M) break;
+      float* yl = Y + (size_t)trow0 * ldy + (size_t)panel * NT * 32 + lane_yo;               // per-lane base, once
+      const float* rl = R ? R + (size_t)trow0 * ldr + (size_t)panel * NT * 32 + lane_ro : nullptr;
+      const bool full = trow0 + 32 <= M;
+      // bias + activation in place (branch outside the register loops)
+      if (GELU && pact == 2) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = (mt0 + i) * 32 + mfma_row(e, h);
-          if (row < M) {
-            float v = acc[i][n][e] + bv;
-            if (pact == 1) v = fmaxf(v, 0.f);
-            if (pact == 2) v = gelu_erf(v);
-            if (R) v += R[(size_t)row * ldr + col];
-            Y[(size_t)row * ldy + col] = v;
+          for (int e = 0; e < 16; ++e) acc[i][n][e] = gelu_erf(acc[i][n][e] + bv[n]);
+      } else if (pact == 1) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][n][e] = fmaxf(acc[i][n][e] + bv[n], 0.f);
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][n][e] += bv[n];
+      }
+      if (full) {
+        if (rl) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            float rr[16];                                      // 16 residual loads in flight, then 16 stores
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rr[e] = rl[(size_t)((e & 3) + 8 * (e >> 2)) * ldr + n * 32];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int ro = (e & 3) + 8 * (e >> 2);          // row inside the tile is ro + 4h
+              yl[(size_t)ro * ldy + n * 32] = acc[i][n][e] + rr[e];
+            }
           }
+        } else {
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int ro = (e & 3) + 8 * (e >> 2);
+              yl[(size_t)ro * ldy + n * 32] = acc[i][n][e];
+            }
         }
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int ro = (e & 3) + 8 * (e >> 2);
+            if (trow0 + ro + 4 * h < M)
+              yl[(size_t)ro * ldy + n * 32] = acc[i][n][e] + (rl ? rl[(size_t)ro * ldr + n * 32] : 0.f);
+          }
       }
     }
   }
@@ -301,12 +347,12 @@ static int poem_num_cus() {
   return cus;
 }
 
-template <int NT, int MT>
+template <int NT, int MT, bool GELU>
 static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
                                  float* Y, int ldy, int M, int N, int K, int act, int act_split, int act2,
                                  hipStream_t s) {
   const size_t lds = (size_t)NT * (K / 8) * 64 * 16;
-  auto kern = gemm_panel_kernel<NT, MT>;
+  auto kern = gemm_panel_kernel<NT, MT, GELU>;
   static size_t lds_set = 0;
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -329,6 +375,9 @@ extern "C" hipError_t poem_launch_gemm_split(const float* X, int ldx, const void
   int NT = 0;
   for (int c : {4, 2, 1})
     if (N % (32 * c) == 0 && (size_t)c * K * 128 <= 128 * 1024 && (act_split >= N || act_split % (32 * c) == 0)) { NT = c; break; }
+  // deep K leaves room for a single 32-column tile per panel, which re-reads X every 8 MFMAs: the operands-from-L2
+  // kernel is faster there (ffn output Linear, K = 4C)
+  if (NT == 1 && N >= 64 && K >= 512 && !(act_split < N && act2 != act)) NT = 0;
   if (NT == 0 || K % 8 || ((uintptr_t)X & 15) || ldx % 4) {
     if (act_split < N && act2 != act) return hipErrorInvalidValue;
     return poem_launch_gemm2(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, 0, 0, s);
@@ -337,9 +386,13 @@ extern "C" hipError_t poem_launch_gemm_split(const float* X, int ldx, const void
   const int wpp = std::max(1, std::max(poem_num_cus(), panels) / panels) * 8;       // waves per panel
   auto cost = [&](int mt) { return (long)(((mtiles + mt - 1) / mt + wpp - 1) / wpp) * mt; };
   const bool mt2 = 5 * cost(2) <= 6 * cost(1);   // 64-row wave tiles unless the 32-row split balances >= 20 % better
+  const bool gelu = act == 2 || (act_split < N && act2 == 2);
 #define POEM_PANEL(NTV)                                                                                            \
-  return mt2 ? launch_panel_t<NTV, 2>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)           \
-             : launch_panel_t<NTV, 1>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)
+  if (gelu)                                                                                                        \
+    return mt2 ? launch_panel_t<NTV, 2, true>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)   \
+               : launch_panel_t<NTV, 1, true>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s);  \
+  return mt2 ? launch_panel_t<NTV, 2, false>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)    \
+             : launch_panel_t<NTV, 1, false>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)
   if (NT == 4) { POEM_PANEL(4); }
   if (NT == 2) { POEM_PANEL(2); }
   POEM_PANEL(1);

@@ -248,6 +248,97 @@ __global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_wres_rm_kernel(const f
   }
 }
 
+
+// ---- V6: as V5 but the store epilogue is software-pipelined: a unit = (row group of MT tiles, NTH = NT/2 column tiles);
+// two accumulator sets alternate, the previous unit's results are stored 2*MT*NTH values at a time between chunk pairs
+// of the current unit's K loop, so stores trickle out at a steady rate instead of chip-wide bursts.
+template <int NT, int MT, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV / 4) void gemm_pipe_kernel(const float* __restrict__ X, const float4* __restrict__ Wp,
+                                                          const float* __restrict__ bias, float* __restrict__ Y,
+                                                          int M, int N, int K, int act) {
+  constexpr int NTH = NT / 2;
+  const int KC = K >> 3;
+  const int PP = KC >> 4;                 // chunk pairs per two accumulator registers (K % 128 == 0)
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int panels = N / (32 * NT);
+  const int panel = blockIdx.x % panels, bip = blockIdx.x / panels;
+  const int blocks_in_panel = ((int)gridDim.x - panel + panels - 1) / panels;
+  {
+    const float4* src = Wp + (size_t)panel * NT * KC * 64;
+    for (int i = tid; i < NT * KC * 64; i += NWV * 64) wl[i] = src[i];
+  }
+  __syncthreads();
+  const int mtiles = (M + 31) / 32;
+  const int rgroups = (mtiles + MT - 1) / MT;
+  const int rg0 = bip * NWV + wv, rstride = blocks_in_panel * NWV;
+  if (rg0 >= rgroups) return;
+  const int nunits = ((rgroups - rg0 + rstride - 1) / rstride) * 2;     // (row group, half) units of this wave
+
+  f32x16 accA[MT][NTH], accB[MT][NTH];
+#define ZERO(ACC) _Pragma("unroll") for (int i = 0; i < MT; ++i) _Pragma("unroll") for (int n = 0; n < NTH; ++n) ACC[i][n] = zero16();
+#define STORE_REG(ACC, U, E)                                                                     \
+  {                                                                                              \
+    const int rgp_ = rg0 + ((U) >> 1) * rstride, hf_ = (U) & 1;                                    \
+    _Pragma("unroll") for (int n = 0; n < NTH; ++n) {                                            \
+      const int col_ = (panel * NT + hf_ * NTH + n) * 32 + r;                                    \
+      const float bv_ = bias ? bias[col_] : 0.f;                                                 \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                           \
+        const int row_ = (rgp_ * MT + i) * 32 + mfma_row((E), h);                                \
+        if (row_ < M) {                                                                          \
+          float v_ = ACC[i][n][(E)] + bv_;                                                       \
+          if (act == 1) v_ = fmaxf(v_, 0.f);                                                     \
+          Y[(size_t)row_ * N + col_] = v_;                                                       \
+        }                                                                                        \
+      }                                                                                          \
+    }                                                                                            \
+  }
+#define LOADA(A, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) A[i] = xp[i][(size_t)kq_ * 2]; }
+#define LOADB(B, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int n = 0; n < NTH; ++n) B[n] = wb[(n * KC + kq_) * 64]; }
+#define MMA(ACC, A, B) _Pragma("unroll") for (int t = 0; t < 4; ++t) { _Pragma("unroll") for (int n = 0; n < NTH; ++n) { const float bv = (&B[n].x)[t]; \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) ACC[i][n] = mfma32((&A[i].x)[t], bv, ACC[i][n]); } }
+  // one unit: K loop into CUR while the previous unit's PREV registers are stored two at a time
+#define UNIT(CUR, PREV, U)                                                                       \
+  {                                                                                              \
+    const int rg_ = rg0 + ((U) >> 1) * rstride, half_ = (U) & 1;                                 \
+    const float4* xp[MT];                                                                        \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                               \
+      xp[i] = reinterpret_cast<const float4*>(X + (size_t)min((rg_ * MT + i) * 32 + r, M - 1) * K + 4 * h); \
+    const float4* wb = wl + (size_t)half_ * NTH * KC * 64 + lane;                                \
+    ZERO(CUR)                                                                                    \
+    float4 a0[MT], a1[MT], b0[NTH], b1[NTH];                                                     \
+    LOADA(a0, 0) LOADB(b0, 0)                                                                    \
+    int kc = 0;                                                                                  \
+    _Pragma("unroll") for (int e2 = 0; e2 < 8; ++e2) {                                           \
+      for (int p = 0; p < PP; ++p, kc += 2) {                                                    \
+        LOADA(a1, kc + 1) LOADB(b1, kc + 1)                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        MMA(CUR, a0, b0)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        LOADA(a0, kc + 2) LOADB(b0, kc + 2)                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        MMA(CUR, a1, b1)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+      }                                                                                          \
+      if ((U) > 0) { STORE_REG(PREV, (U) - 1, 2 * e2) STORE_REG(PREV, (U) - 1, 2 * e2 + 1) }     \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    }                                                                                            \
+  }
+  for (int u = 0; u < nunits; u += 2) {
+    UNIT(accA, accB, u)
+    UNIT(accB, accA, u + 1)
+  }
+  // drain: the last unit (always odd index -> accB)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) STORE_REG(accB, nunits - 1, e)
+#undef ZERO
+#undef STORE_REG
+#undef LOADA
+#undef LOADB
+#undef MMA
+#undef UNIT
+}
+
 static float time_it(std::function<void()> fn, int n = 10) {
   hipEvent_t s, e; CK(hipEventCreate(&s)); CK(hipEventCreate(&e));
   for (int i = 0; i < 2; ++i) fn();
@@ -261,8 +352,8 @@ static float time_it(std::function<void()> fn, int n = 10) {
 
 int main() {
   const int K = 256;
-  for (int M : {131072, 25568, 1048576}) {
-    for (int N : {256, 512, 768, 1280}) {
+  for (int M : {131072}) {
+    for (int N : {256}) {
       if (M > 200000 && N > 256) continue;
       size_t xb = packed_linear_floats(M, K) * 4, yb = packed_linear_floats(M, N) * 4;
       float *x, *xpa, *w, *wp, *b, *y1, *y2;
@@ -300,6 +391,14 @@ int main() {
       run_wres(gemm_wres_kernel<256, 4, 2, 8, 0>, 4, 8, "wres MT2 8w");
       run_wres(gemm_wres_kernel<256, 4, 2, 4, 0>, 4, 4, "wres MT2 4w");
       run_wres(gemm_wres_kernel<256, 4, 1, 8, 0>, 4, 8, "wres MT1 8w");
+      for (int mode : {8, 11}) {
+        CK(hipMemset(dbg, 0, 256 * 3 * 8));
+        if (mode == 8) run_wres(gemm_wres_kernel<256, 4, 2, 8, 8>, 4, 8, "wres MT2 8w timed");
+        else run_wres(gemm_wres_kernel<256, 4, 2, 8, 11>, 4, 8, "wres MT2 8w timed nost+L2X");
+        std::vector<long long> hd(256 * 3); CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
+        long long base = hd[0];
+        for (int sl = 0; sl < 16; ++sl) if (hd[sl * 3]) printf("   slot %2d (wave %d): start %8lld  loop %7lld  epi %6lld\n", sl, sl % 8, hd[sl * 3] - base, hd[sl * 3 + 1] - hd[sl * 3], hd[sl * 3 + 2] - hd[sl * 3 + 1]);
+      }
       {
         float* yr1; float* yr2; const size_t rb = (size_t)((M + 31) / 32 * 32) * N * 4;
         CK(hipMalloc(&yr1, rb)); CK(hipMalloc(&yr2, rb)); CK(hipMemset(yr2, 0, rb));
@@ -314,6 +413,24 @@ int main() {
         CK(hipMemcpy(h1.data(), yr1, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), yr2, h2.size() * 4, hipMemcpyDeviceToHost));
         size_t bad = 0; for (size_t i = 0; i < h1.size(); ++i) if (h1[i] != h2[i]) ++bad;
         printf("M=%8d N=%d  %-22s %8.1f us %6.1f TF  mismatches=%zu\n", M, N, "wres RM->RM MT2 8w", t * 1e3, fl / t / 1e9, bad);
+        {
+          auto k2 = gemm_pipe_kernel<4, 2, 8>;
+          CK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          CK(hipMemset(yr2, 0, rb));
+          float t2 = time_it([&] { hipLaunchKernelGGL(k2, dim3(256), dim3(512), lds, 0, (const float*)x, (const float4*)wp, b, yr2, M, N, K, 0); });
+          CK(hipGetLastError());
+          CK(hipMemcpy(h2.data(), yr2, h2.size() * 4, hipMemcpyDeviceToHost));
+          size_t bad2 = 0; for (size_t i = 0; i < h1.size(); ++i) if (h1[i] != h2[i]) ++bad2;
+          printf("M=%8d N=%d  %-22s %8.1f us %6.1f TF  mismatches=%zu\n", M, N, "pipe RM->RM MT2 8w", t2 * 1e3, fl / t2 / 1e9, bad2);
+          auto k3 = gemm_pipe_kernel<4, 1, 8>;
+          CK(hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          CK(hipMemset(yr2, 0, rb));
+          t2 = time_it([&] { hipLaunchKernelGGL(k3, dim3(256), dim3(512), lds, 0, (const float*)x, (const float4*)wp, b, yr2, M, N, K, 0); });
+          CK(hipGetLastError());
+          CK(hipMemcpy(h2.data(), yr2, h2.size() * 4, hipMemcpyDeviceToHost));
+          bad2 = 0; for (size_t i = 0; i < h1.size(); ++i) if (h1[i] != h2[i]) ++bad2;
+          printf("M=%8d N=%d  %-22s %8.1f us %6.1f TF  mismatches=%zu\n", M, N, "pipe RM->RM MT1 8w", t2 * 1e3, fl / t2 / 1e9, bad2);
+        }
         CK(hipFree(yr1)); CK(hipFree(yr2));
       }
       CK(hipFree(x)); CK(hipFree(xpa)); CK(hipFree(w)); CK(hipFree(wp)); CK(hipFree(b)); CK(hipFree(y1)); CK(hipFree(y2));
