@@ -140,7 +140,11 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="0: issue every kernel on one stream (A/B of the side streams)")
     args = ap.parse_args()
 
-    rank, local_rank, world = pdist.init_from_env()
+    # POEM_DIST_BACKEND=gloo + POEM_SINGLE_DEVICE=1: rehearse the N-rank code path on a 1-GPU box (all ranks share cuda:0;
+    # RCCL itself refuses two ranks on one device).  The driver's real runs use the default: nccl == RCCL, one GPU per rank.
+    rank, local_rank, world = pdist.init_from_env(os.environ.get("POEM_DIST_BACKEND"))
+    if os.environ.get("POEM_SINGLE_DEVICE") == "1":
+        local_rank = 0
     if world != args.gpus:
         if rank == 0:
             print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
