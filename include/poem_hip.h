@@ -28,6 +28,8 @@
  *   poem_vector_attention     ptTransformerBlock._forward / ptTransformerBlock_CrossAttn._forward from
  *                             fc_delta to the softmax-weighted sum (point_transformers.py:88-95,144-151)
  *   poem_reg_update           reg_branch second Linear + xyz residual (pt_metro_transformer.py:38)
+ *   poem_triangulate_dlt      batch_triangulate_dlt_torch + the ragged per-sample loop (lib/utils/triangulation.py:5-45,
+ *                             lib/models/POEM.py:284-299) -- the stage that produces reference_joints
  *   poem_head_forward         POEM_Generalized_Head.forward + PtEmbedTRv4.forward (ptEmb_head.py:825-964,
  *                             lib/models/layers/ptEmb_transformer.py:371-376)
  */
@@ -161,6 +163,13 @@ int poem_merge_finalize(const float* g, const float* y, const int32_t* view_offs
 size_t poem_cross_attention_scratch_bytes(int batch, int nq, int nk, int embed, int heads);
 int poem_cross_attention(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk,
                          int embed, int heads, void* scratch, size_t scratch_bytes, void* stream);
+/* Ragged batched DLT triangulation -- replaces lib/utils/triangulation.py:5-45 (batch_triangulate_dlt_torch) and the
+ * per-sample loop of lib/models/POEM.py:284-299: uv (BN,J,2) pixels, cam_intr (BN,3,3), cam_mat (BN,4,4),
+ * view_offsets (B+1) DEVICE int32 prefix sums of views per sample -> out_xyz (B,J,3) in the master frame.
+ * invert=1: cam_mat is the batch's cam_extr (camera->master) and is inverted here (POEM.py:286);
+ * invert=0: cam_mat is already master->camera (the `Extrs` argument of the reference function). */
+int poem_triangulate_dlt(const float* uv, const float* cam_intr, const float* cam_mat, const int32_t* view_offsets,
+                         int batch, int njoints, int invert, float* out_xyz, void* stream);
 /* idx (B,Q,32) int32: 32 nearest src points per query, ascending squared L2, ties -> lower index. */
 int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream);
 /* Vector attention core.  q (B,Q,C); k,v (B,NS,C) gathered by idx; idx (B,Q,32) or (32) when shared_idx!=0;

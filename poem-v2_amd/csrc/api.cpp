@@ -39,6 +39,8 @@ hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src
                                         int nsrc, const float* wd1, const float* bd1, const void* wd2, const float* bd2,
                                         const void* wg1, const float* bg1, const void* wg2, const float* bg2, float* out,
                                         int B, int Q, int C, int ldq, int ldk, int ldv, hipStream_t s);
+hipError_t poem_launch_dlt(const float* uv, const float* intr, const float* mat, const int* offs, float* out, int B, int J,
+                           int invert, hipStream_t s);
 hipError_t poem_launch_gemm_split(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
                                   float* Y, int ldy, int M, int N, int K, int act, int act_split, int act2, hipStream_t s);
 hipError_t poem_launch_prep_xyz(const float* ref_joints, const float* bps, const float* tmpl, float* centre,
@@ -732,6 +734,14 @@ int poem_reg_update(const float* r, const float* w, const float* b, const float*
                     int embed, void* stream) {
   if (!r || !w || !b || !xyz_in || !xyz_out || rows <= 0) return POEM_E_ARG;
   HIPCHK(poem_launch_narrow_linear(r, embed, w, b, xyz_in, xyz_out, rows, embed, 3, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_triangulate_dlt(const float* uv, const float* cam_intr, const float* cam_mat, const int32_t* view_offsets,
+                         int batch, int njoints, int invert, float* out_xyz, void* stream) {
+  if (!uv || !cam_intr || !cam_mat || !view_offsets || !out_xyz || batch <= 0 || njoints <= 0 || (invert & ~1))
+    return POEM_E_ARG;
+  HIPCHK(poem_launch_dlt(uv, cam_intr, cam_mat, view_offsets, out_xyz, batch, njoints, invert, (hipStream_t)stream));
   return POEM_OK;
 }
 

@@ -1,0 +1,47 @@
+"""DLT triangulation of the 21 joints from per-view 2-D predictions -- the stage that produces the head's
+``reference_joints`` (lib/models/POEM.py:284-299 upstream).  MI355X-native: one ``poem_triangulate_dlt`` launch for the
+whole ragged batch instead of a Python loop of per-sample ``torch.linalg.svd`` calls.  No CPU fallback.
+
+``batch_triangulate_dlt_torch`` keeps the reference function's name, argument meaning and result
+(lib/utils/triangulation.py:5-45); ``triangulate_reference_joints`` is the ragged, path-level form."""
+import numpy as np
+import torch
+
+from . import hip
+
+
+def _offsets(views, device):
+    offs = np.concatenate([[0], np.cumsum(np.asarray(views, dtype=np.int64))]).astype(np.int32)
+    return torch.from_numpy(offs).to(device)
+
+
+def triangulate_reference_joints(uv, cam_intr, cam_extr, cam_view_num):
+    """uv (BN,J,2) pixel coordinates per view, cam_intr (BN,3,3), cam_extr (BN,4,4) camera->master (the batch's
+    ``target_cam_extr``), cam_view_num (B,) views per sample -> (B,J,3) joints in the master frame."""
+    if not uv.is_cuda:
+        raise RuntimeError("triangulate_reference_joints runs on the MI355X HIP path only (no CPU fallback)")
+    views = [int(v) for v in cam_view_num]
+    BN, J = uv.shape[0], uv.shape[1]
+    if sum(views) != BN or min(views) < 2:
+        raise ValueError("cam_view_num must sum to the number of views and every sample needs >= 2 views for DLT")
+    f32 = lambda t: t.to(device=uv.device, dtype=torch.float32).contiguous()   # noqa: E731
+    uv, cam_intr, cam_extr = f32(uv), f32(cam_intr), f32(cam_extr)
+    out = torch.empty(len(views), J, 3, dtype=torch.float32, device=uv.device)
+    offs = _offsets(views, uv.device)
+    hip.check(hip.lib().poem_triangulate_dlt(hip.ptr(uv), hip.ptr(cam_intr), hip.ptr(cam_extr), offs.data_ptr(), len(views),
+                                             J, 1, hip.ptr(out), hip.stream()), "poem_triangulate_dlt")
+    return out
+
+
+def batch_triangulate_dlt_torch(kp2ds, Ks, Extrs):
+    """kp2ds (B,N,J,2), Ks (B,N,3,3), Extrs (B,N,4,4) master->camera (used as is, like upstream) -> (B,J,3)."""
+    if not kp2ds.is_cuda:
+        raise RuntimeError("batch_triangulate_dlt_torch runs on the MI355X HIP path only (no CPU fallback)")
+    B, N, J = kp2ds.shape[0], kp2ds.shape[1], kp2ds.shape[2]
+    f32 = lambda t: t.to(dtype=torch.float32).contiguous()   # noqa: E731
+    uv, K, T = f32(kp2ds).view(B * N, J, 2), f32(Ks).view(B * N, 3, 3), f32(Extrs).view(B * N, 4, 4)
+    out = torch.empty(B, J, 3, dtype=torch.float32, device=kp2ds.device)
+    offs = _offsets([N] * B, kp2ds.device)
+    hip.check(hip.lib().poem_triangulate_dlt(hip.ptr(uv), hip.ptr(K), hip.ptr(T), offs.data_ptr(), B, J, 0, hip.ptr(out),
+                                             hip.stream()), "poem_triangulate_dlt")
+    return out

@@ -172,6 +172,47 @@ def run_mepe():
     os.chdir(ROOT)
 
 
+def dlt_inputs(views, seed, noise_px=1.5):
+    """Seeded 2-D joint predictions: the synthetic rig's joints projected into every view + pixel noise."""
+    b = synthetic_batch(views, seed=seed)
+    m = b["img_metas"]
+    K, E = m["cam_intr"], m["cam_extr"]
+    T = torch.linalg.inv(E)
+    vs = torch.repeat_interleave(torch.arange(len(views)), torch.tensor(views))
+    X = b["reference_joints"][vs]                                                  # (BN,21,3) master frame
+    pc = (T[:, None, :3, :3] @ X[..., None]).squeeze(-1) + T[:, None, :3, 3]
+    q = (K[:, None] @ pc[..., None]).squeeze(-1)
+    uv = q[..., :2] / q[..., 2:]
+    g = torch.Generator().manual_seed(seed + 99)
+    return uv + noise_px * torch.randn(uv.shape, generator=g), K, E
+
+
+def run_dlt():
+    """Golden vectors of the reference's own triangulation (lib/utils/triangulation.py) -- uniform and ragged."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_tri", os.path.join(rh.REF_ROOT, "lib", "utils", "triangulation.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rec = {}
+    cases = {"u8": ([8] * 6, 41), "u2": ([2] * 5, 42), "ragged": ([3, 10, 2, 6, 8], 43)}
+    for name, (views, seed) in cases.items():
+        uv, K, E = dlt_inputs(views, seed)
+        T = torch.linalg.inv(E)                                                    # POEM.py:286
+        offs = np.concatenate([[0], np.cumsum(views)])
+        outs = [mod.batch_triangulate_dlt_torch(uv[offs[i]:offs[i + 1]][None], K[offs[i]:offs[i + 1]][None],
+                                                T[offs[i]:offs[i + 1]][None]) for i in range(len(views))]
+        rec[name] = torch.cat(outs, 0).numpy()
+        if len(set(views)) == 1:                                                   # the batched call itself
+            B, N = len(views), views[0]
+            rec[name + ".batched"] = mod.batch_triangulate_dlt_torch(uv.view(B, N, 21, 2), K.view(B, N, 3, 3),
+                                                                     T.view(B, N, 4, 4)).numpy()
+    meta = dict(cases={k: dict(views=v[0], seed=v[1]) for k, v in cases.items()},
+                note="inputs = tests/golden/make_golden.py::dlt_inputs(views, seed)")
+    rec["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "dlt.npz"), **rec)
+    print("dlt:", {k: v.shape for k, v in rec.items() if k != "meta"})
+
+
 def run_evalcfg():
     """The YAML edits and the command line of the reference's scripts/eval_single.py (main(), :41-100) for a few
     settings, recorded as data: the build's scripts/eval_single.py must reproduce them."""
@@ -210,12 +251,14 @@ def run_evalcfg():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or list(CASES) + ["mepe", "evalcfg"]
+    which = sys.argv[1:] or list(CASES) + ["mepe", "evalcfg", "dlt"]
     torch.set_num_threads(8)
     for n in which:
         if n == "mepe":
             run_mepe()
         elif n == "evalcfg":
             run_evalcfg()
+        elif n == "dlt":
+            run_dlt()
         else:
             run_case(n, CASES[n])
