@@ -30,6 +30,8 @@
  *   poem_reg_update           reg_branch second Linear + xyz residual (pt_metro_transformer.py:38)
  *   poem_triangulate_dlt      batch_triangulate_dlt_torch + the ragged per-sample loop (lib/utils/triangulation.py:5-45,
  *                             lib/models/POEM.py:284-299) -- the stage that produces reference_joints
+ *   poem_pa_epe /             PAEval.feed + align_w_scale (lib/metrics/pa_eval.py:45-83,104-124) and _PCKMetric.feed
+ *   poem_pck_accumulate       (lib/metrics/pck.py:36-96) -- device-side evaluation metrics
  *   poem_head_forward         POEM_Generalized_Head.forward + PtEmbedTRv4.forward (ptEmb_head.py:825-964,
  *                             lib/models/layers/ptEmb_transformer.py:371-376)
  */
@@ -170,6 +172,16 @@ int poem_cross_attention(const float* q, const float* k, const float* v, float* 
  * invert=0: cam_mat is already master->camera (the `Extrs` argument of the reference function). */
 int poem_triangulate_dlt(const float* uv, const float* cam_intr, const float* cam_mat, const int32_t* view_offsets,
                          int batch, int njoints, int invert, float* out_xyz, void* stream);
+/* Device-side evaluation metrics (replace the host loops of lib/metrics/pa_eval.py:45-83,104-124 and
+ * lib/metrics/pck.py:36-96).
+ * poem_pa_epe: pred, gt (B,P,3) -> out (B,2) = per-sample (Procrustes-aligned mean distance, plain mean distance);
+ *   alignment = PAEval.align_w_scale (scipy orthogonal_procrustes with scale, no reflection handling).
+ * poem_pck_accumulate: adds this batch to counts (P,steps) [#dist <= linspace(val_min,val_max,steps)[t]],
+ *   dist_sum (P) fp64 and n (P); the caller zeroes them at reset and derives pck / auc / epe from them;
+ *   dist_out (B,P) optionally receives this batch's distances (NULL to skip). */
+int poem_pa_epe(const float* pred, const float* gt, float* out, int batch, int npoints, void* stream);
+int poem_pck_accumulate(const float* pred, const float* gt, int batch, int npoints, double val_min, double val_max,
+                        int steps, uint32_t* counts, double* dist_sum, uint32_t* n, float* dist_out, void* stream);
 /* idx (B,Q,32) int32: 32 nearest src points per query, ascending squared L2, ties -> lower index. */
 int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream);
 /* Vector attention core.  q (B,Q,C); k,v (B,NS,C) gathered by idx; idx (B,Q,32) or (32) when shared_idx!=0;

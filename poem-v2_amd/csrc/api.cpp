@@ -41,6 +41,9 @@ hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src
                                         int B, int Q, int C, int ldq, int ldk, int ldv, hipStream_t s);
 hipError_t poem_launch_dlt(const float* uv, const float* intr, const float* mat, const int* offs, float* out, int B, int J,
                            int invert, hipStream_t s);
+hipError_t poem_launch_pa_epe(const float* pred, const float* gt, float* out, int B, int P, hipStream_t s);
+hipError_t poem_launch_pck_accumulate(const float* pred, const float* gt, int B, int P, double vmin, double vmax, int steps,
+                                      unsigned int* counts, double* sum, unsigned int* n, float* dist_out, hipStream_t s);
 hipError_t poem_launch_gemm_split(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
                                   float* Y, int ldy, int M, int N, int K, int act, int act_split, int act2, hipStream_t s);
 hipError_t poem_launch_prep_xyz(const float* ref_joints, const float* bps, const float* tmpl, float* centre,
@@ -742,6 +745,20 @@ int poem_triangulate_dlt(const float* uv, const float* cam_intr, const float* ca
   if (!uv || !cam_intr || !cam_mat || !view_offsets || !out_xyz || batch <= 0 || njoints <= 0 || (invert & ~1))
     return POEM_E_ARG;
   HIPCHK(poem_launch_dlt(uv, cam_intr, cam_mat, view_offsets, out_xyz, batch, njoints, invert, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_pa_epe(const float* pred, const float* gt, float* out, int batch, int npoints, void* stream) {
+  if (!pred || !gt || !out || batch <= 0 || npoints < 3) return POEM_E_ARG;
+  HIPCHK(poem_launch_pa_epe(pred, gt, out, batch, npoints, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_pck_accumulate(const float* pred, const float* gt, int batch, int npoints, double val_min, double val_max,
+                        int steps, uint32_t* counts, double* dist_sum, uint32_t* n, float* dist_out, void* stream) {
+  if (!pred || !gt || !counts || !dist_sum || !n || batch <= 0 || npoints <= 0 || steps <= 0) return POEM_E_ARG;
+  HIPCHK(poem_launch_pck_accumulate(pred, gt, batch, npoints, val_min, val_max, steps, counts, dist_sum, n, dist_out,
+                                    (hipStream_t)stream));
   return POEM_OK;
 }
 

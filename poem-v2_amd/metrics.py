@@ -33,3 +33,151 @@ class MeanEPE:
 
     def __str__(self):
         return f"{self.name}: {self.result():6.4f}"
+
+
+# ---- the remaining evaluation metrics, accumulated on the device ---------------------------------
+def _dev32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class PAEval:
+    """Procrustes-aligned MPJPE / MPVPE -- device counterpart of ``PAEval`` (lib/metrics/pa_eval.py:16-124 upstream).
+
+    Same ``feed`` signature, ``get_measures`` keys, ``get_result`` and string form.  The reference copies every batch to
+    the host and calls scipy once per sample; here ``poem_pa_epe`` aligns the whole batch in one launch and the four
+    sums stay on the device.  No CPU fallback."""
+
+    def __init__(self, cfg=None, mesh_score=False, device="cuda"):
+        self.mesh_score = mesh_score
+        self.device = torch.device(device)
+        self.acc = torch.zeros(5, dtype=torch.float64, device=self.device)   # pa_j, j, pa_v, v, count
+        self.count = 0
+
+    def reset(self):
+        self.acc.zero_()
+        self.count = 0
+
+    def _pair(self, pred, gt):
+        from . import hip
+        pred, gt = _dev32(pred, self.device), _dev32(gt, self.device)
+        if not pred.is_cuda:
+            raise RuntimeError("PAEval runs on the MI355X HIP path only (no CPU fallback)")
+        out = torch.empty(pred.shape[0], 2, dtype=torch.float32, device=self.device)
+        hip.check(hip.lib().poem_pa_epe(hip.ptr(pred), hip.ptr(gt), hip.ptr(out), pred.shape[0], pred.shape[1],
+                                        hip.stream()), "poem_pa_epe")
+        return out.double().sum(0)
+
+    def feed(self, pred_joints_3d_abs, joints_3d_abs, pred_verts_3d_abs=None, verts_3d_abs=None, **kwargs):
+        b = pred_joints_3d_abs.shape[0]
+        self.acc[0:2] += self._pair(pred_joints_3d_abs, joints_3d_abs)
+        if self.mesh_score:
+            self.acc[2:4] += self._pair(pred_verts_3d_abs, verts_3d_abs)
+        self.acc[4] += b
+        self.count += b
+
+    def reduce(self):
+        pdist.all_reduce_sum_(self.acc)
+        return self
+
+    def get_measures(self, **kwargs):
+        a = self.acc.tolist()
+        n = max(a[4], 1.0)
+        m = {"pa_mpjpe": a[0] / n, "mpjpe": a[1] / n}
+        if self.mesh_score:
+            m["pa_mpvpe"], m["mpvpe"] = a[2] / n, a[3] / n
+        return m
+
+    def get_result(self):
+        return self.get_measures()["pa_mpjpe"]
+
+    def __str__(self):
+        m = self.get_measures()
+        s = f"pa_mpjpe(mm): {m['pa_mpjpe'] * 1000.0 :6.4f} | mpjpe: {m['mpjpe']:6.4f}"
+        if self.mesh_score:
+            s += f" | pa_mpvpe(mm): {m['pa_mpvpe'] * 1000.0:6.4f} | mpvpe: {m['mpvpe']:6.4f}"
+        return s
+
+
+class _PCKMetric:
+    """PCK / AUC accumulators -- device counterpart of ``_PCKMetric`` (lib/metrics/pck.py:11-148 upstream): same config
+    keys (VAL_MIN, VAL_MAX, STEPS, EVAL_TYPE), ``feed(preds, targs)``, ``get_pck_all`` and ``get_measures`` keys."""
+    num_kp = 0
+    _keys = {}
+
+    def __init__(self, device="cuda", **cfg):
+        self.val_min, self.val_max, self.steps = float(cfg["VAL_MIN"]), float(cfg["VAL_MAX"]), int(cfg["STEPS"])
+        self.device = torch.device(device)
+        self.reset()
+
+    def reset(self):
+        self.counts = torch.zeros(self.num_kp, self.steps, dtype=torch.int32, device=self.device)
+        self.sum = torch.zeros(self.num_kp, dtype=torch.float64, device=self.device)
+        self.n = torch.zeros(self.num_kp, dtype=torch.int32, device=self.device)
+        self.dists = []          # per-batch (B, num_kp) distance tensors on the device (arbitrary-threshold queries)
+        self.count = 0
+
+    def _get_predictions(self, preds, targs):
+        pk_, tk_ = self._keys[self.eval_type]
+        return preds[pk_].reshape(-1, self.num_kp, 3), targs[tk_].reshape(-1, self.num_kp, 3)
+
+    def feed(self, preds, targs, **kwargs):
+        from . import hip
+        p, t = self._get_predictions(preds, targs)
+        p, t = _dev32(p, self.device), _dev32(t, self.device)
+        if not p.is_cuda:
+            raise RuntimeError("PCK metrics run on the MI355X HIP path only (no CPU fallback)")
+        d = torch.empty(p.shape[0], self.num_kp, dtype=torch.float32, device=self.device)
+        hip.check(hip.lib().poem_pck_accumulate(hip.ptr(p), hip.ptr(t), p.shape[0], self.num_kp, self.val_min, self.val_max,
+                                                self.steps, self.counts.data_ptr(), self.sum.data_ptr(), self.n.data_ptr(),
+                                                hip.ptr(d), hip.stream()), "poem_pck_accumulate")
+        self.dists.append(d)
+        self.count += p.shape[0]
+
+    def reduce(self):
+        """Sum the accumulators over ranks (counts as int64 to stay exact)."""
+        c = self.counts.long()
+        n = self.n.long()
+        pdist.all_reduce_sum_(c), pdist.all_reduce_sum_(n), pdist.all_reduce_sum_(self.sum)
+        self.counts, self.n = c.int(), n.int()
+        return self
+
+    def get_pck_all(self, threshold):
+        d = torch.cat(self.dists, 0).double()
+        return float((d <= threshold).double().mean(0).mean())
+
+    def get_measures(self):
+        import numpy as np
+        thresholds = np.linspace(self.val_min, self.val_max, self.steps)
+        area_under_one = getattr(np, "trapezoid", getattr(np, "trapz", None))(np.ones_like(thresholds), thresholds)
+        n = self.n.cpu().numpy().astype(np.float64)
+        valid = n > 0
+        curve = self.counts.cpu().numpy().astype(np.float64)[valid] / n[valid][:, None]
+        epe = self.sum.cpu().numpy()[valid] / n[valid]
+        auc = getattr(np, "trapezoid", getattr(np, "trapz", None))(curve, thresholds, axis=1) / area_under_one
+        return {"epe_mean_per_kp": epe, "pck_curve_per_kp": curve, "auc_per_kp": auc, "epe_mean_all": float(np.mean(epe)),
+                "auc_all": float(np.mean(auc)), "thresholds": thresholds}
+
+    def __str__(self):
+        return f"h3dpck: {self.get_pck_all(0.02):6.4f}"
+
+
+class Joint3DPCK(_PCKMetric):
+    num_kp = 21
+    _keys = {"joints_3d": ("pred_joints_3d", "master_joints_3d"), "joints_3d_rel": ("pred_joints_3d_rel", "master_joints_3d_rel")}
+
+    def __init__(self, device="cuda", **cfg):
+        self.eval_type = cfg.get("EVAL_TYPE", "joints_3d")
+        if self.eval_type not in self._keys:
+            raise ValueError(f"Unknown eval_type {self.eval_type} in {type(self).__name__}")
+        super().__init__(device=device, **cfg)
+
+
+class Vert3DPCK(_PCKMetric):
+    num_kp = 778
+    _keys = {"verts_3d": ("pred_verts_3d", "master_verts_3d"), "verts_3d_rel": ("pred_verts_3d_rel", "master_verts_3d_rel")}
+
+    def __init__(self, device="cuda", **cfg):
+        self.eval_type = cfg.get("EVAL_TYPE", "verts_3d")
+        if self.eval_type not in self._keys:
+            raise ValueError(f"Unknown eval_type {self.eval_type} in {type(self).__name__}")
+        super().__init__(device=device, **cfg)

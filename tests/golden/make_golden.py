@@ -213,6 +213,43 @@ def run_dlt():
     print("dlt:", {k: v.shape for k, v in rec.items() if k != "meta"})
 
 
+def metric_inputs(seed=7, B=6):
+    g = torch.Generator().manual_seed(seed)
+    gt = 0.08 * torch.randn(B, 799, 3, generator=g) + torch.tensor([0.0, 0.0, 0.6])
+    # prediction = gt rotated / scaled / shifted a little + noise (so the alignment matters)
+    ang = 0.15 * torch.randn(B, generator=g)
+    R = torch.stack([torch.tensor([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+                     for a in ang.tolist()])
+    c = gt.mean(1, keepdim=True)
+    pred = ((gt - c) @ R.transpose(1, 2)) * (1.0 + 0.05 * torch.randn(B, 1, 1, generator=g)) + c
+    pred = pred + 0.004 * torch.randn(B, 799, 3, generator=g) + 0.01 * torch.randn(B, 1, 3, generator=g)
+    return pred, gt
+
+
+def run_metrics():
+    """Measures of the reference's own PAEval / Joint3DPCK / Vert3DPCK on seeded inputs (two feeds each)."""
+    rh.setup()
+    from lib.metrics.pa_eval import PAEval
+    from lib.metrics.pck import Joint3DPCK, Vert3DPCK
+    pred, gt = metric_inputs()
+    pa = PAEval(None, mesh_score=True)
+    cfg = dict(VAL_MIN=0.0, VAL_MAX=0.05, STEPS=20)
+    jp, vp = Joint3DPCK(EVAL_TYPE="joints_3d", **cfg), Vert3DPCK(EVAL_TYPE="verts_3d", **cfg)
+    for sl in (slice(0, 4), slice(4, 6)):
+        pa.feed(pred[sl, :21], gt[sl, :21], pred[sl, 21:], gt[sl, 21:])
+        jp.feed({"pred_joints_3d": pred[sl, :21]}, {"master_joints_3d": gt[sl, :21]})
+        vp.feed({"pred_verts_3d": pred[sl, 21:]}, {"master_verts_3d": gt[sl, 21:]})
+    rec = {"pa." + k: np.float64(v) for k, v in pa.get_measures().items()}
+    for tag, m in (("j", jp), ("v", vp)):
+        ms = m.get_measures()
+        for k in ("epe_mean_per_kp", "pck_curve_per_kp", "auc_per_kp", "epe_mean_all", "auc_all", "thresholds"):
+            rec[f"{tag}.{k}"] = np.asarray(ms[k])
+        rec[f"{tag}.pck_002"] = np.float64(m.get_pck_all(0.02))
+    np.savez_compressed(os.path.join(HERE, "metrics.npz"), **rec)
+    print("metrics:", {k: float(v) for k, v in rec.items() if v.ndim == 0})
+    os.chdir(ROOT)
+
+
 def run_evalcfg():
     """The YAML edits and the command line of the reference's scripts/eval_single.py (main(), :41-100) for a few
     settings, recorded as data: the build's scripts/eval_single.py must reproduce them."""
@@ -251,7 +288,7 @@ def run_evalcfg():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or list(CASES) + ["mepe", "evalcfg", "dlt"]
+    which = sys.argv[1:] or list(CASES) + ["mepe", "evalcfg", "dlt", "metrics"]
     torch.set_num_threads(8)
     for n in which:
         if n == "mepe":
@@ -260,5 +297,7 @@ if __name__ == "__main__":
             run_evalcfg()
         elif n == "dlt":
             run_dlt()
+        elif n == "metrics":
+            run_metrics()
         else:
             run_case(n, CASES[n])
