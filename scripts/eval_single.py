@@ -31,7 +31,8 @@ if ROOT not in sys.path:
 
 import poem_v2_amd as pk  # noqa: E402
 from poem_v2_amd import dist as pdist  # noqa: E402
-from poem_v2_amd.metrics import MeanEPE  # noqa: E402
+from poem_v2_amd.metrics import Joint3DPCK, MeanEPE, PAEval, Vert3DPCK  # noqa: E402
+from poem_v2_amd.triangulation import triangulate_reference_joints  # noqa: E402
 
 # scripts/eval_single.py:5-36 upstream (urls kept for the record; the tars are not shipped)
 DATASET_META = {
@@ -109,6 +110,9 @@ def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, ba
     views_all = random_views(epoch_size, view_range, seed)
     lo, hi = pdist.shard_by_views(views_all, rank, world)
     mpvpe, mpjpe = MeanEPE("verts", device=device), MeanEPE("joints", device=device)
+    pa = PAEval(None, mesh_score=True, device=device)                       # lib/models/POEM.py:147 upstream
+    pck = dict(VAL_MIN=0.0, VAL_MAX=0.02, STEPS=20)                         # AUCCallback defaults, lib/utils/testing.py:31
+    pck_j, pck_v = Joint3DPCK(device=device, EVAL_TYPE="joints_3d", **pck), Vert3DPCK(device=device, EVAL_TYPE="verts_3d", **pck)
     n_done, t0 = 0, None
     with torch.no_grad():
         for it, s in enumerate(range(lo, hi, batch_size)):
@@ -116,12 +120,27 @@ def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, ba
             b = pk.inputs.synthetic_batch(views, seed=seed * 100003 + s)
             metas = dict(b["img_metas"])
             metas["cam_intr"], metas["cam_extr"] = metas["cam_intr"].to(device), metas["cam_extr"].to(device)
-            rj = b["reference_joints"].to(device)
+            # reference joints the way the full model gets them (lib/models/POEM.py:284-299): DLT over each sample's views
+            # of the per-view 2-D joints (here: the synthetic joints projected into every view + 1 px noise)
+            vs = torch.repeat_interleave(torch.arange(len(views)), torch.tensor(views))
+            T = torch.linalg.inv(b["img_metas"]["cam_extr"])
+            X = b["reference_joints"][vs]
+            pc = (T[:, None, :3, :3] @ X[..., None]).squeeze(-1) + T[:, None, :3, 3]
+            q = (b["img_metas"]["cam_intr"][:, None] @ pc[..., None]).squeeze(-1)
+            gn = torch.Generator().manual_seed(seed * 31 + s)
+            uv = q[..., :2] / q[..., 2:] + torch.randn(q[..., :2].shape, generator=gn)
+            if min(views) >= 2:
+                rj = triangulate_reference_joints(uv.to(device), metas["cam_intr"], metas["cam_extr"], views)
+            else:                                        # single-view samples take the given joints (POEM.py:282-283)
+                rj = b["reference_joints"].to(device)
             preds = head(b["mlvl_feat"].to(device), metas, rj)["all_coords_preds"]
             g = torch.Generator().manual_seed(seed * 7919 + s)
             gt = (b["reference_joints"][:, 9:10] + 0.05 * torch.randn(len(views), 799, 3, generator=g)).to(device)
             mpjpe.feed(preds[-1, :, :21], gt[:, :21])      # lib/models/POEM.py:443-444 upstream: joints then verts
             mpvpe.feed(preds[-1, :, 21:], gt[:, 21:])
+            pa.feed(preds[-1, :, :21], gt[:, :21], preds[-1, :, 21:], gt[:, 21:])
+            pck_j.feed({"pred_joints_3d": preds[-1, :, :21]}, {"master_joints_3d": gt[:, :21]})
+            pck_v.feed({"pred_verts_3d": preds[-1, :, 21:]}, {"master_verts_3d": gt[:, 21:]})
             if it == 0:                                    # first batch builds the engine; time from the second on
                 torch.cuda.synchronize(device)
                 t0 = time.perf_counter()
@@ -129,10 +148,12 @@ def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, ba
                 n_done += len(views)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0 if t0 else 0.0
-    mpvpe.reduce(), mpjpe.reduce()
+    mpvpe.reduce(), mpjpe.reduce(), pa.reduce(), pck_j.reduce(), pck_v.reduce()
+    pam = pa.get_measures()
     res = {"dataset_source": "synthetic", "model": model_type, "embed": embed, "view_range": list(view_range),
            "samples": int(mpvpe.acc[1].item()), "MPVPE_mm_vs_synthetic_gt": mpvpe.result() * 1e3,
-           "MPJPE_mm_vs_synthetic_gt": mpjpe.result() * 1e3,
+           "MPJPE_mm_vs_synthetic_gt": mpjpe.result() * 1e3, "PA_MPJPE_mm": pam["pa_mpjpe"] * 1e3,
+           "PA_MPVPE_mm": pam["pa_mpvpe"] * 1e3, "auc_j": pck_j.get_measures()["auc_all"], "auc_v": pck_v.get_measures()["auc_all"],
            "samples_per_s_rank0": (n_done / dt) if dt > 0 and n_done else None, "world_size": world}
     return res
 
