@@ -172,6 +172,11 @@ int poem_cross_attention(const float* q, const float* k, const float* v, float* 
  * invert=0: cam_mat is already master->camera (the `Extrs` argument of the reference function). */
 int poem_triangulate_dlt(const float* uv, const float* cam_intr, const float* cam_mat, const int32_t* view_offsets,
                          int batch, int njoints, int invert, float* out_xyz, void* stream);
+/* Heat-map read-out in front of the triangulation (tail of heatmap_stage, lib/models/POEM.py:213-222, with
+ * integral_heatmap2d, lib/models/integal_pose.py:194-218): heatmaps (BN,J,Hh,Wh) non-negative (sigmoid outputs) ->
+ * uv (BN,J,2) in image pixels: normalise by (sum + 1e-6), expectation of (x/Wh, y/Hh), scale by (img_w, img_h). */
+int poem_heatmap_uv(const float* heatmaps, float* uv, int views, int njoints, int hm_h, int hm_w, float img_w, float img_h,
+                    void* stream);
 /* Device-side evaluation metrics (replace the host loops of lib/metrics/pa_eval.py:45-83,104-124 and
  * lib/metrics/pck.py:36-96).
  * poem_pa_epe: pred, gt (B,P,3) -> out (B,2) = per-sample (Procrustes-aligned mean distance, plain mean distance);

@@ -29,3 +29,18 @@ def triangulate_reference_joints(uv, cam_intr, cam_extr, cam_view_num):
         s, e = int(offs[i]), int(offs[i + 1])
         out.append(batch_triangulate_dlt(uv[s:e][None], cam_intr[s:e][None], T[s:e][None]))
     return torch.cat(out, 0)
+
+
+def heatmap_to_uv(uv_hmap, img_w, img_h):
+    """Tail of heatmap_stage (POEM.py:213-222) with integral_heatmap2d (integal_pose.py:194-218)."""
+    BN, J, Hh, Wh = uv_hmap.shape
+    pdf = uv_hmap.reshape(BN, J, -1)
+    pdf = pdf / (pdf.sum(dim=-1, keepdim=True) + 1e-6)                        # POEM.py:216
+    pdf = pdf.contiguous().view(BN, J, Hh, Wh)
+    v_accu, u_accu = torch.sum(pdf, dim=3), torch.sum(pdf, dim=2)             # integal_pose.py:206-207
+    wv = torch.arange(Hh, dtype=pdf.dtype) / Hh
+    wu = torch.arange(Wh, dtype=pdf.dtype) / Wh
+    v_ = torch.sum(v_accu.mul(wv), dim=-1, keepdim=True)
+    u_ = torch.sum(u_accu.mul(wu), dim=-1, keepdim=True)
+    uv = torch.cat([u_, v_], dim=-1)
+    return torch.einsum("bij,j->bij", uv, torch.tensor([img_w, img_h], dtype=uv.dtype))   # POEM.py:219-221

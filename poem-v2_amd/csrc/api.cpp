@@ -44,6 +44,8 @@ hipError_t poem_launch_dlt(const float* uv, const float* intr, const float* mat,
 hipError_t poem_launch_pa_epe(const float* pred, const float* gt, float* out, int B, int P, hipStream_t s);
 hipError_t poem_launch_pck_accumulate(const float* pred, const float* gt, int B, int P, double vmin, double vmax, int steps,
                                       unsigned int* counts, double* sum, unsigned int* n, float* dist_out, hipStream_t s);
+hipError_t poem_launch_heatmap_uv(const float* hmap, float* uv, int maps, int hh, int hw, float img_w, float img_h,
+                                  hipStream_t s);
 hipError_t poem_launch_gemm_split(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
                                   float* Y, int ldy, int M, int N, int K, int act, int act_split, int act2, hipStream_t s);
 hipError_t poem_launch_prep_xyz(const float* ref_joints, const float* bps, const float* tmpl, float* centre,
@@ -745,6 +747,13 @@ int poem_triangulate_dlt(const float* uv, const float* cam_intr, const float* ca
   if (!uv || !cam_intr || !cam_mat || !view_offsets || !out_xyz || batch <= 0 || njoints <= 0 || (invert & ~1))
     return POEM_E_ARG;
   HIPCHK(poem_launch_dlt(uv, cam_intr, cam_mat, view_offsets, out_xyz, batch, njoints, invert, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_heatmap_uv(const float* heatmaps, float* uv, int views, int njoints, int hm_h, int hm_w, float img_w, float img_h,
+                    void* stream) {
+  if (!heatmaps || !uv || views <= 0 || njoints <= 0 || hm_h <= 0 || hm_w <= 0) return POEM_E_ARG;
+  HIPCHK(poem_launch_heatmap_uv(heatmaps, uv, views * njoints, hm_h, hm_w, img_w, img_h, (hipStream_t)stream));
   return POEM_OK;
 }
 

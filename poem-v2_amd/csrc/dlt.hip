@@ -89,3 +89,38 @@ extern "C" hipError_t poem_launch_dlt(const float* uv, const float* intr, const 
   hipLaunchKernelGGL(dlt_kernel, dim3((total + 63) / 64), dim3(64), 0, s, uv, intr, mat, offs, out, B, J, invert);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Heat-map read-out in front of the triangulation (tail of heatmap_stage, lib/models/POEM.py:213-222 upstream, with
+// integral_heatmap2d, lib/models/integal_pose.py:194-218): per (view, joint)
+//   pdf = hmap / (sum(hmap) + 1e-6);  u = sum_x (x / W_h) * sum_y pdf[y][x];  v = sum_y (y / H_h) * sum_x pdf[y][x]
+//   uv_im = (u * W_img, v * H_img)
+// One wave per (view, joint); fp32 like the reference, fp64 only for the three running sums.
+__global__ __launch_bounds__(256) void heatmap_uv_kernel(const float* __restrict__ hmap, float* __restrict__ uv,
+                                                         int maps, int hh, int hw, float img_w, float img_h) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= maps) return;
+  const float* h = hmap + (size_t)m * hh * hw;
+  double s = 0, su = 0, sv = 0;
+  for (int i = lane; i < hh * hw; i += 64) {
+    const float v = h[i];
+    const int y = i / hw, x = i - y * hw;
+    s += v;
+    su += (double)v * ((float)x / (float)hw);
+    sv += (double)v * ((float)y / (float)hh);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); su += __shfl_xor(su, o, 64); sv += __shfl_xor(sv, o, 64); }
+  if (lane == 0) {
+    const double den = (double)((float)s + 1e-6f);
+    uv[(size_t)m * 2 + 0] = (float)(su / den) * img_w;
+    uv[(size_t)m * 2 + 1] = (float)(sv / den) * img_h;
+  }
+}
+
+extern "C" hipError_t poem_launch_heatmap_uv(const float* hmap, float* uv, int maps, int hh, int hw, float img_w,
+                                             float img_h, hipStream_t s) {
+  hipLaunchKernelGGL(heatmap_uv_kernel, dim3((maps + 3) / 4), dim3(256), 0, s, hmap, uv, maps, hh, hw, img_w, img_h);
+  return hipGetLastError();
+}

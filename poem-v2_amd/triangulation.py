@@ -45,3 +45,22 @@ def batch_triangulate_dlt_torch(kp2ds, Ks, Extrs):
     hip.check(hip.lib().poem_triangulate_dlt(hip.ptr(uv), hip.ptr(K), hip.ptr(T), offs.data_ptr(), B, J, 0, hip.ptr(out),
                                              hip.stream()), "poem_triangulate_dlt")
     return out
+
+
+def heatmap_to_uv(uv_hmap, img_w, img_h):
+    """uv_hmap (BN,J,Hh,Wh) sigmoid heat maps -> (BN,J,2) pixel coordinates: the read-out at the end of the
+    reference's ``heatmap_stage`` (lib/models/POEM.py:213-222 upstream; integral_heatmap2d, integal_pose.py:194-218)."""
+    if not uv_hmap.is_cuda:
+        raise RuntimeError("heatmap_to_uv runs on the MI355X HIP path only (no CPU fallback)")
+    h = uv_hmap.to(dtype=torch.float32).contiguous()
+    BN, J, Hh, Wh = h.shape
+    uv = torch.empty(BN, J, 2, dtype=torch.float32, device=h.device)
+    hip.check(hip.lib().poem_heatmap_uv(hip.ptr(h), hip.ptr(uv), BN, J, Hh, Wh, float(img_w), float(img_h), hip.stream()),
+              "poem_heatmap_uv")
+    return uv
+
+
+def reference_joints_from_heatmaps(uv_hmap, cam_intr, cam_extr, cam_view_num, img_w, img_h):
+    """Heat maps of every view -> per-view 2-D joints -> ragged DLT -> (B,J,3) reference joints: the two launches that
+    replace POEM.py:213-222 + :284-299 upstream."""
+    return triangulate_reference_joints(heatmap_to_uv(uv_hmap, img_w, img_h), cam_intr, cam_extr, cam_view_num)

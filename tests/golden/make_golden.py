@@ -206,8 +206,18 @@ def run_dlt():
             B, N = len(views), views[0]
             rec[name + ".batched"] = mod.batch_triangulate_dlt_torch(uv.view(B, N, 21, 2), K.view(B, N, 3, 3),
                                                                      T.view(B, N, 4, 4)).numpy()
+    # heat-map read-out: the reference's own integral_heatmap2d on seeded sigmoid maps (integal_pose.py:194-218) inside
+    # the normalisation / scaling of heatmap_stage (POEM.py:213-222)
+    rh.setup()
+    from lib.models.integal_pose import integral_heatmap2d
+    g = torch.Generator().manual_seed(44)
+    hm = torch.sigmoid(4.0 * torch.randn(5, 21, 32, 32, generator=g) - 3.0)
+    pdf = hm.reshape(5, 21, -1)
+    pdf = (pdf / (pdf.sum(dim=-1, keepdim=True) + 1e-6)).contiguous().view(5, 21, 32, 32)
+    rec["hm_uv"] = torch.einsum("bij, j->bij", integral_heatmap2d(pdf), torch.tensor([256.0, 256.0])).numpy()
+    os.chdir(ROOT)
     meta = dict(cases={k: dict(views=v[0], seed=v[1]) for k, v in cases.items()},
-                note="inputs = tests/golden/make_golden.py::dlt_inputs(views, seed)")
+                note="inputs = tests/golden/make_golden.py::dlt_inputs(views, seed); hm_uv: sigmoid(4*randn(5,21,32,32; seed 44)-3)")
     rec["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "dlt.npz"), **rec)
     print("dlt:", {k: v.shape for k, v in rec.items() if k != "meta"})

@@ -103,3 +103,39 @@ def test_hip_dlt_full_batch_properties():
         pk.triangulation.triangulate_reference_joints(uv, K, E, views)       # CPU tensors: no fallback
     with pytest.raises(ValueError):
         pk.triangulation.triangulate_reference_joints(uv[:1].cuda(), K[:1].cuda(), E[:1].cuda(), [1])
+
+
+def _heatmaps():
+    g = torch.Generator().manual_seed(44)
+    return torch.sigmoid(4.0 * torch.randn(5, 21, 32, 32, generator=g) - 3.0)
+
+
+def test_oracle_heatmap_readout_matches_reference():
+    z, _ = _golden()
+    got = do.heatmap_to_uv(_heatmaps(), 256.0, 256.0)
+    assert float((got - torch.from_numpy(z["hm_uv"])).abs().max()) < 2e-4      # pixels
+
+
+@pytest.mark.gpu
+def test_hip_heatmap_readout_and_chain():
+    import poem_v2_amd as pk
+    z, _ = _golden()
+    hm = _heatmaps()
+    got = pk.triangulation.heatmap_to_uv(hm.cuda(), 256.0, 256.0).cpu()
+    assert float((got - torch.from_numpy(z["hm_uv"])).abs().max()) < 2e-4      # pixels
+    # a one-hot map reads out its own pixel (x / W * img_w)
+    one = torch.zeros(1, 2, 32, 32)
+    one[0, 0, 5, 9] = 1.0
+    one[0, 1, 31, 0] = 0.5
+    uv = pk.triangulation.heatmap_to_uv(one.cuda(), 256.0, 128.0).cpu()
+    assert torch.allclose(uv[0, 0], torch.tensor([9 / 32 * 256.0, 5 / 32 * 128.0]), atol=1e-3)
+    assert torch.allclose(uv[0, 1], torch.tensor([0.0, 31 / 32 * 128.0]), atol=1e-3)
+    # chained: heat maps -> uv -> DLT equals the two-step oracle
+    views = [2, 3]
+    b = pk.inputs.synthetic_batch(views, seed=9)
+    m = b["img_metas"]
+    rj = pk.triangulation.reference_joints_from_heatmaps(hm.cuda(), m["cam_intr"].cuda(), m["cam_extr"].cuda(), views, 256, 256)
+    orc = do.triangulate_reference_joints(do.heatmap_to_uv(hm, 256.0, 256.0), m["cam_intr"], m["cam_extr"], views)
+    assert rj.shape == (2, 21, 3)
+    err = (rj.cpu() - orc).abs()
+    assert float(err.max()) < 5e-3 * max(1.0, float(orc.abs().max()))       # random maps: ill-conditioned rays, loose bound
