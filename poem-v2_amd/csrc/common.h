@@ -40,6 +40,18 @@ __device__ __forceinline__ float exp_neg(float x) {
   return fmaf(r, e * LN2, r);
 }
 
+// Wave-wide 1 KiB fragment load through a buffer descriptor: address = SGPR base + SGPR byte offset + lane * 16.
+// The per-chunk address update is then scalar arithmetic; a per-lane 64-bit pointer costs two VALU adds per load, and
+// every VALU issue slot inside an MFMA loop costs matrix-pipe time (tools/lab/issue_lab: 72.6 -> 66 cycles per MFMA).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frag_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 frag_load(__amdgpu_buffer_rsrc_t rs, int lane_off_bytes, int scalar_off_bytes) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off_bytes, scalar_off_bytes, 0);
+  return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // Packed Linear weight image used by every MFMA kernel here ("fragment order"):

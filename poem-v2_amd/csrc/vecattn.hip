@@ -56,7 +56,9 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
   constexpr int KC = C / 8;      // even for every supported C
   constexpr int XS = 32 * P;
   const int j = lane & 31, h = lane >> 5;
-  const float4* wp = Wp + (size_t)(wv * TPW) * KC * 64 + lane;
+  const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(Wp, (unsigned)(C * C * 4));
+  const int wbase = __builtin_amdgcn_readfirstlane(wv) * TPW * KC * 1024;      // bytes, wave-uniform
+  const int loff = lane * 16;
   const float* xc = X + (4 * h) * XS + j;
   // Two-stage software pipeline with pinned order (sched_barrier): the weight fragments of chunk kc+1 and the LDS
   // operand of k-step t+1 are in flight while the MFMAs of k-step t issue.  Left to itself hipcc sinks every load to
@@ -66,7 +68,7 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
 #define VA_LOADW(A, KCI)                                                                  \
   {                                                                                       \
     const int kq_ = min((KCI), KC - 1);                                                   \
-    _Pragma("unroll") for (int tp = 0; tp < TPW; ++tp) A[tp] = wp[((size_t)tp * KC + kq_) * 64]; \
+    _Pragma("unroll") for (int tp = 0; tp < TPW; ++tp) A[tp] = frag_load(wrs, loff, wbase + (tp * KC + kq_) * 1024); \
   }
 #define VA_READX(XR, KCI, T)                                                              \
   {                                                                                       \
