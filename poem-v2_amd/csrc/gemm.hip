@@ -231,23 +231,25 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
   const int mtiles = (M + 31) / 32;
   const int rgroups = (mtiles + MT - 1) / MT;
   const int pact = (panel * NT * 32 >= act_split) ? act2 : act;
+  const __amdgpu_buffer_rsrc_t xrs = frag_rsrc(X, 0xffffffffu);
   float bv[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) bv[n] = bias ? bias[(panel * NT + n) * 32 + r] : 0.f;
   const size_t lane_yo = (size_t)(4 * h) * ldy + r, lane_ro = (size_t)(4 * h) * ldr + r;
   for (int rg = bip * NWV + wv; rg < rgroups; rg += blocks_in_panel * NWV) {
     const int mt0 = rg * MT;
-    const float4* xp[MT];
+    // X fragments through the buffer descriptor: per-lane byte offset (row, half) computed once per row group, the
+    // k-chunk offset is scalar -- no VALU address arithmetic inside the MFMA loop
+    unsigned xo[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-      xp[i] = reinterpret_cast<const float4*>(X + (size_t)min((mt0 + i) * 32 + r, M - 1) * ldx + 4 * h);
+    for (int i = 0; i < MT; ++i) xo[i] = (unsigned)min((mt0 + i) * 32 + r, M - 1) * (unsigned)(ldx * 4) + 16u * h;
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[i][n] = zero16();
     float4 a0[MT], a1[MT], b0[NT], b1[NT];
-#define POEM_LOADA(A, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) A[i] = xp[i][(size_t)kq_ * 2]; }
+#define POEM_LOADA(A, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) A[i] = frag_load(xrs, (int)xo[i], kq_ * 32); }
 #define POEM_LOADB(B, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int n = 0; n < NT; ++n) B[n] = wl[(n * KC + kq_) * 64 + lane]; }
 #define POEM_MMA(A, B)                                                          \
   _Pragma("unroll") for (int t = 0; t < 4; ++t) {                               \
@@ -378,7 +380,7 @@ extern "C" hipError_t poem_launch_gemm_split(const float* X, int ldx, const void
   // deep K leaves room for a single 32-column tile per panel, which re-reads X every 8 MFMAs: the operands-from-L2
   // kernel is faster there (ffn output Linear, K = 4C)
   if (NT == 1 && N >= 64 && K >= 512 && !(act_split < N && act2 != act)) NT = 0;
-  if (NT == 0 || K % 8 || ((uintptr_t)X & 15) || ldx % 4) {
+  if (NT == 0 || K % 8 || ((uintptr_t)X & 15) || ldx % 4 || (unsigned long long)M * ldx * 4ull >= (1ull << 32)) {
     if (act_split < N && act2 != act) return hipErrorInvalidValue;
     return poem_launch_gemm2(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, 0, 0, s);
   }
