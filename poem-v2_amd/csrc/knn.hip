@@ -3,18 +3,33 @@
 // contraction -- near-ties must order the way the CPU evaluation orders them), ascending, ties -> lower index.
 // One wave per query; each lane keeps ceil(NS/64) candidate distances in registers (strided so that the source
 // coordinates are read coalesced) and the wave extracts the minimum 32 times.
+//
+// Extraction cost: every lane caches the minimum of each group of 8 of its registers.  A round is then
+//   8 compare-selects (lane minimum over its group minima) + a 6-step wave arg-min + -- in the ONE lane that owned the
+//   winner -- invalidating that element and re-scanning its group of 8 (a branch only that lane takes),
+// instead of re-scanning all PER registers in every lane every round (64 -> ~20 VALU ops per round and lane).
 #include "common.h"
 
-template <int PER>
-__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ qxyz, const float* __restrict__ sxyz,
-                                                  int* __restrict__ idx, int B, int NQ, int NS) {
+// Block = QPB waves = QPB queries of ONE sample; the sample's source coordinates are staged once in LDS (12-byte
+// stride: conflict-free) instead of every query wave streaming all NS points from L2.
+template <int PER, int QPB>
+__global__ __launch_bounds__(QPB * 64) void knn_kernel(const float* __restrict__ qxyz, const float* __restrict__ sxyz,
+                                                       int* __restrict__ idx, int B, int NQ, int NS) {
+  constexpr int NG = PER / 8;                 // groups of 8 registers
+  extern __shared__ float sp[];               // NS * 3
   const int lane = threadIdx.x & 63;
-  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= (long)B * NQ) return;
-  const int b = (int)(wid / NQ);
+  const int qgroups = (NQ + QPB - 1) / QPB;
+  const int b = blockIdx.x / qgroups;
+  const int qi = (blockIdx.x % qgroups) * QPB + (threadIdx.x >> 6);
+  {
+    const float* src = sxyz + (size_t)b * NS * 3;
+    for (int i = threadIdx.x; i < NS * 3; i += QPB * 64) sp[i] = src[i];
+  }
+  __syncthreads();
+  if (qi >= NQ) return;
+  const long wid = (long)b * NQ + qi;
   const float* qp = qxyz + wid * 3;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
-  const float* sp = sxyz + (size_t)b * NS * 3;
   float d[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
@@ -26,37 +41,92 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ qxyz
       d[i] = INFINITY;
     }
   }
+  // group minima (value, register index); strict '<' keeps the lower register = lower source index on ties
+  float gmin[NG];
+  int gidx[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float best = d[8 * g];
+    int bi = 8 * g;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const bool lt = d[8 * g + k] < best;
+      best = lt ? d[8 * g + k] : best;
+      bi = lt ? 8 * g + k : bi;
+    }
+    gmin[g] = best;
+    gidx[g] = bi;
+  }
   int* out = idx + wid * 32;
   for (int round = 0; round < 32; ++round) {
-    float best = d[0];
-    int bi = 0;
+    float best = gmin[0];
+    int bi = gidx[0];
 #pragma unroll
-    for (int i = 1; i < PER; ++i) {
-      const bool lt = d[i] < best;      // strict: keeps the lower index on ties
-      best = lt ? d[i] : best;
-      bi = lt ? i : bi;
+    for (int g = 1; g < NG; ++g) {
+      const bool lt = gmin[g] < best;
+      best = lt ? gmin[g] : best;
+      bi = lt ? gidx[g] : bi;
     }
     int bc = lane + 64 * bi;
+    // wave arg-min without LDS round trips (__shfl_xor is a ds_bpermute: 12 dependent ~100-cycle hops per round):
+    // four DPP exchanges settle every row of 16 lanes, four v_readlane pairs fetch the row winners.
+#define POEM_DPP_STEP(CTRL)                                                                                   \
+    {                                                                                                         \
+      const float ob = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, best), CTRL, 0xf, 0xf, false)); \
+      const int oc = __builtin_amdgcn_update_dpp(0, bc, CTRL, 0xf, 0xf, false);                               \
+      const bool take = (ob < best) || (ob == best && oc < bc);                                               \
+      best = take ? ob : best;                                                                                \
+      bc = take ? oc : bc;                                                                                    \
+    }
+    POEM_DPP_STEP(0xB1)     // quad_perm [1,0,3,2]
+    POEM_DPP_STEP(0x4E)     // quad_perm [2,3,0,1]
+    POEM_DPP_STEP(0x141)    // row_half_mirror
+    POEM_DPP_STEP(0x140)    // row_mirror
+#undef POEM_DPP_STEP
+    {
+      float rb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best), 0));
+      int rc = __builtin_amdgcn_readlane(bc, 0);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oc = __shfl_xor(bc, o, 64);
-      const bool take = (ob < best) || (ob == best && oc < bc);
-      best = take ? ob : best;
-      bc = take ? oc : bc;
+      for (int rw = 1; rw < 4; ++rw) {
+        const float ob = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, best), 16 * rw));
+        const int oc = __builtin_amdgcn_readlane(bc, 16 * rw);
+        const bool take = (ob < rb) || (ob == rb && oc < rc);
+        rb = take ? ob : rb;
+        rc = take ? oc : rc;
+      }
+      best = rb;
+      bc = rc;
     }
     if (lane == 0) out[round] = bc;
+    if ((bc & 63) == lane) {                  // the owner lane: drop the winner, re-scan its group of 8
+      const int wi = bc >> 6, wg = wi >> 3;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) d[i] = (lane + 64 * i == bc) ? INFINITY : d[i];
+      for (int g = 0; g < NG; ++g) {
+        if (g == wg) {
+          float nb = INFINITY;
+          int ni = 8 * g;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            d[8 * g + k] = (8 * g + k == wi) ? INFINITY : d[8 * g + k];
+            const bool lt = d[8 * g + k] < nb;
+            nb = lt ? d[8 * g + k] : nb;
+            ni = lt ? 8 * g + k : ni;
+          }
+          gmin[g] = nb;
+          gidx[g] = ni;
+        }
+      }
+    }
   }
 }
 
 extern "C" hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS,
                                       hipStream_t s) {
-  const long waves = (long)B * NQ;
-  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  if (NS <= 64 * 16) hipLaunchKernelGGL((knn_kernel<16>), grid, block, 0, s, qxyz, sxyz, idx, B, NQ, NS);
-  else if (NS <= 64 * 64) hipLaunchKernelGGL((knn_kernel<64>), grid, block, 0, s, qxyz, sxyz, idx, B, NQ, NS);
+  constexpr int QPB = 16;
+  dim3 grid((unsigned)(B * ((NQ + QPB - 1) / QPB))), block(QPB * 64);
+  const size_t lds = (size_t)NS * 3 * sizeof(float);
+  if (NS <= 64 * 16) hipLaunchKernelGGL((knn_kernel<16, QPB>), grid, block, lds, s, qxyz, sxyz, idx, B, NQ, NS);
+  else if (NS <= 64 * 64) hipLaunchKernelGGL((knn_kernel<64, QPB>), grid, block, lds, s, qxyz, sxyz, idx, B, NQ, NS);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
