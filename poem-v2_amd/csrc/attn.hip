@@ -306,5 +306,7 @@ extern "C" hipError_t poem_launch_cross_attention(const float* q, const float* k
     default: break;
   }
 #endif
+  // head dim 128 (POEM-large) needs ~200 VGPRs: two waves per SIMD without spills beat three with
+  if (C / heads >= 128) return launch_attn<4, 2>(q, k, v, ctx, B, NQ, NK, C, heads, ldkv, scratch, ksplit, s);
   return launch_attn<4, 3>(q, k, v, ctx, B, NQ, NK, C, heads, ldkv, scratch, ksplit, s);
 }
