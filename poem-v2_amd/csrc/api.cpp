@@ -32,7 +32,11 @@ hipError_t poem_launch_merge_finalize(const float* g, const float* y, const int*
                                       hipStream_t s);
 hipError_t poem_launch_cross_attention(const float* q, const float* k, const float* v, float* ctx, int B, int NQ, int NK,
                                        int C, int heads, int ldkv, float* scratch, hipStream_t s);
-size_t poem_cross_attention_scratch_floats(int B, int NQ, int NK, int C, int heads, int* ksplit_out);
+size_t poem_cross_attention_scratch_floats(int B, int NQ, int NK, int C, int heads, int with_images);
+hipError_t poem_launch_cross_attention_img(const float* q, int ldq, const void* kimg, const void* vimg, float* ctx, int B,
+                                           int NQ, int NK, int C, int heads, float* scratch, hipStream_t s);
+hipError_t poem_launch_gemm_segs(const float* X, int ldx, const void* Wp, const float* bias, int M, int K, int act,
+                                 int seg_cols, int nsegs, float* const* outs, const int* modes, hipStream_t s);
 hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS, hipStream_t s);
 hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                         const int* idx, int shared_idx, const float* q, const float* k, const float* v,
@@ -209,7 +213,8 @@ struct Plan {
   // decoder (per call scratch)
   float *feats0, *qe, *qp, *ctx, *att, *h_attn, *xs, *y3, *rs, *qc, *rc, *y4, *ffo;
   // basis-point side, one set per block (produced ahead of time on the side stream):
-  // y1 = (BS, 5C) [kp1 | vp1 | kp2 | vp2 | xk], y2 = (BS, 2C) [kc | vc]
+  // y1 = 5 x (BS, C): K image 1 | V image 1 | K image 2 | V image 2 (MFMA fragment order, attn.hip) | xk (row-major),
+  // y2 = (BS, 2C) [kc | vc]
   float *ke[8], *y1[8], *y2[8];
   // per block kept tensors (taps)
   float *h_cross[8], *f_self[8], *f_cross[8], *feats[8];
@@ -265,7 +270,7 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   }
   p.q3t = a.take<float>((size_t)B * C);
   p.par = a.take<float>((size_t)B * 106);
-  p.attn_scratch = a.take<float>(poem_cross_attention_scratch_floats(B, (int)Q, (int)S, (int)C, c.heads, nullptr) + 4);
+  p.attn_scratch = a.take<float>(poem_cross_attention_scratch_floats(B, (int)Q, (int)S, (int)C, c.heads, 0) + 4);
   p.bytes = align_up(a.off, 256);
   return p;
 }
@@ -306,10 +311,15 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     GEMM_ON(sb, pt_feats, C, bb + B_EMB_W, bb + B_EMB_B, nullptr, 0, p.ke[i], C, BS, C, C, POEM_ACT_NONE);
     const auto& f = h->fused[i];
     // F1: keys/values of both BERT cross attentions + fc1 of the vector cross attention (hoisted to the S source rows)
-    HIPCHK(poem_launch_gemm_split(p.ke[i], C, f.w[0], f.b[0], nullptr, 0, p.y1[i], 5 * C, BS, 5 * C, C, POEM_ACT_NONE,
-                                  5 * C, POEM_ACT_NONE, sb));
-    // F2: w_ks | w_vs of the vector cross attention on xk = y1[:, 4C:5C]
-    HIPCHK(poem_launch_gemm_split(p.y1[i] + 4 * C, 5 * C, f.w[1], nullptr, nullptr, 0, p.y2[i], 2 * C, BS, 2 * C, C,
+    // (the four key/value blocks leave the GEMM as MFMA fragment images, the fifth row-major)
+    {
+      const size_t seg = (size_t)BS * C;
+      float* outs[5] = {p.y1[i], p.y1[i] + seg, p.y1[i] + 2 * seg, p.y1[i] + 3 * seg, p.y1[i] + 4 * seg};
+      const int modes[5] = {1, 2, 1, 2, 0};
+      HIPCHK(poem_launch_gemm_segs(p.ke[i], C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, 5, outs, modes, sb));
+    }
+    // F2: w_ks | w_vs of the vector cross attention on xk (fifth block of y1)
+    HIPCHK(poem_launch_gemm_split(p.y1[i] + 4 * (size_t)BS * C, C, f.w[1], nullptr, nullptr, 0, p.y2[i], 2 * C, BS, 2 * C, C,
                                   POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, sb));
     if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));
     return POEM_OK;
@@ -354,8 +364,9 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       float* hout = a == 0 ? p.h_attn : p.h_cross[i];
       GEMM(hidden, C, ab + 0, ab + 1, nullptr, 0, p.qp, C, BQ, C, C, POEM_ACT_NONE);
       if (ov && a == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
-      HIPCHK(poem_launch_cross_attention(p.qp, p.y1[i] + (2 * a) * C, p.y1[i] + (2 * a + 1) * C, p.ctx, B, Q, S, C, c.heads,
-                                         5 * C, p.attn_scratch, s));
+      HIPCHK(poem_launch_cross_attention_img(p.qp, C, p.y1[i] + (size_t)(2 * a) * BS * C,
+                                             p.y1[i] + (size_t)(2 * a + 1) * BS * C, p.ctx, B, Q, S, C, c.heads,
+                                             p.attn_scratch, s));
       GEMM(p.ctx, C, ab + 6, ab + 7, hidden, C, p.att, C, BQ, C, C, POEM_ACT_NONE);
       HIPCHK(poem_launch_layernorm(p.att, h->R(ab + 8), h->R(ab + 9), hout, BQ, C, c.ln_eps, s));
       hidden = hout;
@@ -702,7 +713,7 @@ int poem_merge_finalize(const float* g, const float* y, const int32_t* view_offs
 
 size_t poem_cross_attention_scratch_bytes(int batch, int nq, int nk, int embed, int heads) {
   if (batch <= 0 || nq <= 0 || nk % 32 || heads <= 0 || embed % heads) return 0;
-  return poem_cross_attention_scratch_floats(batch, nq, nk, embed, heads, nullptr) * sizeof(float);
+  return poem_cross_attention_scratch_floats(batch, nq, nk, embed, heads, 1) * sizeof(float);
 }
 
 int poem_cross_attention(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk, int embed,

@@ -1,236 +1,286 @@
-// BERT-style multi-head cross attention of the 799 queries over the 4096 basis points, flash-style, exact fp32.
+// BERT-style multi-head cross attention of the 799 queries over the 4096 basis points, flash-style, exact fp32 MFMA.
 // softmax(Q K^T / sqrt(dh)) V without materialising the (B, heads, Q, S) score tensor.
 //
-// Block = NWV waves, one (batch, head, 32*NWV-query group, key split); every wave owns 32 queries.  Per 32-key tile:
-//   S^T = K . Q^T      MFMA A = K tile from LDS (row = key), B = Q fragment held in registers (lane = query)
-//                      -> D[key][query]: lane = query, registers = keys, so the per-query softmax statistics are
-//                         lane-local (+1 exchange with the other half-wave)
-//   O^T += V^T . P^T   MFMA A = V tile from LDS (lane = channel d), B = P registers used *directly* as the operand:
-//                      k-step i consumes key row (i&3)+8(i>>2)+4*half, exactly the key that register i holds.
-// K/V tiles are staged through double-buffered LDS, next tile prefetched into registers during the MFMAs.
+// Keys and values arrive as MFMA *fragment images* (written directly by the projection GEMM's epilogue, gemm.hip
+// output modes 1 and 2, or by the repack kernels below for the row-major op-level entry point):
+//   K image  KI[(kt * C/8  + kco) * 64 + lane]       = float4( K[32kt + (lane&31)][8kco + 4(lane>>5) + 0..3] )
+//   V image  VI[((kt * C/32 + vt) * 4 + g) * 64 + lane] = float4( V[32kt + 8g + 4(lane>>5) + 0..3][32vt + (lane&31)] )
+// so every operand of both contractions is one coalesced 1 KiB wave load that lands in exactly the registers the MFMA
+// reads -- no LDS, no barriers, every wave is independent:
+//   S^T = K . Q^T      A = K fragment (row = key),   B = Q fragment held in registers (lane = query)
+//                      -> D[key][query]: lane = query, registers = keys; softmax statistics are lane-local
+//   O^T += V^T . P^T   A = V fragment (row = channel), B = P registers used *directly* as the operand:
+//                      k-step i consumes key (i&3) + 8(i>>2) + 4*half, exactly the key that register i holds.
+// The K fragments of tile t+1 are requested right after the QK^T MFMAs of tile t have consumed the registers, the V
+// fragments right after the PV MFMAs: each load has a whole 32-MFMA phase (>= 2048 cycles) to arrive.
 //
-// Work decomposition (the kernel is MFMA-bound; what matters is an even load on the 1024 SIMDs):
-//   * 4 waves per block = one wave per SIMD (5-wave blocks covering 799 = 25 x 32 queries exactly measured 20 % slower:
-//     two waves of one barrier-coupled block on one SIMD);
-//   * the key axis is split KSPLIT ways when the unsplit grid would be a single ragged round over the 4-blocks-per-CU
-//     residency; each split writes un-normalised partial (O, m, l) in fragment order and `attn_combine_kernel` merges
-//     them with the usual log-sum-exp weights;
-//   * <= 128 VGPRs -> 4 waves per SIMD, so one wave's softmax VALU work hides under the others' MFMAs
-//     (measured: 86 % MFMA-busy while a round is full; the rest of the gap is round quantisation and the 31-query tail).
+// fp32 MFMA and the VALU share the SIMD's fp32 lanes on gfx950 (tools/lab/dual_lab, phase_lab: a VALU instruction
+// costs its full issue time whether it is interleaved with MFMAs, placed between them, or issued by another wave), so
+// the softmax is written for instruction count: raw scores, the scale and log2(e) folded into one packed fma per pair
+// (v_pk_fma_f32), v_exp_f32, packed adds for the row sums, v_max3 for the tile maximum, and a *lazy* running maximum
+// -- the stabiliser only moves (and O is only rescaled) when a tile exceeds it by more than 2^LAZY_LOG2; any
+// stabiliser gives the same softmax, the rescale branch is wave-uniform and rare.  Row sums stay per half-wave until
+// the end of a chunk.
+//
+// Work decomposition: item = (batch, head, key chunk, 32-query tile); a chunk is a fixed number of key tiles that
+// depends only on (NK, dh) -- never on the batch size or the chip -- and every item starts from an empty state and
+// writes un-normalised (O, m, l) partials that `attn_combine_kernel` merges in fixed order: a sample's result is
+// bit-identical whatever batch it travels in.  One persistent block per CU; items are dealt to the CU's four SIMDs in
+// contiguous, equal shares (the matrix pipe is per SIMD) and round-robin to the waves of a SIMD, so co-resident waves
+// read the same K/V chunk (L1/L2 hits) for neighbouring query tiles.
 #include "common.h"
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
-#ifdef POEM_ATTN_DBG   // tools/lab only
-__device__ long long attn_dbg[8 * 4 * 8];
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define POEM_ATTN_LAZY_LOG2 8.0f
+#ifndef POEM_XA_VARIANT
+#define POEM_XA_VARIANT 0
 #endif
 
-template <int DH, int NWV, int MINW>
-__global__ __launch_bounds__(NWV * 64, MINW) void cross_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                 const float* __restrict__ v, float* __restrict__ ctx,
-                                                                 float4* __restrict__ part_o, float2* __restrict__ part_ml,
-                                                                 int NQ, int NK, int C, int ldkv, int ksplit) {
-  constexpr int DT = (DH + 31) / 32;       // 32-wide channel tiles of the output
-  constexpr int KC = DH / 8;               // k-chunks of the QK^T contraction
-  constexpr int KS = DH + 4;               // K tile row stride (floats): conflict-free ds_read_b128 by row
-  constexpr int VS = 32 * DT;              // V tile row stride (zero padded to a whole channel tile)
-  constexpr int NT = NWV * 64;
-  constexpr int F4 = 8 * DH;               // float4s per 32-key tile
-  constexpr int LD = (F4 + NT - 1) / NT;   // float4 loads per thread per tile
-  __shared__ __attribute__((aligned(16))) float Ks[2][32 * KS];
-  __shared__ __attribute__((aligned(16))) float Vs[2][32 * VS];
+// streaming (non-temporal) 16-byte accesses for the partials: written once, read once -- they should not displace the
+// step's reusable tensors (the vector attention's gather sources) from L2 / Infinity Cache
+__device__ __forceinline__ void nt_store4(float4* p, float4 v) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
+}
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z / ksplit, ks = blockIdx.z % ksplit, head = blockIdx.y;
-  const int heads = gridDim.y;
-  const int qtile = blockIdx.x * NWV + wv;
-  const int qrow = qtile * 32 + r;
-  const bool wave_live = qtile * 32 < NQ;
-  const int qclamp = min(qrow, NQ - 1);
-  const float* kb = k + (size_t)b * NK * ldkv + head * DH;
-  const float* vb = v + (size_t)b * NK * ldkv + head * DH;
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-  // zero the padded V columns once (DH < 32 only)
-  if (DH < VS) {
-    for (int i = tid; i < 2 * 32 * VS; i += NT) (&Vs[0][0])[i] = 0.f;
-    __syncthreads();
-  }
+#ifdef POEM_LAB   // tools/lab only: per-wave (shader cycles, 100 MHz ticks, items) of the last launch
+__device__ long long xattn_dbg[4096 * 4];
+#endif
+#ifdef POEM_XA_STAMPS   // tools/lab only: cycles per phase of wave 0 of block 5
+__device__ long long xattn_ph[8];
+#define XA_STAMP(k) do { if (dbg_on) { const long long t_ = clock64(); if ((k) != 0) dbg_ph[(k)] += t_ - dbg_last; else if (dbg_last) dbg_ph[0] += t_ - dbg_last; dbg_last = t_; } } while (0)
+#else
+#define XA_STAMP(k) do { } while (0)
+#endif
 
-  // Q fragment: lane (query r, half h) holds Q[r][8kc + 4h + t]
-  float4 qf[KC];
-  {
-    const float* qp = q + ((size_t)b * NQ + qclamp) * C + head * DH + 4 * h;
+template <int DH, int W>
+__global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restrict__ q, int ldq,
+                                                           const float4* __restrict__ kimg,
+                                                           const float4* __restrict__ vimg,
+                                                           float4* __restrict__ part_o, float2* __restrict__ part_ml,
+                                                           int B, int NQ, int NK, int C, int heads, int tpc, float kc2,
+                                                           float lazy_raw, int map) {
+  constexpr int KC = DH / 8;               // K fragments (float4) per key tile
+  constexpr int DT = (DH + 31) / 32;       // 32-channel tiles of the output
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int nqt = (NQ + 31) / 32, nkt = NK / 32, chunks = nkt / tpc;
+  const int items = B * heads * chunks * nqt;
+  // logical block id: blocks of one XCD (blockIdx % 8) take neighbouring item ranges -> one L2 serves a K/V chunk
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  // map 1: a CU owns a contiguous item range and deals it round-robin to all its waves (wave w sits on SIMD w % 4, so
+  //        the SIMDs stay balanced to within one item) -- every wave of the CU streams the same K/V chunk at the same
+  //        time: one HBM/L2 fetch serves them all.
+  // map 0: each SIMD owns a contiguous range, dealt to its W waves.
+  const int sg = map ? lb : lb * 4 + (wv & 3), ng = map ? nb : nb * 4;
+  const int ibase = items / ng, irem = items % ng;
+  const int lo = ibase * sg + min(sg, irem), hi = lo + ibase + (sg < irem ? 1 : 0);
+  const int first = map ? wv : (wv >> 2), stride = map ? 4 * W : W;
+  const __amdgpu_buffer_rsrc_t krs = frag_rsrc(kimg, 0xffffffffu), vrs = frag_rsrc(vimg, 0xffffffffu);
+  const int loff = lane * 16;
+#ifdef POEM_LAB
+  const long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+  int dbg_items = 0;
+#endif
+#ifdef POEM_XA_STAMPS
+  const bool dbg_on = blockIdx.x == 5 && wv == 0;
+  long long dbg_ph[4] = {0, 0, 0, 0}, dbg_last = 0;
+#endif
+
+  for (int item = lo + first; item < hi; item += stride) {
+#ifdef POEM_LAB
+    ++dbg_items;
+#endif
+    const int qt = item % nqt;
+    int t = item / nqt;
+    const int ch = t % chunks;
+    t /= chunks;
+    const int head = t % heads, b = t / heads;
+    const int qrow = min(qt * 32 + r, NQ - 1);
+
+    // Q fragment: lane (query r, half h) holds Q[r][8kc + 4h + t]
+    float4 qf[KC];
+    {
+      const float* qp = q + ((size_t)b * NQ + qrow) * ldq + head * DH + 4 * h;
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) qf[kc] = *reinterpret_cast<const float4*>(qp + 8 * kc);
-  }
+      for (int kc = 0; kc < KC; ++kc) qf[kc] = *reinterpret_cast<const float4*>(qp + 8 * kc);
+    }
+    // scalar byte offsets of this item's first key tile in the two images
+    const int kt0 = ch * tpc;
+    const int ktile_bytes = C * 128;                                        // 32 keys x C floats, both images
+    int koff = __builtin_amdgcn_readfirstlane((b * nkt + kt0) * ktile_bytes + head * KC * 1024);
+    int voff = __builtin_amdgcn_readfirstlane((b * nkt + kt0) * ktile_bytes + ((head * DH) / 32) * 4096);
 
-  float4 kreg[LD], vreg[LD];
-#define POEM_LOAD_TILE(KT)                                                                                      \
-  _Pragma("unroll") for (int i_ = 0; i_ < LD; ++i_) {                                                           \
-    const int f_ = tid + NT * i_;                                                                               \
-    if (F4 % NT == 0 || f_ < F4) {                                                                              \
-      const int row_ = f_ / (DH / 4), c4_ = f_ % (DH / 4);                                                      \
-      kreg[i_] = *reinterpret_cast<const float4*>(kb + (size_t)((KT) * 32 + row_) * ldkv + 4 * c4_);            \
-      vreg[i_] = *reinterpret_cast<const float4*>(vb + (size_t)((KT) * 32 + row_) * ldkv + 4 * c4_);            \
-    }                                                                                                           \
-  }
-#define POEM_STORE_TILE(BUF)                                                                                    \
-  _Pragma("unroll") for (int i_ = 0; i_ < LD; ++i_) {                                                           \
-    const int f_ = tid + NT * i_;                                                                               \
-    if (F4 % NT == 0 || f_ < F4) {                                                                              \
-      const int row_ = f_ / (DH / 4), c4_ = f_ % (DH / 4);                                                      \
-      *reinterpret_cast<float4*>(&Ks[BUF][row_ * KS + 4 * c4_]) = kreg[i_];                                     \
-      *reinterpret_cast<float4*>(&Vs[BUF][row_ * VS + 4 * c4_]) = vreg[i_];                                     \
-    }                                                                                                           \
-  }
-
-  f32x16 o[DT];
+    float4 kf[KC], vf[DT][4];
 #pragma unroll
-  for (int d = 0; d < DT; ++d) o[d] = zero16();
-  float m_run = -INFINITY, l_run = 0.f;
-  const float inv_sdh = 1.0f / sqrtf((float)DH);   // exact for dh in {16, 64, 256}; <= 1 ulp from the division otherwise
+    for (int kc = 0; kc < KC; ++kc) kf[kc] = frag_load(krs, loff, koff + kc * 1024);
+    __builtin_amdgcn_sched_barrier(0);   // issue order Q, K, V as in the loop: the loop header then waits for K only
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) vf[d][g] = frag_load(vrs, loff, voff + (d * 4 + g) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
 
-  const int tps = NK / 32 / ksplit;                // key tiles of this split
-  const int kt0 = ks * tps, kt1 = kt0 + tps;
-  POEM_LOAD_TILE(kt0)
-  POEM_STORE_TILE(0)
-  __syncthreads();
-#ifdef POEM_ATTN_DBG
-  long long ta = 0, tb = 0, tc = 0, tstart = clock64();
-#endif
-  for (int kt = kt0; kt < kt1; ++kt) {
-#ifdef POEM_ATTN_DBG
-    const long long t0 = clock64();
-#endif
-    const int buf = (kt - kt0) & 1;
-    { const int kn = min(kt + 1, kt1 - 1); POEM_LOAD_TILE(kn) }
-    if (wave_live) {
+    f32x16 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[d] = zero16();
+    float m_ref = -INFINITY, nbias = 0.f, l_run = 0.f;
+
+    for (int kt = 0; kt < tpc; ++kt) {
+      XA_STAMP(0);
+      // ---- S^T = K . Q^T (raw scores)
       f32x16 s = zero16();
-      const float* kr = &Ks[buf][r * KS + 4 * h];
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) {
-        const float4 a = *reinterpret_cast<const float4*>(kr + 8 * kc);
-        s = mfma32(a.x, qf[kc].x, s);
-        s = mfma32(a.y, qf[kc].y, s);
-        s = mfma32(a.z, qf[kc].z, s);
-        s = mfma32(a.w, qf[kc].w, s);
+        s = mfma32(kf[kc].x, qf[kc].x, s);
+        s = mfma32(kf[kc].y, qf[kc].y, s);
+        s = mfma32(kf[kc].z, qf[kc].z, s);
+        s = mfma32(kf[kc].w, qf[kc].w, s);
       }
-      float mx = -INFINITY;
+      __builtin_amdgcn_sched_barrier(0);
+      // next tile's K fragments into the registers the MFMAs above have just read (clamped: the last prefetch of an
+      // item re-reads its own last tile)
+      const int adv = (kt + 1 < tpc) ? ktile_bytes : 0;
+      koff += adv;
+#ifndef POEM_XA_NOLOADS
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = s[i] * inv_sdh; mx = fmaxf(mx, s[i]); }
-      mx = fmaxf(mx, xhalf(mx));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = (m_new == m_run) ? 1.0f : (m_run == -INFINITY ? 0.0f : exp_neg(m_run - m_new));
-      float ps = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = exp_neg(s[i] - m_new); ps += s[i]; }
-      ps += xhalf(ps);
-      l_run = l_run * alpha + ps;
-      m_run = m_new;
-#ifdef POEM_ATTN_DBG
-      ta += clock64() - t0;
-      const long long t1 = clock64();
+      for (int kc = 0; kc < KC; ++kc) kf[kc] = frag_load(krs, loff, koff + kc * 1024);
 #endif
-      if (__any(alpha != 1.0f)) {   // exact skip: alpha == 1 whenever this lane's running max did not move
+      __builtin_amdgcn_sched_barrier(0);
+
+      XA_STAMP(1);
+      // ---- softmax numerators, lazy stabiliser
+#if !(POEM_XA_VARIANT & 1)
+      float mx = max3f(s[0], s[1], s[2]);
+      mx = max3f(mx, s[3], s[4]);
+      mx = max3f(mx, s[5], s[6]);
+      mx = max3f(mx, s[7], s[8]);
+      mx = max3f(mx, s[9], s[10]);
+      mx = max3f(mx, s[11], s[12]);
+      mx = max3f(mx, s[13], s[14]);
+      mx = fmaxf(mx, s[15]);
+      if (__any(mx > m_ref + lazy_raw)) {          // wave-uniform, rare after the first tile
+        const float mf = fmaxf(mx, xhalf(mx));     // both halves of a query agree on the new stabiliser
+        const float m_new = (mf > m_ref + lazy_raw) ? mf : m_ref;
+        const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * kc2);   // 1 where unchanged, 0 on the first tile
 #pragma unroll
-        for (int d = 0; d < DT; ++d) {
+        for (int d = 0; d < DT; ++d)
 #pragma unroll
           for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
-        }
+        l_run *= alpha;
+        m_ref = m_new;
+        nbias = -m_new * kc2;
       }
+#endif
+      const f32x2 kc2v = {kc2, kc2}, nbv = {nbias, nbias};
+      f32x2 ps = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        f32x2 tv = {s[i], s[i + 1]};
+        tv = __builtin_elementwise_fma(tv, kc2v, nbv);
+#if !(POEM_XA_VARIANT & 2)
+        tv[0] = __builtin_amdgcn_exp2f(tv[0]);
+        tv[1] = __builtin_amdgcn_exp2f(tv[1]);
+#endif
+        s[i] = tv[0];
+        s[i + 1] = tv[1];
+        ps += tv;
+      }
+      l_run += ps[0] + ps[1];
+      __builtin_amdgcn_sched_barrier(0);
+      XA_STAMP(2);
+
+      // ---- O^T += V^T . P^T; the V fragments of register group g are re-requested (next tile) as soon as the four
+      //      k-steps that read them have been issued
+      voff += adv;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float* vr = &Vs[buf][mfma_row(i, h) * VS + r];
 #pragma unroll
-        for (int d = 0; d < DT; ++d) o[d] = mfma32(vr[32 * d], s[i], o[d]);
-      }
-#ifdef POEM_ATTN_DBG
-      tb += clock64() - t1;
-#endif
-    }
-#ifdef POEM_ATTN_DBG
-    const long long t2 = clock64();
-#endif
-    POEM_STORE_TILE(buf ^ 1)   // (the final, redundant store targets the buffer nobody reads again)
-    __syncthreads();
-#ifdef POEM_ATTN_DBG
-    tc += clock64() - t2;
-#endif
-  }
-#ifdef POEM_ATTN_DBG
-  if (blockIdx.x < 2 && blockIdx.y == 1 && blockIdx.z >= 20 && blockIdx.z < 22 && lane == 0 && wv < 4) {
-    long long* d = &attn_dbg[(((blockIdx.z - 20) * 2 + blockIdx.x) * 4 + wv) * 8];
-    d[0] = kt1 - kt0; d[1] = clock64() - tstart; d[2] = ta; d[3] = tb; d[4] = tc;
-  }
-#endif
-#undef POEM_LOAD_TILE
-#undef POEM_STORE_TILE
-
-  if (!wave_live) return;
-  if (ksplit == 1) {
-    if (qrow < NQ) {
-      float* out = ctx + ((size_t)b * NQ + qrow) * C + head * DH;
-      const float inv_l = 1.0f / l_run;
+        for (int d = 0; d < DT; ++d) o[d] = mfma32((&vf[d][i >> 2].x)[i & 3], s[i], o[d]);
+        if ((i & 3) == 3) {
+          __builtin_amdgcn_sched_barrier(0);
+#ifndef POEM_XA_NOLOADS
 #pragma unroll
-      for (int d = 0; d < DT; ++d) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int ch = 32 * d + 8 * g + 4 * h;
-          if (ch < DH)
-            *reinterpret_cast<float4*>(out + ch) =
-                make_float4(o[d][4 * g] / l_run, o[d][4 * g + 1] / l_run, o[d][4 * g + 2] / l_run, o[d][4 * g + 3] / l_run);
+          for (int d = 0; d < DT; ++d) vf[d][i >> 2] = frag_load(vrs, loff, voff + (d * 4 + (i >> 2)) * 1024);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      (void)inv_l;
+      XA_STAMP(3);
     }
-  } else {
+
     // partial (O, m, l): fragment order, one coalesced 1 KiB store per (channel tile, register group)
-    const int qtiles = (NQ + 31) / 32;
-    const size_t slab = ((size_t)((b * heads + head) * ksplit + ks) * qtiles + qtile);
-    float4* po = part_o + slab * (DT * 4) * 64 + lane;
+    l_run += xhalf(l_run);
+    float4* po = part_o + (size_t)item * (DT * 4) * 64 + lane;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        po[(d * 4 + g) * 64] = make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]);
-    if (h == 0) part_ml[slab * 32 + r] = make_float2(m_run, l_run);
+        nt_store4(po + (d * 4 + g) * 64, make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]));
+    if (h == 0) part_ml[(size_t)item * 32 + r] = make_float2(m_ref, l_run);
+    // drain the stores here: with stores possibly pending at the key loop's header hipcc cannot count on in-order
+    // returns and waits for vmcnt(0) on every iteration, i.e. for the V prefetch it has just issued
+    __builtin_amdgcn_s_waitcnt(0x0F70);
   }
+#ifdef POEM_LAB
+  if (lane == 0) {
+    long long* d = &xattn_dbg[((size_t)blockIdx.x * 4 * W + wv) % 4096 * 4];
+    d[0] = clock64() - dbg_c0; d[1] = wall_clock64() - dbg_w0; d[2] = dbg_items; d[3] = blockIdx.x;
+  }
+#endif
+#ifdef POEM_XA_STAMPS
+  if (dbg_on && lane == 0) for (int i = 0; i < 4; ++i) xattn_ph[i] = dbg_ph[i];
+#endif
 }
 
-// ctx[b, q, head*DH + c] = sum_s e^{m_s - M} O_s[c] / sum_s e^{m_s - M} l_s      (M = max_s m_s)
+// ctx[b, q, head*DH + c] = sum_s w_s O_s[c] / sum_s w_s l_s,   w_s = 2^{(m_s - M) kc2},  M = max_s m_s
 template <int DH>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float4* __restrict__ part_o,
                                                            const float2* __restrict__ part_ml, float* __restrict__ ctx,
-                                                           int NQ, int C, int heads, int ksplit, int total_waves) {
+                                                           int NQ, int C, int heads, int chunks, int total_waves,
+                                                           float kc2) {
   constexpr int DT = (DH + 31) / 32;
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per (b, head, qtile)
   if (wid >= total_waves) return;
-  const int qtiles = (NQ + 31) / 32;
-  const int qtile = wid % qtiles, bh = wid / qtiles, head = bh % heads, b = bh / heads;
-  const int qrow = qtile * 32 + r;
-  float w[16], M = -INFINITY;      // ksplit <= 16
-  for (int s = 0; s < ksplit; ++s) {
-    const float2 ml = part_ml[((size_t)(bh * ksplit + s) * qtiles + qtile) * 32 + r];
+  const int nqt = (NQ + 31) / 32;
+  const int qt = wid % nqt, bh = wid / nqt, head = bh % heads, b = bh / heads;
+  const int qrow = qt * 32 + r;
+  float w[16], M = -INFINITY;      // chunks <= 16
+  for (int s = 0; s < chunks; ++s) {
+    const float2 ml = part_ml[((size_t)(bh * chunks + s) * nqt + qt) * 32 + r];
     w[s] = ml.x;
     M = fmaxf(M, ml.x);
   }
   float den = 0.f;
-  for (int s = 0; s < ksplit; ++s) {
-    const float2 ml = part_ml[((size_t)(bh * ksplit + s) * qtiles + qtile) * 32 + r];
-    w[s] = (w[s] == M) ? 1.0f : exp_neg(w[s] - M);
+  for (int s = 0; s < chunks; ++s) {
+    const float2 ml = part_ml[((size_t)(bh * chunks + s) * nqt + qt) * 32 + r];
+    w[s] = (w[s] == M) ? 1.0f : __builtin_amdgcn_exp2f((w[s] - M) * kc2);
     den = fmaf(w[s], ml.y, den);
   }
   if (qrow >= NQ) return;
-  float* out = ctx + ((size_t)b * NQ + qrow) * C + head * DH;
+  const int c0 = head * DH, vt0 = c0 / 32;
+  float* out = ctx + ((size_t)b * NQ + qrow) * C;
 #pragma unroll
   for (int d = 0; d < DT; ++d)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int ch = 32 * d + 8 * g + 4 * h;
-      if (ch >= DH) continue;
+      const int ch = 32 * (vt0 + d) + 8 * g + 4 * h;          // absolute channel of this float4
+      if (ch < c0 || ch >= c0 + DH) continue;                  // head dims < 32 share a channel tile with other heads
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = 0; s < ksplit; ++s) {
-        const float4 p = part_o[(((size_t)(bh * ksplit + s) * qtiles + qtile) * (DT * 4) + d * 4 + g) * 64 + lane];
+      for (int s = 0; s < chunks; ++s) {
+        const float4 p = nt_load4(part_o + (((size_t)(bh * chunks + s) * nqt + qt) * (DT * 4) + d * 4 + g) * 64 + lane);
         acc.x = fmaf(w[s], p.x, acc.x); acc.y = fmaf(w[s], p.y, acc.y);
         acc.z = fmaf(w[s], p.z, acc.z); acc.w = fmaf(w[s], p.w, acc.w);
       }
@@ -238,75 +288,128 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float4* __restr
     }
 }
 
-// scratch floats needed by the split-key path (0 when the shape runs unsplit)
-extern "C" size_t poem_cross_attention_scratch_floats(int B, int NQ, int NK, int C, int heads, int* ksplit_out) {
-  const int dh = C / heads;
-  const int qtiles = (NQ + 31) / 32;
-  const int ktiles = NK / 32;
-  // 4-wave blocks, 4 resident per CU (1024 slots).  Two key splits measured best on the headline shape (896 x 2 blocks);
-  // the split count deliberately does NOT depend on the batch size: a sample's result is then bit-identical whatever
-  // batch it travels in (the property data-parallel sharding relies on).
-  (void)B; (void)heads; (void)qtiles;
-  const int ks = (ktiles % 2 == 0 && ktiles / 2 >= 16) ? 2 : 1;
-  if (ksplit_out) *ksplit_out = ks;
-  if (ks == 1) return 0;
-  const int DT = (dh + 31) / 32;
-  const size_t slabs = (size_t)B * heads * ks * qtiles;
-  return slabs * (size_t)DT * 4 * 64 * 4 + slabs * 32 * 2;
+// row-major (B*NK, ld) keys / values -> fragment images (op-level entry point and tests; the decoder's projection
+// GEMM writes the images itself)
+__global__ void attn_pack_k_kernel(const float* __restrict__ k, int ld, int C, float4* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  const long f = i >> 6;
+  const int kco = (int)(f % (C / 8));
+  const long mt = f / (C / 8);
+  const float* p = k + (size_t)(mt * 32 + (lane & 31)) * ld + 8 * kco + 4 * (lane >> 5);
+  out[i] = make_float4(p[0], p[1], p[2], p[3]);
 }
 
-template <int NWV, int MINW>
-static hipError_t launch_attn(const float* q, const float* k, const float* v, float* ctx, int B, int NQ, int NK, int C,
-                              int heads, int ldkv, float* scratch, int ksplit, hipStream_t s) {
+__global__ void attn_pack_v_kernel(const float* __restrict__ v, int ld, int C, float4* __restrict__ out, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  const int g = (int)((i >> 6) & 3);
+  const long f = i >> 8;
+  const int vt = (int)(f % (C / 32));
+  const long mt = f / (C / 32);
+  const float* p = v + (size_t)(mt * 32 + 8 * g + 4 * (lane >> 5)) * ld + 32 * vt + (lane & 31);
+  out[i] = make_float4(p[0], p[(size_t)ld], p[2 * (size_t)ld], p[3 * (size_t)ld]);
+}
+
+// key tiles per chunk: a function of the key count and head dim only (see the header)
+static int attn_tiles_per_chunk(int NK, int dh) {
+  const int nkt = NK / 32;
+  (void)dh;
+#ifdef POEM_LAB
+  if (const char* e = getenv("POEM_ATTN_TPC")) { const int t = atoi(e); if (t > 0 && nkt % t == 0) return t; }
+#endif
+  if (nkt % 32 == 0 && nkt >= 64) return 32;
+  return nkt;
+}
+
+// scratch floats: partial (O, m, l) of every item [+ the two fragment images when the caller passes row-major k, v]
+extern "C" size_t poem_cross_attention_scratch_floats(int B, int NQ, int NK, int C, int heads, int with_images) {
   const int dh = C / heads;
-  const int qtiles = (NQ + 31) / 32;
+  const int nqt = (NQ + 31) / 32;
+  const int chunks = (NK / 32) / attn_tiles_per_chunk(NK, dh);
   const int DT = (dh + 31) / 32;
-  const size_t slabs = (size_t)B * heads * ksplit * qtiles;
+  const size_t items = (size_t)B * heads * chunks * nqt;
+  size_t n = items * (size_t)DT * 4 * 64 * 4 + items * 32 * 2;
+  n = (n + 63) / 64 * 64;
+  if (with_images) n += 2 * (size_t)B * NK * C;
+  return n;
+}
+
+static int poem_attn_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+
+// q (B, NQ, ldq) row-major; kimg / vimg: fragment images of the (B*NK, C) key / value matrices
+extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, const void* kimg, const void* vimg,
+                                                      float* ctx, int B, int NQ, int NK, int C, int heads,
+                                                      float* scratch, hipStream_t s) {
+  const int dh = C / heads;
+  if (NK % 32 || C % 32 || (size_t)B * NK * C * 4 >= (1ull << 31)) return hipErrorInvalidValue;
+  const int nqt = (NQ + 31) / 32;
+  const int tpc = attn_tiles_per_chunk(NK, dh);
+  const int chunks = (NK / 32) / tpc;
+  if (chunks > 16) return hipErrorInvalidValue;
+  const int DT = (dh + 31) / 32;
+  const size_t items = (size_t)B * heads * chunks * nqt;
   float4* part_o = reinterpret_cast<float4*>(scratch);
-  float2* part_ml = reinterpret_cast<float2*>(scratch + slabs * (size_t)DT * 4 * 64 * 4);
-  dim3 grid((qtiles + NWV - 1) / NWV, heads, B * ksplit), block(NWV * 64);
-  const int waves = B * heads * qtiles;
-#define POEM_ATTN_CASE(D)                                                                                       \
-  case D:                                                                                                       \
-    hipLaunchKernelGGL((cross_attn_kernel<D, NWV, MINW>), grid, block, 0, s, q, k, v, ctx, part_o, part_ml, NQ, NK, C, \
-                       ldkv, ksplit);                                                                           \
-    if (ksplit > 1)                                                                                             \
-      hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, \
-                         C, heads, ksplit, waves);                                                              \
-    break
+  float2* part_ml = reinterpret_cast<float2*>(scratch + items * (size_t)DT * 4 * 64 * 4);
+  const float kc2 = (float)(1.4426950408889634 / sqrt((double)dh));
+  const float lazy_raw = POEM_ATTN_LAZY_LOG2 / kc2;
+  const int cus = poem_attn_cus();
+  const int grid = (int)std::min<size_t>((size_t)cus, (items + 3) / 4);
+  const int waves = B * heads * nqt;
+#define POEM_XATTN(D, WV)                                                                                         \
+  hipLaunchKernelGGL((xattn_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, (const float4*)kimg,        \
+                     (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map);         \
+  hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
+                     heads, chunks, waves, kc2)
+  int wsel = 0, map = 0;
+#ifdef POEM_LAB
+  if (const char* e = getenv("POEM_ATTN_W")) wsel = atoi(e);
+  if (const char* e = getenv("POEM_ATTN_MAP")) map = atoi(e);
+#endif
   switch (dh) {
-    POEM_ATTN_CASE(8);
-    POEM_ATTN_CASE(16);
-    POEM_ATTN_CASE(32);
-    POEM_ATTN_CASE(64);
-    POEM_ATTN_CASE(128);
+    case 8: POEM_XATTN(8, 4); break;
+    case 16: POEM_XATTN(16, 4); break;
+    case 32: POEM_XATTN(32, 4); break;
+    case 64:
+      if (wsel == 2) { POEM_XATTN(64, 2); }
+#ifdef POEM_LAB
+      else if (wsel == 1) { POEM_XATTN(64, 1); }
+#endif
+      else if (wsel == 4) { POEM_XATTN(64, 4); }
+      else { POEM_XATTN(64, 3); }
+      break;
+    case 128:
+      if (wsel == 2) { POEM_XATTN(128, 2); }
+      else { POEM_XATTN(128, 1); }
+      break;
     default:
       return hipErrorInvalidValue;
   }
-#undef POEM_ATTN_CASE
+#undef POEM_XATTN
   return hipGetLastError();
 }
 
+// row-major k, v (B*NK rows, ldkv) -> images in scratch -> kernel above
 extern "C" hipError_t poem_launch_cross_attention(const float* q, const float* k, const float* v, float* ctx, int B,
                                                   int NQ, int NK, int C, int heads, int ldkv, float* scratch,
                                                   hipStream_t s) {
-  int ksplit = 1;
-  const size_t need = poem_cross_attention_scratch_floats(B, NQ, NK, C, heads, &ksplit);
-  if (need && !scratch) ksplit = 1;
-#ifdef POEM_LAB
-  int cfg = 0;
-  if (const char* e = getenv("POEM_ATTN_KS")) { const int kk = atoi(e); if (kk >= 1 && kk <= ksplit) ksplit = kk; }
-  if (const char* e = getenv("POEM_ATTN_CFG")) cfg = atoi(e);
-  switch (cfg) {
-    case 1: return launch_attn<4, 3>(q, k, v, ctx, B, NQ, NK, C, heads, ldkv, scratch, ksplit, s);
-    case 2: return launch_attn<4, 4>(q, k, v, ctx, B, NQ, NK, C, heads, ldkv, scratch, ksplit, s);
-    case 3: return launch_attn<5, 3>(q, k, v, ctx, B, NQ, NK, C, heads, ldkv, scratch, ksplit, s);
-    case 4: return launch_attn<8, 4>(q, k, v, ctx, B, NQ, NK, C, heads, ldkv, scratch, ksplit, s);
-    case 5: return launch_attn<8, 3>(q, k, v, ctx, B, NQ, NK, C, heads, ldkv, scratch, ksplit, s);
-    default: break;
-  }
-#endif
-  // head dim 128 (POEM-large) needs ~200 VGPRs: two waves per SIMD without spills beat three with
-  if (C / heads >= 128) return launch_attn<4, 2>(q, k, v, ctx, B, NQ, NK, C, heads, ldkv, scratch, ksplit, s);
-  return launch_attn<4, 3>(q, k, v, ctx, B, NQ, NK, C, heads, ldkv, scratch, ksplit, s);
+  if (NK % 32 || C % 32) return hipErrorInvalidValue;
+  const size_t part = poem_cross_attention_scratch_floats(B, NQ, NK, C, heads, 0);
+  float4* kimg = reinterpret_cast<float4*>(scratch + part);
+  float4* vimg = kimg + (size_t)B * NK * C / 4;
+  const long total = (long)B * NK * C / 4;
+  hipLaunchKernelGGL(attn_pack_k_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k, ldkv, C, kimg, total);
+  hipLaunchKernelGGL(attn_pack_v_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, v, ldkv, C, vimg, total);
+  return poem_launch_cross_attention_img(q, C, kimg, vimg, ctx, B, NQ, NK, C, heads, scratch, s);
 }

@@ -208,33 +208,36 @@ extern "C" hipError_t poem_launch_gemm2(const float* X, int ldx, const void* Wp,
 // in LDS (fragment order, conflict-free ds_read_b128) and its 8 waves (2 per SIMD) stream row groups of MT x 32 rows:
 // the only global traffic of the main loop is the X operand (16-byte fragment loads, one chunk ahead), so L2 carries
 // 1/3 of what the operands-from-L2 kernel above needs, and a fused wide N (several Linears that share the input,
-// weights concatenated along N) reads X from HBM once per panel pass.  Plain formulation D[m][n] (lane = output column):
-// every store instruction writes two full 128-byte row segments.
+// weights concatenated along N) reads X from HBM once per panel pass.
 // act2 applies to columns >= act_split (two Linears with different activations fused along N).
-template <int NT, int MT, bool GELU>
-__global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restrict__ X, int ldx,
-                                                            const float4* __restrict__ Wp, const float* __restrict__ bias,
-                                                            const float* __restrict__ R, int ldr, float* __restrict__ Y,
-                                                            int ldy, int M, int N, int K, int act, int act_split, int act2) {
+//
+// Output modes, per column segment of a fused N (PanelSegs; seg_cols == 0 -> one row-major output Y/ldy):
+//   0  row-major: plain formulation D[m][n] (lane = output column), every store writes two 128-byte row segments
+//   1  K image for attn.hip: transposed formulation D[n][m] (operands swapped in the MFMA, same registers) -- lane =
+//      row, registers = 16 output channels = four float4 fragments of the packed-activation order -> 1 KiB stores
+//   2  V image for attn.hip: plain formulation, registers 4g..4g+3 of a lane are four consecutive rows of one column
+//      = one float4 of the image -> 1 KiB stores
+// The image modes need M % 32 == 0 and carry no residual.
+struct PanelSegs {
+  float* ptr[6];
+  int mode[6];
+  int seg_cols;
+};
+
+template <int NT, int MT, bool GELU, int OMODE>
+__device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx, const float4* __restrict__ wl,
+                                           const float* __restrict__ bias, const float* __restrict__ R, int ldr,
+                                           float* __restrict__ Y, int ldy, int M, int K, int pact, int col0, int ycol0,
+                                           int bip, int blocks_in_panel) {
   constexpr int NWV = 8;
   const int KC = K >> 3;
-  extern __shared__ __attribute__((aligned(16))) float4 wl[];   // NT * KC * 64 float4
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int panels = N / (32 * NT);
-  const int panel = blockIdx.x % panels, bip = blockIdx.x / panels;
-  const int blocks_in_panel = ((int)gridDim.x - panel + panels - 1) / panels;
-  {
-    const float4* src = Wp + (size_t)panel * NT * KC * 64;
-    for (int i = tid; i < NT * KC * 64; i += NWV * 64) wl[i] = src[i];
-  }
-  __syncthreads();
   const int mtiles = (M + 31) / 32;
   const int rgroups = (mtiles + MT - 1) / MT;
-  const int pact = (panel * NT * 32 >= act_split) ? act2 : act;
   const __amdgpu_buffer_rsrc_t xrs = frag_rsrc(X, 0xffffffffu);
   float bv[NT];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) bv[n] = bias ? bias[(panel * NT + n) * 32 + r] : 0.f;
+  for (int n = 0; n < NT; ++n) bv[n] = (bias && OMODE != 1) ? bias[col0 + n * 32 + r] : 0.f;
   const size_t lane_yo = (size_t)(4 * h) * ldy + r, lane_ro = (size_t)(4 * h) * ldr + r;
   for (int rg = bip * NWV + wv; rg < rgroups; rg += blocks_in_panel * NWV) {
     const int mt0 = rg * MT;
@@ -254,8 +257,9 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
 #define POEM_MMA(A, B)                                                          \
   _Pragma("unroll") for (int t = 0; t < 4; ++t) {                               \
     _Pragma("unroll") for (int n = 0; n < NT; ++n) {                            \
-      const float bv = (&B[n].x)[t];                                            \
-      _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][n] = mfma32((&A[i].x)[t], bv, acc[i][n]); \
+      const float bw = (&B[n].x)[t];                                            \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i)                            \
+        acc[i][n] = OMODE == 1 ? mfma32(bw, (&A[i].x)[t], acc[i][n]) : mfma32((&A[i].x)[t], bw, acc[i][n]); \
     }                                                                           \
   }
     POEM_LOADA(a0, 0) POEM_LOADB(b0, 0)
@@ -274,6 +278,29 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
 #undef POEM_LOADA
 #undef POEM_LOADB
 #undef POEM_MMA
+    if (OMODE == 1) {
+      // D[n][m]: lane = row of the tile, register e = channel 8(e>>2) + 4h + (e&3) of column tile n.
+      // image float4 index ((mt * ldy/8 + kco) * 64 + lane), kco = (ycol0 + 32n)/8 + g      (ldy = segment width)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if ((mt0 + i) * 32 >= M) break;
+        float4* yp = reinterpret_cast<float4*>(Y) + ((size_t)(mt0 + i) * (ldy >> 3) + (ycol0 >> 3)) * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float4 v = make_float4(acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+            if (bias) {
+              const float4 bb = *reinterpret_cast<const float4*>(bias + col0 + n * 32 + 8 * g + 4 * h);
+              v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            }
+            if (pact == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (GELU && pact == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+            yp[(size_t)(n * 4 + g) * 64] = v;
+          }
+      }
+      continue;
+    }
     // Epilogue.  The partner wave on this SIMD is usually inside its MFMA loop and the two compete for issue slots, so
     // every instruction here costs several times its nominal latency: bias lives in registers for the whole block, the
     // store address is a wave-uniform (scalar) row base + one per-lane offset, and in-bounds tiles skip the row checks.
@@ -281,9 +308,6 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
     for (int i = 0; i < MT; ++i) {
       const int trow0 = (mt0 + i) * 32;
       if (trow0 >= M) break;
-      float* yl = Y + (size_t)trow0 * ldy + (size_t)panel * NT * 32 + lane_yo;               // per-lane base, once
-      const float* rl = R ? R + (size_t)trow0 * ldr + (size_t)panel * NT * 32 + lane_ro : nullptr;
-      const bool full = trow0 + 32 <= M;
       // bias + activation in place (branch outside the register loops)
       if (GELU && pact == 2) {
 #pragma unroll
@@ -301,6 +325,20 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][n][e] += bv[n];
       }
+      if (OMODE == 2) {
+        // image float4 index (((mt * ldy/32 + vt) * 4 + g) * 64 + lane), vt = ycol0/32 + n
+        float4* yp = reinterpret_cast<float4*>(Y) + ((size_t)(mt0 + i) * (ldy >> 5) + (ycol0 >> 5)) * 256 + lane;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            yp[(size_t)(n * 4 + g) * 64] =
+                make_float4(acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+        continue;
+      }
+      float* yl = Y + (size_t)trow0 * ldy + (size_t)ycol0 + lane_yo;               // per-lane base, once
+      const float* rl = R ? R + (size_t)trow0 * ldr + (size_t)col0 + lane_ro : nullptr;
+      const bool full = trow0 + 32 <= M;
       if (full) {
         if (rl) {
 #pragma unroll
@@ -338,6 +376,42 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
   }
 }
 
+template <int NT, int MT, bool GELU>
+__global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restrict__ X, int ldx,
+                                                            const float4* __restrict__ Wp, const float* __restrict__ bias,
+                                                            const float* __restrict__ R, int ldr, float* __restrict__ Y,
+                                                            int ldy, int M, int N, int K, int act, int act_split, int act2,
+                                                            PanelSegs segs) {
+  constexpr int NWV = 8;
+  const int KC = K >> 3;
+  extern __shared__ __attribute__((aligned(16))) float4 wl[];   // NT * KC * 64 float4
+  const int tid = threadIdx.x;
+  const int panels = N / (32 * NT);
+  const int panel = blockIdx.x % panels, bip = blockIdx.x / panels;
+  const int blocks_in_panel = ((int)gridDim.x - panel + panels - 1) / panels;
+  {
+    const float4* src = Wp + (size_t)panel * NT * KC * 64;
+    for (int i = tid; i < NT * KC * 64; i += NWV * 64) wl[i] = src[i];
+  }
+  __syncthreads();
+  const int col0 = panel * NT * 32;
+  const int pact = (col0 >= act_split) ? act2 : act;
+  if (segs.seg_cols == 0) {
+    panel_rows<NT, MT, GELU, 0>(X, ldx, wl, bias, R, ldr, Y, ldy, M, K, pact, col0, col0, bip, blocks_in_panel);
+    return;
+  }
+  const int sidx = col0 / segs.seg_cols;
+  const int ycol0 = col0 - sidx * segs.seg_cols;
+  float* ys = segs.ptr[sidx];
+  const int mode = segs.mode[sidx];
+  if (mode == 1)
+    panel_rows<NT, MT, GELU, 1>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
+  else if (mode == 2)
+    panel_rows<NT, MT, GELU, 2>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
+  else
+    panel_rows<NT, MT, GELU, 0>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
+}
+
 static int poem_num_cus() {
   static int cus = 0;
   if (!cus) {
@@ -352,7 +426,7 @@ static int poem_num_cus() {
 template <int NT, int MT, bool GELU>
 static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
                                  float* Y, int ldy, int M, int N, int K, int act, int act_split, int act2,
-                                 hipStream_t s) {
+                                 const PanelSegs& segs, hipStream_t s) {
   const size_t lds = (size_t)NT * (K / 8) * 64 * 16;
   auto kern = gemm_panel_kernel<NT, MT, GELU>;
   static size_t lds_set = 0;
@@ -365,23 +439,24 @@ static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const 
   const int panels = N / (32 * NT);
   const int grid = std::max(poem_num_cus(), panels);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, X, ldx, (const float4*)Wp, bias, R, ldr, Y, ldy, M, N, K, act,
-                     act_split, act2);
+                     act_split, act2, segs);
   return hipGetLastError();
 }
 
-// Fused-N aware GEMM entry: columns [0, act_split) use `act`, columns [act_split, N) use `act2`.
-extern "C" hipError_t poem_launch_gemm_split(const float* X, int ldx, const void* Wp, const float* bias, const float* R,
-                                             int ldr, float* Y, int ldy, int M, int N, int K, int act, int act_split,
-                                             int act2, hipStream_t s) {
+static hipError_t launch_gemm_split_impl(const float* X, int ldx, const void* Wp, const float* bias, const float* R,
+                                         int ldr, float* Y, int ldy, int M, int N, int K, int act, int act_split,
+                                         int act2, const PanelSegs& segs, hipStream_t s) {
+  const bool seg = segs.seg_cols > 0;
   // panel kernel: N a multiple of 32*NT, panel (NT*K*128 B) within 128 KiB of LDS, the split on a panel boundary
   int NT = 0;
   for (int c : {4, 2, 1})
-    if (N % (32 * c) == 0 && (size_t)c * K * 128 <= 128 * 1024 && (act_split >= N || act_split % (32 * c) == 0)) { NT = c; break; }
+    if (N % (32 * c) == 0 && (size_t)c * K * 128 <= 128 * 1024 && (act_split >= N || act_split % (32 * c) == 0) &&
+        (!seg || segs.seg_cols % (32 * c) == 0)) { NT = c; break; }
   // deep K leaves room for a single 32-column tile per panel, which re-reads X every 8 MFMAs: the operands-from-L2
   // kernel is faster there (ffn output Linear, K = 4C)
-  if (NT == 1 && N >= 64 && K >= 512 && !(act_split < N && act2 != act)) NT = 0;
+  if (!seg && NT == 1 && N >= 64 && K >= 512 && !(act_split < N && act2 != act)) NT = 0;
   if (NT == 0 || K % 8 || ((uintptr_t)X & 15) || ldx % 4 || (unsigned long long)M * ldx * 4ull >= (1ull << 32)) {
-    if (act_split < N && act2 != act) return hipErrorInvalidValue;
+    if (seg || (act_split < N && act2 != act)) return hipErrorInvalidValue;
     return poem_launch_gemm2(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, 0, 0, s);
   }
   const int mtiles = (M + 31) / 32, panels = N / (32 * NT);
@@ -389,16 +464,37 @@ extern "C" hipError_t poem_launch_gemm_split(const float* X, int ldx, const void
   auto cost = [&](int mt) { return (long)(((mtiles + mt - 1) / mt + wpp - 1) / wpp) * mt; };
   const bool mt2 = 5 * cost(2) <= 6 * cost(1);   // 64-row wave tiles unless the 32-row split balances >= 20 % better
   const bool gelu = act == 2 || (act_split < N && act2 == 2);
-#define POEM_PANEL(NTV)                                                                                            \
-  if (gelu)                                                                                                        \
-    return mt2 ? launch_panel_t<NTV, 2, true>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)   \
-               : launch_panel_t<NTV, 1, true>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s);  \
-  return mt2 ? launch_panel_t<NTV, 2, false>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)    \
-             : launch_panel_t<NTV, 1, false>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s)
+#define POEM_PANEL(NTV)                                                                                                  \
+  if (gelu)                                                                                                              \
+    return mt2 ? launch_panel_t<NTV, 2, true>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s)   \
+               : launch_panel_t<NTV, 1, true>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s);  \
+  return mt2 ? launch_panel_t<NTV, 2, false>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s)    \
+             : launch_panel_t<NTV, 1, false>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s)
   if (NT == 4) { POEM_PANEL(4); }
   if (NT == 2) { POEM_PANEL(2); }
   POEM_PANEL(1);
 #undef POEM_PANEL
+}
+
+// Fused-N aware GEMM entry: columns [0, act_split) use `act`, columns [act_split, N) use `act2`.
+extern "C" hipError_t poem_launch_gemm_split(const float* X, int ldx, const void* Wp, const float* bias, const float* R,
+                                             int ldr, float* Y, int ldy, int M, int N, int K, int act, int act_split,
+                                             int act2, hipStream_t s) {
+  PanelSegs none{};
+  return launch_gemm_split_impl(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, none, s);
+}
+
+// Fused-N GEMM whose N = nsegs * seg_cols columns go to separate outputs, each in its own layout:
+// mode 0 row-major (ld = seg_cols), 1 attention K image, 2 attention V image (see attn.hip).  M % 32 == 0.
+extern "C" hipError_t poem_launch_gemm_segs(const float* X, int ldx, const void* Wp, const float* bias, int M, int K,
+                                            int act, int seg_cols, int nsegs, float* const* outs, const int* modes,
+                                            hipStream_t s) {
+  if (nsegs < 1 || nsegs > 6 || seg_cols % 32 || M % 32) return hipErrorInvalidValue;
+  PanelSegs segs{};
+  segs.seg_cols = seg_cols;
+  for (int i = 0; i < nsegs; ++i) { segs.ptr[i] = outs[i]; segs.mode[i] = modes[i]; }
+  const int N = seg_cols * nsegs;
+  return launch_gemm_split_impl(X, ldx, Wp, bias, nullptr, 0, nullptr, 0, M, N, K, act, N, act, segs, s);
 }
 
 extern "C" hipError_t poem_launch_gemm(const float* X, int ldx, const void* Wp, const float* bias, const float* R,

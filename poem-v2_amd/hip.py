@@ -10,7 +10,7 @@ import torch  # noqa: F401  (must be imported before the library so that both sh
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libpoem_hip.so")
+LIB_PATH = os.environ.get("POEM_HIP_LIB") or os.path.join(CSRC, "libpoem_hip.so")   # override: A/B runs of a kept build
 ASSETS = os.path.join(_HERE, "assets")
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
