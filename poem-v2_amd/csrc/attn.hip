@@ -33,8 +33,6 @@
 #include <cmath>
 #include <cstdlib>
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 #define POEM_ATTN_LAZY_LOG2 8.0f
 #ifndef POEM_XA_VARIANT
 #define POEM_XA_VARIANT 0
@@ -171,7 +169,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
       mx = max3f(mx, s[13], s[14]);
       mx = fmaxf(mx, s[15]);
       if (__any(mx > m_ref + lazy_raw)) {          // wave-uniform, rare after the first tile
-        const float mf = fmaxf(mx, xhalf(mx));     // both halves of a query agree on the new stabiliser
+        const float mf = half_max(mx);             // both halves of a query agree on the new stabiliser
         const float m_new = (mf > m_ref + lazy_raw) ? mf : m_ref;
         const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * kc2);   // 1 where unchanged, 0 on the first tile
 #pragma unroll
@@ -221,7 +219,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
     }
 
     // partial (O, m, l): fragment order, one coalesced 1 KiB store per (channel tile, register group)
-    l_run += xhalf(l_run);
+    l_run = half_sum(l_run);
     float4* po = part_o + (size_t)item * (DT * 4) * 64 + lane;
 #pragma unroll
     for (int d = 0; d < DT; ++d)

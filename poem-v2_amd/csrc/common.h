@@ -27,6 +27,20 @@ __device__ __forceinline__ f32x16 zero16() {
 // exchange with the lane 32 positions away (the other half-wave)
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 
+// Reductions over the two half-waves (lane l and lane l ^ 32) with one v_permlane32_swap: after the swap of a value with
+// itself, r[0] holds the lower half's values in both halves and r[1] the upper half's, so r[0] (+) r[1] is the
+// two-half reduction in every lane (no LDS round trip, two VALU instructions).
+__device__ __forceinline__ float half_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float half_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // exp(x) for x <= 0 (softmax numerators) with ~1 ulp accuracy in 6 VALU ops: x*log2(e) is split into a rounded head
 // (fed to the hardware exp2) and an fma-recovered tail applied as a first-order correction.
 __device__ __forceinline__ float exp_neg(float x) {

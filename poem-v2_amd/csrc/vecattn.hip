@@ -75,26 +75,36 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
     const int kq_ = min((KCI), KC - 1);                                                   \
     _Pragma("unroll") for (int p = 0; p < P; ++p) XR[p] = xc[(kq_ * 8 + (T)) * XS + 32 * p]; \
   }
-#define VA_MMA(A, T, XR)                                                                  \
+  // INIT: the very first k-step takes its C operand from the inline constant 0 -- the accumulators are never zeroed
+  // with v_mov (64 VALU instructions per GEMM that would come straight out of the matrix pipe's time)
+#define VA_MMA(A, T, XR, INIT)                                                            \
   _Pragma("unroll") for (int tp = 0; tp < TPW; ++tp) {                                    \
     const float av = (&A[tp].x)[T];                                                       \
-    _Pragma("unroll") for (int p = 0; p < P; ++p)                                         \
-      acc[tp][p] = FLIP ? mfma32(XR[p], av, acc[tp][p]) : mfma32(av, XR[p], acc[tp][p]);  \
+    _Pragma("unroll") for (int p = 0; p < P; ++p) {                                       \
+      const f32x16 c_ = (INIT) ? zero16() : acc[tp][p];                                   \
+      acc[tp][p] = FLIP ? mfma32(XR[p], av, c_) : mfma32(av, XR[p], c_);                  \
+    }                                                                                     \
   }
-#define VA_CHUNK(A, KCI)                                                                  \
-  VA_READX(xb, KCI, 1) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 0, xa) __builtin_amdgcn_sched_barrier(0); \
-  VA_READX(xa, KCI, 2) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 1, xb) __builtin_amdgcn_sched_barrier(0); \
-  VA_READX(xb, KCI, 3) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 2, xa) __builtin_amdgcn_sched_barrier(0); \
-  VA_READX(xa, (KCI) + 1, 0) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 3, xb) __builtin_amdgcn_sched_barrier(0);
+#define VA_CHUNK(A, KCI, INIT)                                                            \
+  VA_READX(xb, KCI, 1) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 0, xa, INIT) __builtin_amdgcn_sched_barrier(0); \
+  VA_READX(xa, KCI, 2) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 1, xb, false) __builtin_amdgcn_sched_barrier(0); \
+  VA_READX(xb, KCI, 3) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 2, xa, false) __builtin_amdgcn_sched_barrier(0); \
+  VA_READX(xa, (KCI) + 1, 0) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 3, xb, false) __builtin_amdgcn_sched_barrier(0);
   VA_LOADW(a0, 0)
   VA_READX(xa, 0, 0)
-  for (int kc = 0; kc < KC; kc += 2) {
+  VA_LOADW(a1, 1)
+  __builtin_amdgcn_sched_barrier(0);
+  VA_CHUNK(a0, 0, true)
+  VA_LOADW(a0, 2)
+  __builtin_amdgcn_sched_barrier(0);
+  VA_CHUNK(a1, 1, false)
+  for (int kc = 2; kc < KC; kc += 2) {
     VA_LOADW(a1, kc + 1)
     __builtin_amdgcn_sched_barrier(0);
-    VA_CHUNK(a0, kc)
+    VA_CHUNK(a0, kc, false)
     VA_LOADW(a0, kc + 2)
     __builtin_amdgcn_sched_barrier(0);
-    VA_CHUNK(a1, kc + 1)
+    VA_CHUNK(a1, kc + 1, false)
   }
 #undef VA_LOADW
 #undef VA_READX
@@ -111,7 +121,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   float* X = smem;                                   // C * XS
   float* dl = smem + C * XS;                         // P*32*3 coordinate deltas
   int* sidx = reinterpret_cast<int*>(dl + P * 32 * 3);  // P*32 neighbour row ids
-  float* qs = reinterpret_cast<float*>(sidx + P * 32);  // P*C query rows
+  int* voffs = sidx + P * 32;                           // P*32 byte offsets of the neighbours' v rows
+  float* qs = reinterpret_cast<float*>(voffs + P * 32); // P*C query rows
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
   const int groups = (A.Q + P - 1) / P;
@@ -152,6 +163,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
     dl[tid * 3 + 1] = qx[1] - nx[1];
     dl[tid * 3 + 2] = qx[2] - nx[2];
     sidx[tid] = id;
+    voffs[tid] = (int)(((unsigned)b * (unsigned)A.NS + (unsigned)id) * (unsigned)(A.ldv * 4));
   }
   for (int f = tid; f < P * C / 4; f += NT) {           // query rows -> LDS (read back as broadcasts in epilogue 1)
     const int p = f / (C / 4), c4 = f % (C / 4);
@@ -194,11 +206,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   }
   __syncthreads();
 
-  f32x16 acc[TPW][P], pos[TPW][P];
-#pragma unroll
-  for (int tp = 0; tp < TPW; ++tp)
-#pragma unroll
-    for (int p = 0; p < P; ++p) acc[tp][p] = zero16();
+  f32x16 acc[TPW][P], pos[TPW][P];   // acc is initialised by the first k-step of every GEMM (chain_gemm, INIT)
 
   // k_j for this lane's (channel tile, neighbour) cells: 16-byte row gathers issued BEFORE the first GEMM so their
   // L2/HBM latency hides under its MFMAs; they wait in the registers that become `pos` in the epilogue.
@@ -232,10 +240,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       for (int p = 0; p < P; ++p) {
         const float4 qq = *reinterpret_cast<const float4*>(qs + p * C + cbase + 8 * g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pv = acc[tp][p][4 * g + e] + (&bb.x)[e];
-          acc[tp][p][4 * g + e] = ((&qq.x)[e] - pos[tp][p][4 * g + e]) + pv;
-          pos[tp][p][4 * g + e] = pv;
+        for (int e = 0; e < 4; e += 2) {      // register pairs -> v_pk_add_f32
+          const int i = 4 * g + e;
+          const f32x2 pv = f32x2{acc[tp][p][i], acc[tp][p][i + 1]} + f32x2{(&bb.x)[e], (&bb.x)[e + 1]};
+          const f32x2 tv = (f32x2{(&qq.x)[e], (&qq.x)[e + 1]} - f32x2{pos[tp][p][i], pos[tp][p][i + 1]}) + pv;
+          acc[tp][p][i] = tv[0]; acc[tp][p][i + 1] = tv[1];
+          pos[tp][p][i] = pv[0]; pos[tp][p][i + 1] = pv[1];
         }
       }
     }
@@ -248,7 +258,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = acc[tp][p][i];
-        acc[tp][p][i] = 0.f;
       }
   __syncthreads();
 
@@ -269,7 +278,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * g + e;
           X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = fmaxf(acc[tp][p][i] + (&bb.x)[e], 0.f);
-          acc[tp][p][i] = 0.f;
         }
     }
   }
@@ -281,43 +289,54 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   VA_STAMP(6);
   __syncthreads();   // X is dead from here on: reuse it as per-wave transpose scratch
 
+  // Softmax over the 32 neighbours (registers x 2 half-waves) and the weighted sum, written for instruction count --
+  // every VALU instruction here comes out of the matrix pipe's time (tools/lab/phase_lab):
+  //   * b_g2 is constant over the neighbours of a channel, so softmax_j((a_ij + b_g2)/sqrt(C)) == softmax_j(a_ij/sqrt(C)):
+  //     the bias is not applied at all;
+  //   * scale, log2(e) and the stabiliser fold into one packed fma per register pair, then v_exp_f32;
+  //   * sums / weighted sums run on register pairs (v_pk_add_f32 / v_pk_fma_f32), the normalisation is one reciprocal
+  //     at the end, the two half-waves meet through v_permlane32_swap;
+  //   * the v_j gathers take a 32-bit row offset from LDS (voffs) through a buffer descriptor: one v_add per load.
   float* scr = X + wv * (32 * 33);
+  const float k2 = inv_sqrt_c * 1.44269504088896340736f;
+  const __amdgpu_buffer_rsrc_t vrs = frag_rsrc(A.v, 0xffffffffu);
 #pragma unroll
   for (int tp = 0; tp < TPW; ++tp) {
     const int cch = (wv * TPW + tp) * 32 + j;   // this lane's output channel
-    const float bg = A.bg2[cch];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       // pos tile [c'][j] (lane = neighbour) -> [j][c'] (lane = channel) through the wave-private scratch
 #pragma unroll
       for (int i = 0; i < 16; ++i) scr[j * 33 + mfma_row(i, h)] = pos[tp][p][i];
+      float vg[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        vg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrs, voffs[p * 32 + mfma_row(i, h)] + cch * 4, 0, 0));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      float val[16];
+      float pt[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int jj = mfma_row(i, h);
-        const float pt = scr[jj * 33 + j];
-        const float vg = A.v[((size_t)b * A.NS + sidx[p * 32 + jj]) * A.ldv + cch];
-        val[i] = vg + pt;
-      }
+      for (int i = 0; i < 16; ++i) pt[i] = scr[mfma_row(i, h) * 33 + j];
+      f32x16& a = acc[tp][p];
+      float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
+#pragma unroll
+      for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, a[i]), a[i + 1]);
+      mx = half_max(fmaxf(mx, a[15]));
+      const float nb = -mx * k2;
+      const f32x2 k2v = {k2, k2}, nbv = {nb, nb};
+      f32x2 sum2 = {0.f, 0.f}, res2 = {0.f, 0.f};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      float mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        acc[tp][p][i] = (acc[tp][p][i] + bg) * inv_sqrt_c;
-        mx = fmaxf(mx, acc[tp][p][i]);
+      for (int i = 0; i < 16; i += 2) {
+        f32x2 e = __builtin_elementwise_fma(f32x2{a[i], a[i + 1]}, k2v, nbv);
+        e[0] = __builtin_amdgcn_exp2f(e[0]);
+        e[1] = __builtin_amdgcn_exp2f(e[1]);
+        const f32x2 val = f32x2{vg[i], vg[i + 1]} + f32x2{pt[i], pt[i + 1]};
+        sum2 += e;
+        res2 = __builtin_elementwise_fma(e, val, res2);
       }
-      mx = fmaxf(mx, xhalf(mx));
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { acc[tp][p][i] = exp_neg(acc[tp][p][i] - mx); sum += acc[tp][p][i]; }
-      sum += xhalf(sum);
-      const float inv_sum = 1.0f / sum;
-      float res = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) res = fmaf(acc[tp][p][i] * inv_sum, val[i], res);
-      res += xhalf(res);
-      if (h == 0 && i0 + p < A.Q) A.out[((size_t)b * A.Q + i0 + p) * C + cch] = res;
+      const float sum = half_sum(sum2[0] + sum2[1]);
+      const float res = half_sum(res2[0] + res2[1]);
+      if (h == 0 && i0 + p < A.Q) A.out[((size_t)b * A.Q + i0 + p) * C + cch] = res * __builtin_amdgcn_rcpf(sum);
     }
   }
   VA_STAMP(7);
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
 template <int C, int P, int NW, int MINW>
 static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s) {
   const int groups = (a.Q + P - 1) / P;
-  size_t lds = (size_t)C * 32 * P * 4 + P * 32 * 3 * 4 + P * 32 * 4 + (size_t)P * C * 4;
+  size_t lds = (size_t)C * 32 * P * 4 + P * 32 * 3 * 4 + 2 * P * 32 * 4 + (size_t)P * C * 4;
 #ifdef POEM_VA_DBG
   if (const char* e = getenv("POEM_VA_LDSPAD")) lds += atoi(e);
 #endif
