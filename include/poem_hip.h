@@ -177,6 +177,30 @@ int poem_triangulate_dlt(const float* uv, const float* cam_intr, const float* ca
  * uv (BN,J,2) in image pixels: normalise by (sum + 1e-6), expectation of (x/Wh, y/Hh), scale by (img_w, img_h). */
 int poem_heatmap_uv(const float* heatmaps, float* uv, int views, int njoints, int hm_h, int hm_w, float img_w, float img_h,
                     void* stream);
+/* Convolutional glue between the backbone's multi-level features and the head -- replaces
+ * PtEmbedMultiviewStereoV2.feat_decode / uv_decode (lib/models/POEM.py:167-211, HRNet branch) built from
+ * lib/models/bricks/conv.py ConvBlocks.  The Python mirror (poem_v2_amd/decode.py) chains them exactly as the
+ * reference methods do.
+ * poem_pack_conv3x3: OIHW (cout,cin,3,3) weights -> MFMA fragment image (poem_conv3x3_packed_bytes bytes); cin % 8 == 0.
+ * poem_conv3x3: in (views,cin,h+2,w+2) with a zero border; y = conv(in)*scale[c] + shift[c] (conv bias and eval-mode
+ *   BatchNorm folded by the caller; arrays padded to a multiple of 32 channels), optional ReLU, optional lateral add
+ *   residual (views,cout,h/stride,w/stride) AFTER the activation (POEM.py:185-186); element (n,c,y,x) is written to
+ *   out[n*out_view_stride + c*out_ch_stride + y*out_row_stride + x + out_offset] so that the result can land inside
+ *   the next conv's zero-bordered input.  stride 1|2 (padding 1), (h/stride)*(w/stride) % 32 == 0.
+ * poem_upsample2_concat_pad: out (views, ca+cb, h+2*pad, w+2*pad) = [bilinear x2 (align_corners=False) of
+ *   a (views,ca,h/2,w/2) | b (views,cb,h,w)] with a zero border of pad (0|1) pixels (F.interpolate + torch.cat,
+ *   POEM.py:189,203-204); ca or cb may be 0.
+ * poem_pool_conv1x1_sigmoid: x (views,c,h,w) -> max_pool2d(2,2) -> 1x1 conv (j x c, bias) -> sigmoid ->
+ *   heatmaps (views,j,h/2,w/2)  (POEM.py:206-207); c <= 64, j <= 32. */
+size_t poem_conv3x3_packed_bytes(int cout, int cin);
+int poem_pack_conv3x3(const float* w_oihw, int cout, int cin, void* packed, void* stream);
+int poem_conv3x3(const float* in_padded, const void* w_packed, const float* scale, const float* shift,
+                 const float* residual, float* out, int views, int cin, int cout, int h, int w, int stride, int relu,
+                 int64_t out_view_stride, int out_ch_stride, int out_row_stride, int out_offset, void* stream);
+int poem_upsample2_concat_pad(const float* a, int ca, const float* b, int cb, float* out, int views, int h, int w, int pad,
+                              void* stream);
+int poem_pool_conv1x1_sigmoid(const float* x, const float* w, const float* bias, float* heatmaps, int views, int c, int j,
+                              int h, int w_, void* stream);
 /* Device-side evaluation metrics (replace the host loops of lib/metrics/pa_eval.py:45-83,104-124 and
  * lib/metrics/pck.py:36-96).
  * poem_pa_epe: pred, gt (B,P,3) -> out (B,2) = per-sample (Procrustes-aligned mean distance, plain mean distance);

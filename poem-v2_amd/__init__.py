@@ -5,6 +5,6 @@ Public surface mirrors the reference's plugin API for this path: ``HEAD`` / ``TR
 registers them, as ``import lib.models`` does upstream)."""
 from .config import CN  # noqa: F401
 from .builder import HEAD, TRANSFORMER, Registry, build_from_cfg, build_head, build_transformer  # noqa: F401
-from . import weights, inputs, hip, configs, triangulation  # noqa: F401
+from . import weights, inputs, hip, configs, triangulation, decode  # noqa: F401
 from .transformer import PtEmbedTRv4  # noqa: F401
 from .head import POEM_Generalized_Head  # noqa: F401

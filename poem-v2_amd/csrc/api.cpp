@@ -50,6 +50,15 @@ hipError_t poem_launch_pck_accumulate(const float* pred, const float* gt, int B,
                                       unsigned int* counts, double* sum, unsigned int* n, float* dist_out, hipStream_t s);
 hipError_t poem_launch_heatmap_uv(const float* hmap, float* uv, int maps, int hh, int hw, float img_w, float img_h,
                                   hipStream_t s);
+size_t poem_conv3x3_packed_floats(int Cout, int Cin);
+hipError_t poem_launch_pack_conv3x3(const float* w, int Cout, int Cin, void* out, hipStream_t s);
+hipError_t poem_launch_conv3x3(const float* in, const void* wp, const float* scale, const float* shift, const float* res,
+                               float* out, int views, int Cin, int Cout, int H, int W, int stride, int relu, long out_ns,
+                               int out_cs, int out_rs, int out_off, hipStream_t s);
+hipError_t poem_launch_upcat_pad(const float* a, int Ca, const float* b, int Cb, float* out, int views, int H, int W,
+                                 int pad, hipStream_t s);
+hipError_t poem_launch_pool_head(const float* x, const float* w, const float* bias, float* hmap, int views, int C, int J,
+                                 int H, int W, hipStream_t s);
 hipError_t poem_launch_gemm_split(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
                                   float* Y, int ldy, int M, int N, int K, int act, int act_split, int act2, hipStream_t s);
 hipError_t poem_launch_prep_xyz(const float* ref_joints, const float* bps, const float* tmpl, float* centre,
@@ -765,6 +774,44 @@ int poem_heatmap_uv(const float* heatmaps, float* uv, int views, int njoints, in
                     void* stream) {
   if (!heatmaps || !uv || views <= 0 || njoints <= 0 || hm_h <= 0 || hm_w <= 0) return POEM_E_ARG;
   HIPCHK(poem_launch_heatmap_uv(heatmaps, uv, views * njoints, hm_h, hm_w, img_w, img_h, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+size_t poem_conv3x3_packed_bytes(int cout, int cin) {
+  if (cout <= 0 || cin <= 0 || cin % 8) return 0;
+  return poem_conv3x3_packed_floats(cout, cin) * sizeof(float);
+}
+
+int poem_pack_conv3x3(const float* w_oihw, int cout, int cin, void* packed, void* stream) {
+  if (!w_oihw || !packed || cout <= 0 || cin <= 0 || cin % 8) return POEM_E_ARG;
+  HIPCHK(poem_launch_pack_conv3x3(w_oihw, cout, cin, packed, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_conv3x3(const float* in_padded, const void* w_packed, const float* scale, const float* shift,
+                 const float* residual, float* out, int views, int cin, int cout, int h, int w, int stride, int relu,
+                 int64_t out_view_stride, int out_ch_stride, int out_row_stride, int out_offset, void* stream) {
+  if (!in_padded || !w_packed || !scale || !shift || !out || views <= 0 || cin <= 0 || cin % 8 || cout <= 0) return POEM_E_ARG;
+  if ((stride != 1 && stride != 2) || h <= 0 || w <= 0 || h % stride || w % stride || ((h / stride) * (w / stride)) % 32)
+    return POEM_E_UNSUPPORTED;
+  HIPCHK(poem_launch_conv3x3(in_padded, w_packed, scale, shift, residual, out, views, cin, cout, h, w, stride, relu,
+                             (long)out_view_stride, out_ch_stride, out_row_stride, out_offset, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_upsample2_concat_pad(const float* a, int ca, const float* b, int cb, float* out, int views, int h, int w, int pad,
+                              void* stream) {
+  if (!out || views <= 0 || ca < 0 || cb < 0 || ca + cb <= 0 || (ca && !a) || (cb && !b) || h <= 0 || w <= 0) return POEM_E_ARG;
+  if (pad < 0 || pad > 1 || (ca && (h % 2 || w % 2))) return POEM_E_UNSUPPORTED;
+  HIPCHK(poem_launch_upcat_pad(a, ca, b, cb, out, views, h, w, pad, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_pool_conv1x1_sigmoid(const float* x, const float* w, const float* bias, float* heatmaps, int views, int c, int j,
+                              int h, int w_, void* stream) {
+  if (!x || !w || !bias || !heatmaps || views <= 0 || c <= 0 || j <= 0) return POEM_E_ARG;
+  if (c > 64 || j > 32 || h % 2 || w_ % 2) return POEM_E_UNSUPPORTED;
+  HIPCHK(poem_launch_pool_head(x, w, bias, heatmaps, views, c, j, h, w_, (hipStream_t)stream));
   return POEM_OK;
 }
 

@@ -1,0 +1,245 @@
+// Row N1 of the scope table: the convolutional glue between the backbone's multi-level features and the head
+// (lib/models/POEM.py:167-222 upstream, HRNet branch) --
+//   feat_decode : three stride-2 ConvBlocks (3x3 conv + BatchNorm(eval) + ReLU) with lateral adds, bilinear x2, 1x1 conv
+//   uv_decode   : three [bilinear x2 -> concat -> 3x3 ConvBlock] stages, 2x2 max-pool, 1x1 conv + sigmoid (21 heat maps)
+// as four kernels:
+//   upcat_pad_kernel      bilinear x2 of A (align_corners=False) | channel-concat with B | zero border of `pad` pixels
+//   conv3x3_kernel        implicit GEMM on the fp32 matrix cores over a zero-bordered input (no boundary predicates:
+//                         every tap is base + scalar offset), epilogue = per-channel affine (conv bias and BatchNorm
+//                         folded on the host), ReLU, lateral add; output strides let it write straight into the next
+//                         conv's bordered input
+//   pool_head_kernel      2x2 max-pool + 1x1 conv (40 -> 21) + sigmoid
+// (the 1x1 feat_in conv reuses conv1x1_kernel of sample.hip; the heat-map read-out is poem_heatmap_uv of dlt.hip).
+//
+// conv3x3 as a GEMM: D[co][pixel] = sum_{tap, ci} W[co][ci][tap] * X[ci][pixel + tap offset].
+//   A = packed weights  WP[((cot * 9 + tap) * Cin/8 + cc) * 64 + lane] = float4( W[32cot + (lane&31)][8cc + 4(lane>>5) + 0..3][tap] )
+//       (one coalesced 1 KiB wave load = four k-steps of a 32-channel tile; rows >= Cout are zero)
+//   B = the input itself: lane = output pixel (32 consecutive pixels of the raster), k-step t of chunk cc reads channel
+//       8cc + 4(lane>>5) + t at that pixel's tap position -- a dword load whose lane offset is computed once per tile
+//       and whose (chunk, tap, k-step) part is a scalar offset of the buffer descriptor.
+//   D layout: lane = pixel, registers = output channels -> the epilogue's stores are 128-byte row segments.
+// A wave owns CT channel tiles x PT pixel tiles; waves are independent (no LDS, no barriers).
+#include "common.h"
+#include <algorithm>
+
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Cout, int Cin, float4* __restrict__ out, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = i & 63;
+  int f = i >> 6;
+  const int cc = f % (Cin / 8);
+  f /= (Cin / 8);
+  const int tap = f % 9, cot = f / 9;
+  const int co = cot * 32 + (lane & 31), ci = 8 * cc + 4 * (lane >> 5);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (co < Cout) {
+    const float* p = w + ((size_t)co * Cin + ci) * 9 + tap;
+    v = make_float4(p[0], p[9], p[18], p[27]);
+  }
+  out[i] = v;
+}
+
+extern "C" size_t poem_conv3x3_packed_floats(int Cout, int Cin) { return (size_t)((Cout + 31) / 32) * 9 * (Cin / 8) * 64 * 4; }
+
+extern "C" hipError_t poem_launch_pack_conv3x3(const float* w, int Cout, int Cin, void* out, hipStream_t s) {
+  if (Cin % 8) return hipErrorInvalidValue;
+  const int total = ((Cout + 31) / 32) * 9 * (Cin / 8) * 64;
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, Cout, Cin, (float4*)out, total);
+  return hipGetLastError();
+}
+
+struct Conv3Args {
+  const float* in;      // (views, Cin, H+2, W+2) zero-bordered
+  const float4* wp;     // packed weights
+  const float* scale;   // (cot*32) per-channel multiplier   (BatchNorm folded; 1 without norm)
+  const float* shift;   // (cot*32) per-channel offset       (conv bias + BatchNorm folded)
+  const float* res;     // optional lateral input (views, Cout, Ho, Wo), added after the activation
+  float* out;           // element (n, co, y, x) at out[n * out_ns + co * out_cs + y * out_rs + x + out_off]
+  int Cin, Cout, H, W, stride, relu;
+  long out_ns;
+  int out_cs, out_rs, out_off;
+  int views;
+};
+
+template <int CT, int PT>
+__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args A) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  const int Ho = A.H / A.stride, Wo = A.W / A.stride, Hp = A.H + 2, Wp = A.W + 2;
+  const int ptiles = Ho * Wo / 32, pgroups = ptiles / PT;
+  const int cogroups = ((A.Cout + 31) / 32) / CT;
+  const long item = (long)blockIdx.x * 4 + wv;
+  if (item >= (long)A.views * cogroups * pgroups) return;
+  const int pg = (int)(item % pgroups);
+  const int cg = (int)((item / pgroups) % cogroups);
+  const int n = (int)(item / ((long)pgroups * cogroups));
+  const int plane = Hp * Wp, KC = A.Cin / 8;
+  const __amdgpu_buffer_rsrc_t xrs = frag_rsrc(A.in + (size_t)n * A.Cin * plane, (unsigned)((size_t)A.Cin * plane * 4));
+  const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(A.wp, 0xffffffffu);
+
+  int xoff[PT];      // lane byte offset: channel 4h of the pixel's top-left tap
+  int py[PT], px[PT];
+#pragma unroll
+  for (int p = 0; p < PT; ++p) {
+    const int pix = (pg * PT + p) * 32 + j;
+    py[p] = pix / Wo;
+    px[p] = pix % Wo;
+    xoff[p] = (4 * h * plane + py[p] * A.stride * Wp + px[p] * A.stride) * 4;
+  }
+  f32x16 acc[CT][PT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int p = 0; p < PT; ++p) acc[c][p] = zero16();
+  const int wbase = (cg * CT) * 9 * KC * 1024;        // bytes
+  for (int tap = 0; tap < 9; ++tap) {
+    const int tapoff = ((tap / 3) * Wp + (tap % 3)) * 4;
+    for (int cc = 0; cc < KC; ++cc) {
+      float4 a[CT];
+      float b[PT][4];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) a[c] = frag_load(wrs, lane * 16, wbase + ((c * 9 + tap) * KC + cc) * 1024);
+      const int soff = cc * 8 * plane * 4 + tapoff;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+          b[p][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[p], soff + t * plane * 4, 0));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+          for (int p = 0; p < PT; ++p)
+            acc[c][p] = mfma32((&a[c].x)[t], b[p][t], acc[c][p]);
+    }
+  }
+  // epilogue: affine (conv bias + BatchNorm), ReLU, lateral add; lane = pixel, register e = channel 8(e>>2) + 4h + (e&3)
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const int cbase = (cg * CT + c) * 32 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 sc = *reinterpret_cast<const float4*>(A.scale + cbase + 8 * g);
+      const float4 sh = *reinterpret_cast<const float4*>(A.shift + cbase + 8 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = cbase + 8 * g + e;
+        if (co >= A.Cout) continue;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+          float v = fmaf(acc[c][p][4 * g + e], (&sc.x)[e], (&sh.x)[e]);
+          if (A.relu) v = fmaxf(v, 0.f);
+          if (A.res) v += A.res[((size_t)n * A.Cout + co) * (Ho * Wo) + py[p] * Wo + px[p]];
+          A.out[(size_t)n * A.out_ns + (size_t)co * A.out_cs + py[p] * A.out_rs + px[p] + A.out_off] = v;
+        }
+      }
+    }
+  }
+}
+
+// in (views, Cin, H+2, W+2) zero-bordered; out element strides as in Conv3Args.  stride 1 or 2, H, W even,
+// (H/stride)*(W/stride) % 32 == 0, Cin % 8 == 0.
+extern "C" hipError_t poem_launch_conv3x3(const float* in, const void* wp, const float* scale, const float* shift,
+                                          const float* res, float* out, int views, int Cin, int Cout, int H, int W,
+                                          int stride, int relu, long out_ns, int out_cs, int out_rs, int out_off,
+                                          hipStream_t s) {
+  if (Cin % 8 || (stride != 1 && stride != 2) || H % stride || W % stride) return hipErrorInvalidValue;
+  const int Ho = H / stride, Wo = W / stride;
+  if ((Ho * Wo) % 32) return hipErrorInvalidValue;
+  if ((size_t)Cin * (H + 2) * (W + 2) * 4 >= (1ull << 31)) return hipErrorInvalidValue;
+  Conv3Args a{in, (const float4*)wp, scale, shift, res, out, Cin, Cout, H, W, stride, relu, out_ns, out_cs, out_rs, out_off, views};
+  const int cot = (Cout + 31) / 32, ptiles = Ho * Wo / 32;
+  const int pt = (ptiles % 2 == 0) ? 2 : 1;
+  const int ct = (cot % 5 == 0) ? 5 : (cot % 3 == 0) ? 3 : (cot % 2 == 0) ? 2 : 1;
+  const long items = (long)views * (cot / ct) * (ptiles / pt);
+  const dim3 grid((unsigned)((items + 3) / 4)), block(256);
+#define POEM_CONV(CTV, PTV) hipLaunchKernelGGL((conv3x3_kernel<CTV, PTV>), grid, block, 0, s, a)
+  if (pt == 2) {
+    if (ct == 5) POEM_CONV(5, 2); else if (ct == 3) POEM_CONV(3, 2); else if (ct == 2) POEM_CONV(2, 2); else POEM_CONV(1, 2);
+  } else {
+    if (ct == 5) POEM_CONV(5, 1); else if (ct == 3) POEM_CONV(3, 1); else if (ct == 2) POEM_CONV(2, 1); else POEM_CONV(1, 1);
+  }
+#undef POEM_CONV
+  return hipGetLastError();
+}
+
+// out (views, Ca + Cb, H + 2 pad, W + 2 pad): channels [0, Ca) = bilinear x2 (align_corners=False) of a (views, Ca, H/2, W/2),
+// channels [Ca, Ca + Cb) = b (views, Cb, H, W), border = 0.  Ca or Cb may be 0 (pure upsample / pure pad).
+__global__ void upcat_pad_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb,
+                                 float* __restrict__ out, int H, int W, int pad, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Wp = W + 2 * pad, Hp = H + 2 * pad, C = Ca + Cb;
+  const int xp = (int)(i % Wp);
+  long t = i / Wp;
+  const int yp = (int)(t % Hp);
+  t /= Hp;
+  const int c = (int)(t % C);
+  const long n = t / C;
+  const int x = xp - pad, y = yp - pad;
+  float v = 0.f;
+  if (x >= 0 && x < W && y >= 0 && y < H) {
+    if (c < Ca) {
+      // F.interpolate(scale_factor=2, mode='bilinear', align_corners=False): src = (dst + 0.5) / 2 - 0.5, clamped at 0
+      const int h2 = H / 2, w2 = W / 2;
+      const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+      const int y0 = (int)sy, x0 = (int)sx;
+      const int y1 = min(y0 + 1, h2 - 1), x1 = min(x0 + 1, w2 - 1);
+      const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+      const float* p = a + ((size_t)n * Ca + c) * h2 * w2;
+      v = hy * (hx * p[y0 * w2 + x0] + lx * p[y0 * w2 + x1]) + ly * (hx * p[y1 * w2 + x0] + lx * p[y1 * w2 + x1]);
+    } else {
+      v = b[(((size_t)n * Cb + (c - Ca)) * H + y) * W + x];
+    }
+  }
+  out[i] = v;
+}
+
+extern "C" hipError_t poem_launch_upcat_pad(const float* a, int Ca, const float* b, int Cb, float* out, int views, int H,
+                                            int W, int pad, hipStream_t s) {
+  if ((Ca && (H % 2 || W % 2)) || pad < 0 || pad > 1 || Ca + Cb <= 0) return hipErrorInvalidValue;
+  const long total = (long)views * (Ca + Cb) * (H + 2 * pad) * (W + 2 * pad);
+  hipLaunchKernelGGL(upcat_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, Ca, b, Cb, out, H, W, pad, total);
+  return hipGetLastError();
+}
+
+// x (views, C, H, W) -> 2x2 max-pool -> 1x1 conv (J x C, bias) -> sigmoid -> hmap (views, J, H/2, W/2).
+// One thread per pooled pixel; weights (J*C + J floats) staged in LDS.  C <= 64, J <= 32.
+__global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ hmap, int C,
+                                                        int J, int H, int W, long total) {
+  __shared__ float ws[32 * 64 + 32];
+  for (int i = threadIdx.x; i < J * C; i += blockDim.x) ws[i] = w[i];
+  for (int i = threadIdx.x; i < J; i += blockDim.x) ws[32 * 64 + i] = bias[i];
+  __syncthreads();
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int h2 = H / 2, w2 = W / 2;
+  const int xo = (int)(i % w2), yo = (int)((i / w2) % h2);
+  const long n = i / ((long)w2 * h2);
+  float acc[32];
+#pragma unroll
+  for (int jn = 0; jn < 32; ++jn) acc[jn] = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* p = x + (((size_t)n * C + c) * H + 2 * yo) * W + 2 * xo;
+    const float2 r0 = *reinterpret_cast<const float2*>(p), r1 = *reinterpret_cast<const float2*>(p + W);
+    const float pooled = fmaxf(fmaxf(r0.x, r0.y), fmaxf(r1.x, r1.y));
+#pragma unroll
+    for (int jn = 0; jn < 32; ++jn)
+      if (jn < J) acc[jn] = fmaf(pooled, ws[jn * C + c], acc[jn]);
+  }
+#pragma unroll
+  for (int jn = 0; jn < 32; ++jn)
+    if (jn < J) {
+      const float v = acc[jn] + ws[32 * 64 + jn];
+      hmap[(((size_t)n * J + jn) * h2 + yo) * w2 + xo] = 1.0f / (1.0f + expf(-v));
+    }
+}
+
+extern "C" hipError_t poem_launch_pool_head(const float* x, const float* w, const float* bias, float* hmap, int views, int C,
+                                            int J, int H, int W, hipStream_t s) {
+  if (C > 64 || J > 32 || H % 2 || W % 2) return hipErrorInvalidValue;
+  const long total = (long)views * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(pool_head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, hmap, C, J, H, W, total);
+  return hipGetLastError();
+}

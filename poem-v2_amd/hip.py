@@ -63,6 +63,11 @@ SIGNATURES = {
     "poem_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "poem_triangulate_dlt": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "poem_heatmap_uv": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "poem_conv3x3_packed_bytes": (_sz, [_i, _i]),
+    "poem_pack_conv3x3": (_i, [_vp, _i, _i, _vp, _vp]),
+    "poem_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp]),
+    "poem_upsample2_concat_pad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "poem_pool_conv1x1_sigmoid": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_pa_epe": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "poem_pck_accumulate": (_i, [_vp, _vp, _i, _i, ctypes.c_double, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp]),
     "poem_knn": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -297,8 +297,45 @@ def run_evalcfg():
     print("evalcfg:", len(out), "settings")
 
 
+def run_decode():
+    """Golden vectors of the reference model's own feat_decode / uv_decode / heatmap_stage (lib/models/POEM.py:167-222,
+    HRNet branch): the full reference model is built under the harness (random HRNet, never run), the modules of this
+    stage take the seeded weights of oracle/decode_oracle.py::seeded_decoder_state, the inputs are its
+    synthetic_mlvl_feats.  Stored: strided subsets (the fixture stays small) + the full (BN,21,2) pixel coordinates."""
+    import yaml
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import decode_oracle as do
+    CN, _ = rh.setup()
+    with open(os.path.join(rh.REF_ROOT, "config/release/train_medium.yaml")) as f:
+        y = yaml.safe_load(f)
+    from lib.utils import builder
+    cfg = CN(y)
+    model = builder.build_model(cfg.MODEL, data_preset=cfg.DATA_PRESET, train=cfg.TRAIN)
+    model.eval()
+    seed, views = 3, 3
+    sd = do.seeded_decoder_state(seed)
+    ref_sd = model.state_dict()
+    for k, v in sd.items():
+        assert k in ref_sd and tuple(ref_sd[k].shape) == tuple(v.shape), f"key/shape mismatch: {k}"
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    feats = do.synthetic_mlvl_feats(views, seed)
+    with torch.no_grad():
+        mlvl = model.feat_decode([f.clone() for f in feats], "HRNet")
+        hmap, _ = model.uv_decode([f.clone() for f in feats])
+        uv = model.heatmap_stage([f.clone() for f in feats], 256, 256)
+    os.chdir(ROOT)
+    meta = dict(seed=seed, views=views, note="weights = decode_oracle.seeded_decoder_state(seed); inputs = "
+                "decode_oracle.synthetic_mlvl_feats(views, seed); mlvl_feat stored [:, ::4], uv_hmap [:, ::3]")
+    rec = {"mlvl_feat_s4": mlvl[:, ::4].numpy(), "uv_hmap_s3": hmap[:, ::3].numpy(), "uv": uv.numpy(),
+           "mlvl_feat_absmax": np.float32(mlvl.abs().max().item()),
+           "meta": np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)}
+    np.savez_compressed(os.path.join(HERE, "decode.npz"), **rec)
+    print("decode:", {k: getattr(v, "shape", None) for k, v in rec.items() if k != "meta"})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or list(CASES) + ["mepe", "evalcfg", "dlt", "metrics"]
+    which = sys.argv[1:] or list(CASES) + ["mepe", "evalcfg", "dlt", "metrics", "decode"]
     torch.set_num_threads(8)
     for n in which:
         if n == "mepe":
@@ -309,5 +346,7 @@ if __name__ == "__main__":
             run_dlt()
         elif n == "metrics":
             run_metrics()
+        elif n == "decode":
+            run_decode()
         else:
             run_case(n, CASES[n])

@@ -1,0 +1,138 @@
+"""Convolutional glue in front of the head (feat_decode / uv_decode / heatmap_stage): oracle pinned to the
+reference model's own outputs (CPU), HIP kernels vs both (GPU, through the C ABI)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import decode_oracle as do
+from util import GOLDEN
+
+DEV = "cuda:0"
+
+
+def _md(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+def _golden():
+    z = np.load(os.path.join(GOLDEN, "decode.npz"))
+    return z, json.loads(bytes(z["meta"]).decode())
+
+
+def test_oracle_matches_reference_model_outputs():
+    z, meta = _golden()
+    sd = do.seeded_decoder_state(meta["seed"])
+    feats = do.synthetic_mlvl_feats(meta["views"], meta["seed"])
+    mlvl = do.feat_decode(feats, sd)
+    assert tuple(mlvl.shape) == (meta["views"], 160, 16, 16)
+    assert _md(mlvl[:, ::4], torch.from_numpy(z["mlvl_feat_s4"])) < 1e-5 * float(z["mlvl_feat_absmax"])
+    hm = do.uv_decode(feats, sd)
+    assert tuple(hm.shape) == (meta["views"], 21, 32, 32)
+    assert _md(hm[:, ::3], torch.from_numpy(z["uv_hmap_s3"])) < 1e-6
+    assert _md(do.heatmap_stage(feats, sd, 256, 256), torch.from_numpy(z["uv"])) < 1e-4      # pixels
+
+
+def test_decoder_key_table_matches_what_the_fixture_loaded():
+    ks = do.decoder_key_shapes()
+    assert ks["uv_delayer.0.conv.weight"] == (160, 480, 3, 3) and ks["feat_delayer.2.conv.weight"] == (320, 160, 3, 3)
+    assert ks["feat_in.conv.weight"] == (160, 320, 1, 1) and ks["uv_out.conv.weight"] == (21, 40, 1, 1)
+    import poem_v2_amd as pk
+    assert set(pk.decode.FeatureDecoders.live_keys()) == set(ks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,r,stride,relu,res", [(40, 80, 64, 2, True, True), (480, 160, 16, 1, True, False),
+                                                         (120, 40, 64, 1, True, False), (16, 33, 8, 1, False, False),
+                                                         (160, 320, 16, 2, True, True)])
+def test_conv3x3_operator(cin, cout, r, stride, relu, res):
+    import torch.nn.functional as F
+    import poem_v2_amd as pk
+    from poem_v2_amd import hip
+    g = torch.Generator().manual_seed(cin + cout)
+    views = 2
+    x = torch.randn(views, cin, r, r, generator=g)
+    sd = {"c.conv.weight": torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5),
+          "c.conv.bias": 0.1 * torch.randn(cout, generator=g), "c.norm.weight": 1 + 0.2 * torch.randn(cout, generator=g),
+          "c.norm.bias": 0.1 * torch.randn(cout, generator=g), "c.norm.running_mean": 0.1 * torch.randn(cout, generator=g),
+          "c.norm.running_var": 0.5 + torch.rand(cout, generator=g)}
+    ro = r // stride
+    lateral = torch.randn(views, cout, ro, ro, generator=g) if res else None
+    ref = do.conv_block(x.double(), {k: v.double() for k, v in sd.items()}, "c", stride=stride, relu=relu)
+    if res:
+        ref = ref + lateral.double()
+    conv = pk.decode._Conv3x3(sd, "c", torch.device(DEV))
+    xp = pk.decode.upsample2_concat_pad(None, x.to(DEV), r, r, 1)
+    assert _md(xp[:, :, 1:-1, 1:-1], x) == 0.0 and float(xp[:, :, 0].abs().max()) == 0.0
+    # plain output
+    out = torch.empty(views, cout, ro, ro, device=DEV)
+    conv(xp, r, r, stride, out, pk.decode._plain_strides(cout, ro, ro), residual=None if lateral is None else lateral.to(DEV),
+         relu=relu)
+    assert _md(out, ref) < 2e-5
+    # output written into a zero-bordered buffer (the next conv's input)
+    outp = torch.zeros(views, cout, ro + 2, ro + 2, device=DEV)
+    conv(xp, r, r, stride, outp, pk.decode._padded_strides(cout, ro, ro), residual=None if lateral is None else lateral.to(DEV),
+         relu=relu)
+    assert _md(outp[:, :, 1:-1, 1:-1], ref) < 2e-5 and float(outp[:, :, :, 0].abs().max()) == 0.0
+    hip.lib()
+
+
+@pytest.mark.gpu
+def test_upsample_concat_matches_torch():
+    import torch.nn.functional as F
+    import poem_v2_amd as pk
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(2, 24, 8, 8, generator=g), torch.randn(2, 16, 16, 16, generator=g)
+    ref = torch.cat((F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=False), b), dim=1)
+    got = pk.decode.upsample2_concat_pad(a.to(DEV), b.to(DEV), 16, 16, 1)
+    assert _md(got[:, :, 1:-1, 1:-1], ref) < 1e-6
+    got0 = pk.decode.upsample2_concat_pad(a.to(DEV), None, 16, 16, 0)
+    assert _md(got0, ref[:, :24]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_decoders_match_oracle_and_reference_fixture():
+    import poem_v2_amd as pk
+    z, meta = _golden()
+    sd = do.seeded_decoder_state(meta["seed"])
+    feats = do.synthetic_mlvl_feats(meta["views"], meta["seed"])
+    dec = pk.decode.FeatureDecoders(sd, DEV)
+    dfe = [f.to(DEV) for f in feats]
+    mlvl = dec.feat_decode(dfe)
+    scale = float(z["mlvl_feat_absmax"])
+    assert _md(mlvl, do.feat_decode(feats, sd)) < 2e-5 * scale
+    assert _md(mlvl[:, ::4], torch.from_numpy(z["mlvl_feat_s4"])) < 2e-5 * scale
+    hm = dec.uv_decode(dfe)
+    assert _md(hm, do.uv_decode(feats, sd)) < 2e-5          # three chained K <= 4320 contractions in front of a sigmoid
+    assert _md(hm[:, ::3], torch.from_numpy(z["uv_hmap_s3"])) < 2e-5
+    uv = dec.heatmap_stage(dfe, 256, 256)
+    assert _md(uv, torch.from_numpy(z["uv"])) < 5e-4                                         # pixels
+    # the four inputs are not modified (the reference methods do not mutate them either)
+    for a, b in zip(dfe, feats):
+        assert _md(a, b) == 0.0
+
+
+@pytest.mark.gpu
+def test_decoders_feed_the_triangulation():
+    """heat maps -> uv -> ragged DLT: the chained stage in front of the head on one stream."""
+    import poem_v2_amd as pk
+    sd = do.seeded_decoder_state(1)
+    views = [2, 3]
+    feats = [f.to(DEV) for f in do.synthetic_mlvl_feats(sum(views), 1)]
+    dec = pk.decode.FeatureDecoders(sd, DEV)
+    b = pk.inputs.synthetic_batch(views, seed=1)
+    m = b["img_metas"]
+    uv = dec.heatmap_stage(feats, 256, 256)
+    rj = pk.triangulation.triangulate_reference_joints(uv, m["cam_intr"].to(DEV), m["cam_extr"].to(DEV), views)
+    import dlt_oracle as dl
+    ref = dl.triangulate_reference_joints(do.heatmap_stage([f.cpu() for f in feats], sd, 256, 256), m["cam_intr"],
+                                          m["cam_extr"], views)
+    assert torch.isfinite(rj).all() and _md(rj, ref) < 1e-3      # metres; near-degenerate rays amplify the 1e-4 px
+
+
+def test_errors_are_loud_on_cpu_tensors():
+    import poem_v2_amd as pk
+    with pytest.raises(RuntimeError):
+        pk.decode.upsample2_concat_pad(None, torch.zeros(1, 8, 4, 4), 4, 4, 1)
