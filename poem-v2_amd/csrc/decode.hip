@@ -91,28 +91,41 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args A) {
 #pragma unroll
     for (int p = 0; p < PT; ++p) acc[c][p] = zero16();
   const int wbase = (cg * CT) * 9 * KC * 1024;        // bytes
-  for (int tap = 0; tap < 9; ++tap) {
-    const int tapoff = ((tap / 3) * Wp + (tap % 3)) * 4;
-    for (int cc = 0; cc < KC; ++cc) {
-      float4 a[CT];
-      float b[PT][4];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) a[c] = frag_load(wrs, lane * 16, wbase + ((c * 9 + tap) * KC + cc) * 1024);
-      const int soff = cc * 8 * plane * 4 + tapoff;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int p = 0; p < PT; ++p)
-          b[p][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[p], soff + t * plane * 4, 0));
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-          for (int p = 0; p < PT; ++p)
-            acc[c][p] = mfma32((&a[c].x)[t], b[p][t], acc[c][p]);
-    }
+  // Two-stage software pipeline over the 9 * KC (tap, 8-channel chunk) steps with pinned order (sched_barrier): the
+  // operands of step q+1 are in flight while the 4*CT*PT MFMAs of step q issue.
+  const int total = 9 * KC;
+  int tap = 0, cc = 0, q = 0;
+  float4 a0[CT], a1[CT];
+  float b0[PT][4], b1[PT][4];
+#define POEM_CLOAD(A, B)                                                                                          \
+  {                                                                                                               \
+    const int woff_ = wbase + (tap * KC + cc) * 1024;                                                             \
+    const int soff_ = cc * 8 * plane * 4 + ((tap / 3) * Wp + (tap % 3)) * 4;                                      \
+    _Pragma("unroll") for (int c = 0; c < CT; ++c) A[c] = frag_load(wrs, lane * 16, woff_ + c * 9 * KC * 1024);   \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                 \
+      _Pragma("unroll") for (int p = 0; p < PT; ++p)                                                              \
+        B[p][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[p], soff_ + t * plane * 4, 0)); \
+    if (q + 1 < total) { ++q; if (++cc == KC) { cc = 0; ++tap; } }   /* saturates on the last step */              \
   }
+#define POEM_CMMA(A, B)                                                                                           \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                   \
+    _Pragma("unroll") for (int c = 0; c < CT; ++c)                                                                \
+      _Pragma("unroll") for (int p = 0; p < PT; ++p) acc[c][p] = mfma32((&A[c].x)[t], B[p][t], acc[c][p]);
+  POEM_CLOAD(a0, b0)
+  int done = 0;
+  for (; done + 1 < total; done += 2) {
+    POEM_CLOAD(a1, b1)
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_CMMA(a0, b0)
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_CLOAD(a0, b0)
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_CMMA(a1, b1)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (done < total) { POEM_CMMA(a0, b0) }   // odd step count: the last step is already in (a0, b0)
+#undef POEM_CLOAD
+#undef POEM_CMMA
   // epilogue: affine (conv bias + BatchNorm), ReLU, lateral add; lane = pixel, register e = channel 8(e>>2) + 4h + (e&3)
 #pragma unroll
   for (int c = 0; c < CT; ++c) {

@@ -79,8 +79,27 @@ def knn_case(B=32, Q=799, NS=4096):
     print(f"knn B={B} Q={Q} NS={Q}: {t*1e3:8.1f} us", flush=True)
 
 
+def decode_case(views=256):
+    """N1 stage at the bench's view count: feat_decode + heatmap_stage (+ eager PyTorch-ROCm of the same restatement)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import decode_oracle as do
+    sd = do.seeded_decoder_state(0)
+    feats = [f.to(dev) for f in do.synthetic_mlvl_feats(views, 0)]
+    dec = pk.decode.FeatureDecoders(sd, dev)
+    t1 = timeit(lambda: dec.feat_decode(feats), 10)
+    t2 = timeit(lambda: dec.heatmap_stage(feats, 256, 256), 10)
+    fl1 = views * 2.0 * (9 * 40 * 80 * 1024 + 9 * 80 * 160 * 256 + 9 * 160 * 320 * 64 + 320 * 160 * 256)
+    fl2 = views * 2.0 * 9 * (480 * 160 * 256 + 240 * 80 * 1024 + 120 * 40 * 4096)
+    print(f"decode views={views}: feat_decode {t1*1e3:8.1f} us ({fl1/t1/1e9:6.1f} TF)  heatmap_stage {t2*1e3:8.1f} us ({fl2/t2/1e9:6.1f} TF)", flush=True)
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    with torch.no_grad():
+        e1 = timeit(lambda: do.feat_decode(feats, sdd), 5)
+        e2 = timeit(lambda: do.uv_decode(feats, sdd), 5)
+    print(f"   PyTorch-ROCm eager (MIOpen): feat_decode {e1*1e3:8.1f} us  uv_decode {e2*1e3:8.1f} us", flush=True)
+
+
 if __name__ == "__main__":
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     which = sys.argv[1:] or ["gemm"]
-    for wname in which:
-        {"gemm": gemm_cases, "vecattn": vecattn_case, "attn": attn_case, "knn": knn_case}[wname]()
+    for w in which:
+        {"gemm": gemm_cases, "vecattn": vecattn_case, "attn": attn_case, "knn": knn_case, "decode": decode_case}[w]()
