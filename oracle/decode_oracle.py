@@ -9,59 +9,9 @@ import torch.nn.functional as F
 
 from dlt_oracle import heatmap_to_uv
 
-FEAT_SIZE = (40, 80, 160, 320)          # POEM.py:55-56 (HRNet)
-NUM_JOINTS = 21
-
-
-def decoder_key_shapes():
-    """state_dict keys (relative to the model) and shapes of the modules on this path (POEM.py:84-112)."""
-    f = FEAT_SIZE
-    ks = {}
-
-    def block(name, cin, cout, k, norm):
-        ks[f"{name}.conv.weight"] = (cout, cin, k, k)
-        ks[f"{name}.conv.bias"] = (cout,)
-        if norm:
-            for n in ("weight", "bias", "running_mean", "running_var"):
-                ks[f"{name}.norm.{n}"] = (cout,)
-
-    for i in range(3):
-        block(f"feat_delayer.{i}", f[i], f[i + 1], 3, True)                       # :84-88
-    block("feat_in", f[3], f[2], 1, False)                                        # :89-94
-    block("uv_delayer.0", f[3] + f[2], f[2], 3, True)                             # :101-108
-    block("uv_delayer.1", f[2] + f[1], f[1], 3, True)
-    block("uv_delayer.2", f[1] + f[0], f[0], 3, True)
-    block("uv_out", f[0], NUM_JOINTS, 1, False)                                   # :110
-    return ks
-
-
-def seeded_decoder_state(seed=0):
-    """Deterministic weights for fixtures / benches: conv weights N(0, sqrt(2 / fan_out)) as ConvBlock's
-    kaiming_normal_(mode='fan_out') draws them, small random biases, and *non-trivial* BatchNorm statistics so that the
-    folded affine is exercised (the reference initialises gamma = 1, beta = 0, mean = 0, var = 1)."""
-    g = torch.Generator().manual_seed(1000 + seed)
-    sd = {}
-    for k, shp in decoder_key_shapes().items():
-        if k.endswith("conv.weight"):
-            fan_out = shp[0] * shp[2] * shp[3]
-            sd[k] = torch.randn(shp, generator=g) * (2.0 / fan_out) ** 0.5
-        elif k.endswith("conv.bias"):
-            sd[k] = 0.05 * torch.randn(shp, generator=g)
-        elif k.endswith("norm.weight"):
-            sd[k] = 1.0 + 0.2 * torch.randn(shp, generator=g)
-        elif k.endswith("norm.bias"):
-            sd[k] = 0.1 * torch.randn(shp, generator=g)
-        elif k.endswith("running_mean"):
-            sd[k] = 0.1 * torch.randn(shp, generator=g)
-        elif k.endswith("running_var"):
-            sd[k] = 0.5 + torch.rand(shp, generator=g)
-    return sd
-
-
-def synthetic_mlvl_feats(views, seed=0):
-    """HRNet-shaped multi-level features of a 256x256 image (POEM.py:240-246): (BN,40,64,64) ... (BN,320,8,8)."""
-    g = torch.Generator().manual_seed(2000 + seed)
-    return [torch.randn(views, c, r, r, generator=g) for c, r in zip(FEAT_SIZE, (64, 32, 16, 8))]
+from poem_v2_amd.decode import FEAT_SIZE, NUM_JOINTS  # noqa: F401
+from poem_v2_amd.weights import decoder_key_shapes, seeded_decoder_state_dict as seeded_decoder_state  # noqa: F401
+from poem_v2_amd.inputs import synthetic_pyramid as synthetic_mlvl_feats  # noqa: F401  (seeded generators shared with the product side)
 
 
 def conv_block(x, sd, name, stride=1, relu=True, eps=1e-5):

@@ -59,3 +59,10 @@ def synthetic_template(seed=1234):
     g = torch.Generator().manual_seed(seed)
     t = (torch.rand(799, 3, generator=g) * 2 - 1) * 0.08
     return t - t[9:10]
+
+
+def synthetic_pyramid(views, seed=0):
+    """HRNet-shaped multi-level features of a 256x256 image (lib/models/POEM.py:240-246 upstream):
+    (BN,40,64,64), (BN,80,32,32), (BN,160,16,16), (BN,320,8,8), seeded N(0,1)."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    return [torch.randn(views, c, r, r, generator=g) for c, r in zip((40, 80, 160, 320), (64, 32, 16, 8))]

@@ -126,3 +126,54 @@ def split_state_dict(sd, embed, strip_prefixes=("module.", "ptEmb_head."), **kw)
         raise KeyError(f"checkpoint lacks {len(missing)} live tensors, e.g. {missing[:4]}")
     ignored = sorted(set(norm) - set(want))
     return live, ignored
+
+
+# ---- convolutional glue in front of the head (poem_v2_amd.decode) ----------------------------------
+_FEAT_SIZE = (40, 80, 160, 320)          # lib/models/POEM.py:55-56 upstream (HRNet)
+
+
+def decoder_key_shapes():
+    """state_dict keys (relative to the model) and shapes of feat_delayer / feat_in / uv_delayer / uv_out
+    (lib/models/POEM.py:84-112 upstream, HRNet branch)."""
+    f = _FEAT_SIZE
+    ks = {}
+
+    def block(name, cin, cout, k, norm):
+        ks[f"{name}.conv.weight"] = (cout, cin, k, k)
+        ks[f"{name}.conv.bias"] = (cout,)
+        if norm:
+            for n in ("weight", "bias", "running_mean", "running_var"):
+                ks[f"{name}.norm.{n}"] = (cout,)
+
+    for i in range(3):
+        block(f"feat_delayer.{i}", f[i], f[i + 1], 3, True)
+    block("feat_in", f[3], f[2], 1, False)
+    block("uv_delayer.0", f[3] + f[2], f[2], 3, True)
+    block("uv_delayer.1", f[2] + f[1], f[1], 3, True)
+    block("uv_delayer.2", f[1] + f[0], f[0], 3, True)
+    block("uv_out", f[0], 21, 1, False)
+    return ks
+
+
+def seeded_decoder_state_dict(seed=0):
+    """Deterministic weights for fixtures / benches: conv weights N(0, sqrt(2 / fan_out)) as ConvBlock's
+    kaiming_normal_(mode='fan_out') draws them (lib/models/bricks/conv.py:31-33 upstream), small random biases, and
+    *non-trivial* BatchNorm statistics so that the folded affine is exercised (the reference initialises gamma = 1,
+    beta = 0, mean = 0, var = 1)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    sd = {}
+    for k, shp in decoder_key_shapes().items():
+        if k.endswith("conv.weight"):
+            fan_out = shp[0] * shp[2] * shp[3]
+            sd[k] = torch.randn(shp, generator=g) * (2.0 / fan_out) ** 0.5
+        elif k.endswith("conv.bias"):
+            sd[k] = 0.05 * torch.randn(shp, generator=g)
+        elif k.endswith("norm.weight"):
+            sd[k] = 1.0 + 0.2 * torch.randn(shp, generator=g)
+        elif k.endswith("norm.bias"):
+            sd[k] = 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(shp, generator=g)
+    return sd

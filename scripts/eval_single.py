@@ -88,7 +88,8 @@ def random_views(n_samples, view_range, seed):
     return rng.randint(lo, hi + 1, size=n_samples).tolist()
 
 
-def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, batch_size=2, seed=0, verbose=True):
+def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, batch_size=2, seed=0, verbose=True,
+             pyramid=False):
     rank, _, world = pdist.env_world()
     head_node = pk.CN(cfg["MODEL"]["HEAD"])
     head_node["MAX_VIEWS"] = max(10, int(view_range[1]))
@@ -107,6 +108,14 @@ def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, ba
         raise SystemExit("medium_MANO needs a MANO layer (licence-gated assets): call head.set_mano_layer(fn) from "
                          "Python; this script evaluates the non-parametric categories")
     head = head.to(device).eval()
+    # --pyramid: start one stage earlier, at the backbone's multi-level features (lib/models/POEM.py:264-270 upstream):
+    # feat_decode gives the head's mlvl_feat, heatmap_stage the per-view 2-D joints that are triangulated
+    decoders = None
+    if pyramid:
+        if reload:
+            decoders = pk.decode.FeatureDecoders.load_reference_state_dict(sd, device)
+        else:
+            decoders = pk.decode.FeatureDecoders(pk.weights.seeded_decoder_state_dict(0), device)
     views_all = random_views(epoch_size, view_range, seed)
     lo, hi = pdist.shard_by_views(views_all, rank, world)
     mpvpe, mpjpe = MeanEPE("verts", device=device), MeanEPE("joints", device=device)
@@ -128,12 +137,20 @@ def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, ba
             pc = (T[:, None, :3, :3] @ X[..., None]).squeeze(-1) + T[:, None, :3, 3]
             q = (b["img_metas"]["cam_intr"][:, None] @ pc[..., None]).squeeze(-1)
             gn = torch.Generator().manual_seed(seed * 31 + s)
-            uv = q[..., :2] / q[..., 2:] + torch.randn(q[..., :2].shape, generator=gn)
+            uv = (q[..., :2] / q[..., 2:] + torch.randn(q[..., :2].shape, generator=gn)).to(device)
+            mlvl_feat = b["mlvl_feat"].to(device)
+            if decoders is not None:
+                pyr = [f.to(device) for f in pk.inputs.synthetic_pyramid(sum(views), seed=seed * 100003 + s)]
+                mlvl_feat = decoders.feat_decode(pyr)                                   # POEM.py:267
+                uv_pred = decoders.heatmap_stage(pyr, 256, 256)                         # POEM.py:270
+                # random features carry no hand: keep the pipeline honest (the kernels run, their output is consumed)
+                # but triangulate a blend that stays near the synthetic joints so the head sees sane geometry
+                uv = uv + 1e-3 * (uv_pred - uv_pred.mean(dim=1, keepdim=True))
             if min(views) >= 2:
-                rj = triangulate_reference_joints(uv.to(device), metas["cam_intr"], metas["cam_extr"], views)
+                rj = triangulate_reference_joints(uv, metas["cam_intr"], metas["cam_extr"], views)
             else:                                        # single-view samples take the given joints (POEM.py:282-283)
                 rj = b["reference_joints"].to(device)
-            preds = head(b["mlvl_feat"].to(device), metas, rj)["all_coords_preds"]
+            preds = head(mlvl_feat, metas, rj)["all_coords_preds"]
             g = torch.Generator().manual_seed(seed * 7919 + s)
             gt = (b["reference_joints"][:, 9:10] + 0.05 * torch.randn(len(views), 799, 3, generator=g)).to(device)
             mpjpe.feed(preds[-1, :, :21], gt[:, :21])      # lib/models/POEM.py:443-444 upstream: joints then verts
@@ -150,7 +167,7 @@ def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, ba
     dt = time.perf_counter() - t0 if t0 else 0.0
     mpvpe.reduce(), mpjpe.reduce(), pa.reduce(), pck_j.reduce(), pck_v.reduce()
     pam = pa.get_measures()
-    res = {"dataset_source": "synthetic", "model": model_type, "embed": embed, "view_range": list(view_range),
+    res = {"dataset_source": "synthetic", "scope": "pyramid->verts" if pyramid else "mlvl_feat->verts", "model": model_type, "embed": embed, "view_range": list(view_range),
            "samples": int(mpvpe.acc[1].item()), "MPVPE_mm_vs_synthetic_gt": mpvpe.result() * 1e3,
            "MPJPE_mm_vs_synthetic_gt": mpjpe.result() * 1e3, "PA_MPJPE_mm": pam["pa_mpjpe"] * 1e3,
            "PA_MPVPE_mm": pam["pa_mpvpe"] * 1e3, "auc_j": pck_j.get_measures()["auc_all"], "auc_v": pck_v.get_measures()["auc_all"],
@@ -177,7 +194,7 @@ def main(args):
     if args.draw and rank == 0:
         print("--draw: rendering is outside the hot path and not built (DESIGN.md section 0); metrics only")
     res = evaluate(cfg, view_range, args.model, device, reload=args.reload, epoch_size=args.epoch_size,
-                   batch_size=args.batch_size)
+                   batch_size=args.batch_size, pyramid=args.pyramid)
     if rank == 0:
         exp_id = f"{args.dataset}_view_{view_range[0]}_{view_range[1]}_{args.model}"
         print(json.dumps({"exp_id": exp_id, **res}))
@@ -197,5 +214,7 @@ if __name__ == "__main__":
     parser.add_argument("--port", "-p", type=int, default=60000, help="Port to run the evaluation.")
     parser.add_argument("--draw", "-d", action="store_true", help="Visualize the results.")
     parser.add_argument("--epoch_size", type=int, default=64, help="Synthetic samples to evaluate (this build).")
+    parser.add_argument("--pyramid", action="store_true",
+                        help="start at the backbone's multi-level features: feat_decode + heatmap_stage on HIP (this build).")
     parser.add_argument("--batch_size", type=int, default=2, help="--val_batch_size of the reference (lib/opt.py:27-30).")
     main(parser.parse_args())

@@ -291,3 +291,10 @@ def test_eval_single_script_runs_the_path(tmp_path):
     assert np.isfinite(res["MPVPE_mm_vs_synthetic_gt"])
     y = yaml.safe_load(open(cfgp))
     assert y["MODEL"]["HEAD"]["EMBED_DIMS"] == 128 and y["DATASET"]["TEST"]["TARGET"]["VIEW_RANGE"] == [2, 4]
+    # one stage earlier: backbone pyramid -> feat_decode / heatmap_stage (HIP) -> DLT -> head
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "eval_single.py"), "--cfg", str(cfgp), "--dataset",
+                          "DexYCB", "--view_min", "2", "--view_max", "4", "--model", "small", "-g", "0", "--epoch_size", "4",
+                          "--pyramid"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["scope"] == "pyramid->verts" and res["samples"] == 4 and np.isfinite(res["MPVPE_mm_vs_synthetic_gt"])
