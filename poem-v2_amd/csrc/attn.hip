@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
                                                            const float4* __restrict__ vimg,
                                                            float4* __restrict__ part_o, float2* __restrict__ part_ml,
                                                            int B, int NQ, int NK, int C, int heads, int tpc, float kc2,
-                                                           float lazy_raw, int map) {
+                                                           float lazy_raw, int map, int prio_rot) {
   constexpr int KC = DH / 8;               // K fragments (float4) per key tile
   constexpr int DT = (DH + 31) / 32;       // 32-channel tiles of the output
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
@@ -137,6 +137,16 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
 
     for (int kt = 0; kt < tpc; ++kt) {
       XA_STAMP(0);
+      // Rotate the issue priority among the waves of a SIMD every key tile.  With equal priorities the arbiter serves
+      // the oldest wave first and the waves of a SIMD drift apart by whole items; rotating keeps all waves that stream
+      // the same K/V chunk within about a tile of each other, so one fetch from HBM / L2 serves them all.
+      if (W > 1 && prio_rot) {
+        const int pr = (kt + (wv >> 2)) % W;
+        if (pr == 0) __builtin_amdgcn_s_setprio(0);
+        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+      }
       // ---- S^T = K . Q^T (raw scores)
       f32x16 s = zero16();
 #pragma unroll
@@ -367,11 +377,12 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
   const int waves = B * heads * nqt;
 #define POEM_XATTN(D, WV)                                                                                         \
   hipLaunchKernelGGL((xattn_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, (const float4*)kimg,        \
-                     (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map);         \
+                     (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map, prio_rot); \
   hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
-  int wsel = 0, map = 0;
+  int wsel = 0, map = 1, prio_rot = 0;
 #ifdef POEM_LAB
+  if (const char* e = getenv("POEM_ATTN_PRIO")) prio_rot = atoi(e);
   if (const char* e = getenv("POEM_ATTN_W")) wsel = atoi(e);
   if (const char* e = getenv("POEM_ATTN_MAP")) map = atoi(e);
 #endif

@@ -196,9 +196,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
         for (int g = 0; g < 4; ++g) {
           const float4 bb = *reinterpret_cast<const float4*>(A.bd1 + cbase + 8 * g);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < 4; e += 2) {
             const int i = 4 * g + e;
-            X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = fmaxf(hh[i] + (&bb.x)[e], 0.f);
+            const f32x2 v = f32x2{hh[i], hh[i + 1]} + f32x2{(&bb.x)[e], (&bb.x)[e + 1]};
+            X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = fmaxf(v[0], 0.f);
+            X[((wv * TPW + tp) * 32 + mfma_row(i + 1, h)) * XS + 32 * p + j] = fmaxf(v[1], 0.f);
           }
         }
       }
@@ -275,9 +277,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
 #pragma unroll
       for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; e += 2) {
           const int i = 4 * g + e;
-          X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = fmaxf(acc[tp][p][i] + (&bb.x)[e], 0.f);
+          const f32x2 v = f32x2{acc[tp][p][i], acc[tp][p][i + 1]} + f32x2{(&bb.x)[e], (&bb.x)[e + 1]};
+          X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = fmaxf(v[0], 0.f);
+          X[((wv * TPW + tp) * 32 + mfma_row(i + 1, h)) * XS + 32 * p + j] = fmaxf(v[1], 0.f);
         }
     }
   }

@@ -31,7 +31,8 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const char* ws[] = {"3", "2", "1"};
   const char* ms[] = {"1", "0"};
-  const bool single = argc > 3;     // PMC runs: one variant only (W from argv[3], map from argv[4])
+  if (argc > 5) setenv("POEM_ATTN_PRIO", argv[5], 1);
+  const bool single = argc > 3;     // PMC runs: one variant only (W from argv[3], map from argv[4], prio rotation argv[5])
   if (single) { ws[0] = argv[3]; ms[0] = argc > 4 ? argv[4] : "0"; }
   const int nwv = single ? 1 : (C == 256 ? 3 : 1), nmp = single ? 1 : 2;
   for (int wi = 0; wi < nwv; ++wi) for (int mi = 0; mi < nmp; ++mi) {
