@@ -82,3 +82,57 @@ def test_mean_epe_known_answer():
     s2, n2 = po.mean_epe(pred[:2] * 2, gt[:2])
     assert abs(s1 - float(z["sum1"])) < 1e-7 and abs(s2 - float(z["sum2"])) < 1e-7
     assert abs((s1 + s2) / (n1 + n2) - float(z["avg"])) < 1e-8
+
+
+def test_q2_quirk_block0_takes_the_fixed_anchors_for_both_attentions():
+    """SURVEY Q2 (point_transformers.py:10-32,71-79,129-136): in block 0 every query's 32 "neighbours" are the fixed
+    anchors, for the self AND the cross attention; in the cross attention the anchor ids index the basis-point FEATURE
+    rows while the coordinates are the anchors' template-space positions.  Pinned by the tiny fixture's block-0 taps
+    (test_tiny_stage_taps); here the semantics themselves: only the 32 anchor rows of the basis-point features can
+    influence block 0's vector cross attention."""
+    z, meta = load_golden("tiny")
+    cfg, w, consts, batch = case_setup(meta["spec"])
+    g = torch.Generator().manual_seed(3)
+    B, Q, S, C = 2, 799, meta["spec"]["nsample"], cfg.embed
+    qxyz, qf = torch.randn(B, Q, 3, generator=g) * 0.3, torch.randn(B, Q, C, generator=g)
+    pxyz, pf = torch.randn(B, S, 3, generator=g) * 0.3, torch.randn(B, S, C, generator=g)
+    taps = {}
+    with torch.no_grad():
+        po.decoder_block(w, cfg, 0, qxyz, qf, pxyz, pf, consts, taps=taps)
+    aidx = consts["anchor_idx"].long()
+    assert aidx.numel() == 32 and int(aidx.max()) < 775
+    assert torch.equal(taps["b0.idx_self"], aidx.view(1, 1, 32).expand(B, Q, 32))
+    assert torch.equal(taps["b0.idx_cross"], taps["b0.idx_self"])
+    # perturb a basis-point feature row that is NOT an anchor id: the vector cross attention of block 0 must not see it
+    # (the two BERT cross attentions do attend to every row, so compare f_cross given identical h: use the taps' inputs)
+    free = next(i for i in range(S) if i not in set(aidx.tolist()))
+    p = "transformer.pt_metro_encoder.0."
+    ke = po.linear(pf, w[p + "embedding.weight"], w[p + "embedding.bias"])
+    ke2 = ke.clone(); ke2[:, free] += 1.0
+    ke3 = ke.clone(); ke3[:, int(aidx[5])] += 1.0
+    idx = taps["b0.idx_cross"]
+    nxyz = consts["anchor"].view(1, 1, 32, 3).expand(B, Q, 32, 3)
+    vp = p + "encoder.vec_attn.query_cross_attn."
+    with torch.no_grad():
+        f0 = po.vec_attn_cross(w, vp, qxyz, taps["b0.f_self"], ke, idx, nxyz)
+        f1 = po.vec_attn_cross(w, vp, qxyz, taps["b0.f_self"], ke2, idx, nxyz)
+        f2 = po.vec_attn_cross(w, vp, qxyz, taps["b0.f_self"], ke3, idx, nxyz)
+    assert torch.equal(f0, f1) and not torch.equal(f0, f2)
+
+
+def test_q3_quirk_flat_reshape_runs_of_799():
+    """SURVEY Q3 (pt_metro_transformer.py:139-151): (B,799,C).reshape(-1,799) chunks each sample's 799*C floats into C
+    consecutive runs of 799 -- row r of the Linear(799,1) input is flat[r*799:(r+1)*799], NOT channel r."""
+    B, C = 2, 8
+    feats = torch.arange(B * 799 * C, dtype=torch.float32).view(B, 799, C)
+    wflat = torch.zeros(1, 799); wflat[0, 3] = 1.0            # picks element 3 of every run
+    w = {"p.flat_verts.weight": wflat, "p.flat_verts.bias": torch.zeros(1),
+         "p.mano_linear.weight": torch.zeros(106, C), "p.mano_linear.bias": torch.zeros(106)}
+    w["p.mano_linear.weight"][96, 5] = 1.0                    # beta_0 <- run 5 of each sample
+    w["p.mano_linear.bias"][0:96:6] = 1.0                     # a valid rot6d (x axis, y axis) so the tail stays finite
+    w["p.mano_linear.bias"][4:96:6] = 1.0
+    mano = lambda pose, betas: (torch.zeros(B, 778, 3), torch.zeros(B, 21, 3))   # noqa: E731
+    xyz, pose, betas = po.parametric_tail(w, "p.", feats, torch.zeros(B, 799, 3), mano, C)
+    flat = feats.reshape(B, -1)
+    assert torch.equal(betas[:, 0], flat[:, 5 * 799 + 3])     # run 5, element 3 of the sample's flat storage
+    assert float(flat[0, 5 * 799 + 3]) != float(feats[0, 3, 5])   # ... which is not (vertex 3, channel 5)
