@@ -192,7 +192,7 @@ static int check_config(const poem_config_t* c) {
   if (c->in_channels % 8 || c->nsample % 32 || c->nsample % C) return POEM_E_UNSUPPORTED;
   if (c->heads <= 0 || C % c->heads) return POEM_E_UNSUPPORTED;
   const int dh = C / c->heads;
-  if (!(dh == 8 || dh == 16 || dh == 32 || dh == 64 || dh == 128)) return POEM_E_UNSUPPORTED;
+  if (!(dh == 8 || dh == 16 || dh == 32 || dh == 64 || dh == 128 || dh == 256)) return POEM_E_UNSUPPORTED;
   if (c->nsample > 4096 || c->nquery > 4096 || c->nquery < 33) return POEM_E_UNSUPPORTED;
   if ((c->feat_h * c->feat_w) % 32) return POEM_E_UNSUPPORTED;
   if (c->max_views < 1 || c->max_views > 64 || c->nblocks < 1) return POEM_E_ARG;

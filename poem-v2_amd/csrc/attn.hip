@@ -52,6 +52,50 @@ __device__ __forceinline__ float4 nt_load4(const float4* p) {
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
+// Softmax numerators of one 32-key tile, in place (s: raw scores -> p), with the lazy running stabiliser (see the
+// header): 8 v_max3 + 8 v_pk_fma + 16 v_exp_f32 + 9 packed adds per tile; the rescale branch is wave-uniform and rare.
+template <int DT>
+__device__ __forceinline__ void softmax_tile(f32x16& s, f32x16 (&o)[DT], float& m_ref, float& nbias, float& l_run,
+                                             float kc2, float lazy_raw) {
+#if !(POEM_XA_VARIANT & 1)
+  float mx = max3f(s[0], s[1], s[2]);
+  mx = max3f(mx, s[3], s[4]);
+  mx = max3f(mx, s[5], s[6]);
+  mx = max3f(mx, s[7], s[8]);
+  mx = max3f(mx, s[9], s[10]);
+  mx = max3f(mx, s[11], s[12]);
+  mx = max3f(mx, s[13], s[14]);
+  mx = fmaxf(mx, s[15]);
+  if (__any(mx > m_ref + lazy_raw)) {          // wave-uniform, rare after the first tile
+    const float mf = half_max(mx);             // both halves of a query agree on the new stabiliser
+    const float m_new = (mf > m_ref + lazy_raw) ? mf : m_ref;
+    const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * kc2);   // 1 where unchanged, 0 on the first tile
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    l_run *= alpha;
+    m_ref = m_new;
+    nbias = -m_new * kc2;
+  }
+#endif
+  const f32x2 kc2v = {kc2, kc2}, nbv = {nbias, nbias};
+  f32x2 ps = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) {
+    f32x2 tv = {s[i], s[i + 1]};
+    tv = __builtin_elementwise_fma(tv, kc2v, nbv);
+#if !(POEM_XA_VARIANT & 2)
+    tv[0] = __builtin_amdgcn_exp2f(tv[0]);
+    tv[1] = __builtin_amdgcn_exp2f(tv[1]);
+#endif
+    s[i] = tv[0];
+    s[i + 1] = tv[1];
+    ps += tv;
+  }
+  l_run += ps[0] + ps[1];
+}
+
 #ifdef POEM_LAB   // tools/lab only: per-wave (shader cycles, 100 MHz ticks, items) of the last launch
 __device__ long long xattn_dbg[4096 * 4];
 #endif
@@ -169,43 +213,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
 
       XA_STAMP(1);
       // ---- softmax numerators, lazy stabiliser
-#if !(POEM_XA_VARIANT & 1)
-      float mx = max3f(s[0], s[1], s[2]);
-      mx = max3f(mx, s[3], s[4]);
-      mx = max3f(mx, s[5], s[6]);
-      mx = max3f(mx, s[7], s[8]);
-      mx = max3f(mx, s[9], s[10]);
-      mx = max3f(mx, s[11], s[12]);
-      mx = max3f(mx, s[13], s[14]);
-      mx = fmaxf(mx, s[15]);
-      if (__any(mx > m_ref + lazy_raw)) {          // wave-uniform, rare after the first tile
-        const float mf = half_max(mx);             // both halves of a query agree on the new stabiliser
-        const float m_new = (mf > m_ref + lazy_raw) ? mf : m_ref;
-        const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * kc2);   // 1 where unchanged, 0 on the first tile
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
-        l_run *= alpha;
-        m_ref = m_new;
-        nbias = -m_new * kc2;
-      }
-#endif
-      const f32x2 kc2v = {kc2, kc2}, nbv = {nbias, nbias};
-      f32x2 ps = {0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        f32x2 tv = {s[i], s[i + 1]};
-        tv = __builtin_elementwise_fma(tv, kc2v, nbv);
-#if !(POEM_XA_VARIANT & 2)
-        tv[0] = __builtin_amdgcn_exp2f(tv[0]);
-        tv[1] = __builtin_amdgcn_exp2f(tv[1]);
-#endif
-        s[i] = tv[0];
-        s[i + 1] = tv[1];
-        ps += tv;
-      }
-      l_run += ps[0] + ps[1];
+      softmax_tile<DT>(s, o, m_ref, nbias, l_run, kc2, lazy_raw);
       __builtin_amdgcn_sched_barrier(0);
       XA_STAMP(2);
 
@@ -250,6 +258,114 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
 #ifdef POEM_XA_STAMPS
   if (dbg_on && lane == 0) for (int i = 0; i < 4; ++i) xattn_ph[i] = dbg_ph[i];
 #endif
+}
+
+// Head dims 128 and 256 (POEM-large / -huge): the K and V fragments of a key tile no longer fit the register file next
+// to Q and O, so they stream through a two-slot ring of 8 fragments (32 registers each): a tile is a fixed sequence of
+// NG = DH/64 + DH/64 operand groups -- K channel groups of 64, then V channel-tile pairs -- and while the 32 MFMAs of
+// group n issue, group n+1 (the next tile's first K group after the last V pair) is in flight into the other slot.
+// NG is even, so the slot of every group is a compile-time constant.  Same items, partials and combine as above.
+template <int DH, int W>
+__global__ __launch_bounds__(256 * W, W) void xattn_stream_kernel(const float* __restrict__ q, int ldq,
+                                                                  const float4* __restrict__ kimg,
+                                                                  const float4* __restrict__ vimg,
+                                                                  float4* __restrict__ part_o,
+                                                                  float2* __restrict__ part_ml, int B, int NQ, int NK,
+                                                                  int C, int heads, int tpc, float kc2, float lazy_raw,
+                                                                  int map) {
+  constexpr int KC = DH / 8, DT = DH / 32, NGK = KC / 8, NGV = DT / 2;
+  static_assert(NGK == NGV && NGK >= 1, "head dim must be a multiple of 64");
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int nqt = (NQ + 31) / 32, nkt = NK / 32, chunks = nkt / tpc;
+  const int items = B * heads * chunks * nqt;
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int sg = map ? lb : lb * 4 + (wv & 3), ng = map ? nb : nb * 4;
+  const int ibase = items / ng, irem = items % ng;
+  const int lo = ibase * sg + min(sg, irem), hi = lo + ibase + (sg < irem ? 1 : 0);
+  const int first = map ? wv : (wv >> 2), stride = map ? 4 * W : W;
+  const __amdgpu_buffer_rsrc_t krs = frag_rsrc(kimg, 0xffffffffu), vrs = frag_rsrc(vimg, 0xffffffffu);
+  const int loff = lane * 16;
+
+  for (int item = lo + first; item < hi; item += stride) {
+    const int qt = item % nqt;
+    int t = item / nqt;
+    const int ch = t % chunks;
+    t /= chunks;
+    const int head = t % heads, b = t / heads;
+    const int qrow = min(qt * 32 + r, NQ - 1);
+    float4 qf[KC];
+    {
+      const float* qp = q + ((size_t)b * NQ + qrow) * ldq + head * DH + 4 * h;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) qf[kc] = *reinterpret_cast<const float4*>(qp + 8 * kc);
+    }
+    const int kt0 = ch * tpc;
+    const int ktile_bytes = C * 128;
+    int koff = __builtin_amdgcn_readfirstlane((b * nkt + kt0) * ktile_bytes + head * KC * 1024);
+    int voff = __builtin_amdgcn_readfirstlane((b * nkt + kt0) * ktile_bytes + ((head * DH) / 32) * 4096);
+    float4 ring[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ring[0][e] = frag_load(krs, loff, koff + e * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[d] = zero16();
+    float m_ref = -INFINITY, nbias = 0.f, l_run = 0.f;
+
+    for (int kt = 0; kt < tpc; ++kt) {
+      const int adv = (kt + 1 < tpc) ? ktile_bytes : 0;
+      f32x16 s = zero16();
+#pragma unroll
+      for (int g = 0; g < NGK; ++g) {
+        // next group: K group g+1 of this tile, or V pair 0 behind the last K group
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          ring[(g + 1) & 1][e] = (g + 1 < NGK) ? frag_load(krs, loff, koff + ((g + 1) * 8 + e) * 1024)
+                                               : frag_load(vrs, loff, voff + e * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float4 a = ring[g & 1][e];
+          const float4 bq = qf[g * 8 + e];
+          s = mfma32(a.x, bq.x, s);
+          s = mfma32(a.y, bq.y, s);
+          s = mfma32(a.z, bq.z, s);
+          s = mfma32(a.w, bq.w, s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      softmax_tile<DT>(s, o, m_ref, nbias, l_run, kc2, lazy_raw);
+      __builtin_amdgcn_sched_barrier(0);
+      koff += adv;
+#pragma unroll
+      for (int v = 0; v < NGV; ++v) {
+        // next group: V pair v+1 of this tile, or the next tile's K group 0 behind the last pair
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          ring[(NGK + v + 1) & 1][e] = (v + 1 < NGV) ? frag_load(vrs, loff, voff + ((v + 1) * 8 + e) * 1024)
+                                                     : frag_load(krs, loff, koff + e * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+          for (int dd = 0; dd < 2; ++dd)
+            o[2 * v + dd] = mfma32((&ring[(NGK + v) & 1][dd * 4 + (i >> 2)].x)[i & 3], s[i], o[2 * v + dd]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      voff += adv;
+    }
+    l_run = half_sum(l_run);
+    float4* po = part_o + (size_t)item * (DT * 4) * 64 + lane;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        nt_store4(po + (d * 4 + g) * 64, make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]));
+    if (h == 0) part_ml[(size_t)item * 32 + r] = make_float2(m_ref, l_run);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // see xattn_kernel
+  }
 }
 
 // ctx[b, q, head*DH + c] = sum_s w_s O_s[c] / sum_s w_s l_s,   w_s = 2^{(m_s - M) kc2},  M = max_s m_s
@@ -380,6 +496,11 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
                      (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map, prio_rot); \
   hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
+#define POEM_XSTREAM(D, WV)                                                                                        \
+  hipLaunchKernelGGL((xattn_stream_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, (const float4*)kimg,   \
+                     (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map);           \
+  hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
+                     heads, chunks, waves, kc2)
   int wsel = 0, map = 1, prio_rot = 0;
 #ifdef POEM_LAB
   if (const char* e = getenv("POEM_ATTN_PRIO")) prio_rot = atoi(e);
@@ -398,14 +519,13 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
       else if (wsel == 4) { POEM_XATTN(64, 4); }
       else { POEM_XATTN(64, 3); }
       break;
-    case 128:
-      if (wsel == 2) { POEM_XATTN(128, 2); }
-      else { POEM_XATTN(128, 1); }
-      break;
+    case 128: POEM_XSTREAM(128, 2); break;
+    case 256: POEM_XSTREAM(256, 1); break;
     default:
       return hipErrorInvalidValue;
   }
 #undef POEM_XATTN
+#undef POEM_XSTREAM
   return hipGetLastError();
 }
 

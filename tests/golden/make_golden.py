@@ -38,6 +38,7 @@ CASES = {
     "small": dict(model="small", embed=128, nsample=4096, views=[2], seed=1, parametric=False, full=False),
     "medium": dict(model="medium", embed=256, nsample=4096, views=[2, 8], seed=2, parametric=False, full=False),
     "large": dict(model="large", embed=512, nsample=4096, views=[10], seed=3, parametric=False, full=False),
+    "huge": dict(model="huge", embed=1024, nsample=4096, views=[2], seed=6, parametric=False, full=False),
     # BASELINE config c5 in miniature: ragged view counts at the medium release shape
     "ragged": dict(model="medium", embed=256, nsample=4096, views=[3, 10, 1, 6], seed=4, parametric=False, full=False),
     # BASELINE config c3's model: medium_MANO release shape (parametric tail with the toy MANO stand-in)

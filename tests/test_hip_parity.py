@@ -60,7 +60,8 @@ def test_layernorm():
     assert _md(hip.layernorm(x.to(DEV), gm.to(DEV), bt.to(DEV), 1e-12), ref) < 1e-5
 
 
-@pytest.mark.parametrize("C,heads,NQ,NK", [(32, 4, 100, 64), (128, 4, 799, 1024), (256, 4, 799, 4096), (512, 4, 257, 512)])
+@pytest.mark.parametrize("C,heads,NQ,NK", [(32, 4, 100, 64), (128, 4, 799, 1024), (256, 4, 799, 4096), (512, 4, 257, 512),
+                                           (512, 4, 799, 4096), (1024, 4, 130, 256), (1024, 4, 799, 4096)])
 def test_cross_attention(C, heads, NQ, NK):
     g = torch.Generator().manual_seed(C + NQ)
     B = 2
@@ -184,7 +185,7 @@ def test_head_tiny_stage_taps_vs_golden(name):
         assert _md(out["pred_shape"], torch.from_numpy(z["pred_shape"])) < 2e-5
 
 
-@pytest.mark.parametrize("name", ["small", "medium", "large", "ragged", "mediummano"])
+@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano"])
 def test_head_release_shapes_vs_golden_and_oracle(name):
     """BASELINE.json bar: MPVPE of the HIP path vs the reference <= 1e-3 mm (1e-6 m), last decoder layer."""
     z, meta = load_golden(name)

@@ -33,7 +33,7 @@ def test_tiny_stage_taps(name):
         assert _maxdiff(out["pred_shape"], z["pred_shape"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["small", "medium", "large", "ragged", "mediummano"])
+@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano"])
 def test_release_shapes(name):
     z, meta = load_golden(name)
     cfg, w, consts, batch = case_setup(meta["spec"])
