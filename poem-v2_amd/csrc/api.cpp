@@ -71,6 +71,9 @@ hipError_t poem_launch_finalize_param(const float* verts, const float* joints, c
 hipError_t poem_launch_q3_flatten(const float* feats, const float* fw, const float* fb, float* t, int B, int Q, int C,
                                   hipStream_t s);
 hipError_t poem_launch_rot6d_to_aa(const float* par, float* pose_aa, float* betas, int B, hipStream_t s);
+hipError_t poem_launch_compose_weight(const float* A, const float* Bm, float* out, int N, int Cm, int K, hipStream_t s);
+hipError_t poem_launch_compose_bias(const float* A, const float* b1, const float* b2, float* out, int N, int Cm,
+                                    hipStream_t s);
 }
 
 static thread_local int g_last_hip_error = 0;
@@ -160,10 +163,14 @@ struct poem_handle_s {
   float* pe_table = nullptr;         // (sum N, C, HW)
   // Linears that share their input are fused along N (packed images concatenate tile-wise; results are bit-identical
   // to the separate GEMMs -- every output column is its own fma chain):
-  //   F1 (5C x C): attn.key | attn.value | cross_attn.key | cross_attn.value | query_cross_attn.fc1      input ke
-  //   F2 (2C x C): query_cross_attn.w_ks | w_vs                                                          input xk
-  //   F3 (3C x C): query_self_attn.w_qs | w_ks | w_vs                                                    input xs
   //   F4 (5C x C): reg_branch.0 (relu) | intermediate.dense (gelu)                                       input f_cross
+  // and Linears that follow each other WITHOUT a non-linearity are composed into one (W = A B, b = A b1 + b2, fp64
+  // products rounded once -- misc.hip compose_*; results agree with the sequential form to fp32 round-off):
+  //   F1 (6C x C): (attn.key | attn.value | cross_attn.key | cross_attn.value) o embedding
+  //                | (query_cross_attn.w_ks | w_vs) o query_cross_attn.fc1 o embedding          input pt_feats (all blocks)
+  //   F2 (2C x C): embedding | attn.query o embedding                                            input query feats
+  //   F3 (3C x C): (query_self_attn.w_qs | w_ks | w_vs) o query_self_attn.fc1                    input h_cross
+  // so `ke`, `xk` and `xs` are never materialised and three GEMMs per block disappear.
   struct Fused { const void* w[4]; const float* b[4]; };
   std::vector<Fused> fused;
   bool taps = false;
@@ -220,11 +227,12 @@ struct Plan {
   // sampling stage
   float *x, *uv, *g, *h1, *h2, *mm, *mh, *y, *bps_feat, *centre, *pt_xyz, *xyz[9];
   // decoder (per call scratch)
-  float *feats0, *qe, *qp, *ctx, *att, *h_attn, *xs, *y3, *rs, *qc, *rc, *y4, *ffo;
+  float *feats0, *qp, *ctx, *att, *h_attn, *y3, *rs, *qc, *rc, *y4, *ffo;
   // basis-point side, one set per block (produced ahead of time on the side stream):
-  // y1 = 5 x (BS, C): K image 1 | V image 1 | K image 2 | V image 2 (MFMA fragment order, attn.hip) | xk (row-major),
-  // y2 = (BS, 2C) [kc | vc]
-  float *ke[8], *y1[8], *y2[8];
+  // y1 = 6 x (BS, C): K image 1 | V image 1 | K image 2 | V image 2 (MFMA fragment order, attn.hip) | kc | vc (row-major
+  // keys / values of the vector cross attention)
+  float *y1[8];
+  float *qeqp;     // (BQ, 2C): [qe | first attention's query projection]
   // per block kept tensors (taps)
   float *h_cross[8], *f_self[8], *f_cross[8], *feats[8];
   float *q3t, *par, *attn_scratch;
@@ -254,12 +262,11 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   float* xyz_all = a.take<float>((size_t)(c.nblocks + 1) * BQ * 3);   // [0] = initial, [1..] = per-block outputs (contiguous)
   for (int i = 0; i <= c.nblocks; ++i) p.xyz[i] = xyz_all ? xyz_all + (size_t)i * BQ * 3 : nullptr;
   p.feats0 = a.take<float>(BQ * C);
-  p.qe = a.take<float>(BQ * C);
+  p.qeqp = a.take<float>(BQ * C * 2);
   p.qp = a.take<float>(BQ * C);
   p.ctx = a.take<float>(BQ * C);
   p.att = a.take<float>(BQ * C);
   p.h_attn = a.take<float>(BQ * C);
-  p.xs = a.take<float>(BQ * C);
   p.y3 = a.take<float>(BQ * C * 3);
   p.rs = a.take<float>(BQ * C);
   p.qc = a.take<float>(BQ * C);
@@ -273,9 +280,7 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
     p.feats[i] = a.take<float>(BQ * C);
     p.idx_self[i] = a.take<int32_t>(BQ * 32);
     p.idx_cross[i] = a.take<int32_t>(BQ * 32);
-    p.ke[i] = a.take<float>(BS * C);
-    p.y1[i] = a.take<float>(BS * C * 5);
-    p.y2[i] = a.take<float>(BS * C * 2);
+    p.y1[i] = a.take<float>(BS * C * 6);
   }
   p.q3t = a.take<float>((size_t)B * C);
   p.par = a.take<float>((size_t)B * 106);
@@ -316,20 +321,13 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     HIPCHK(hipStreamWaitEvent(sk, h->ev_fork, 0));
   }
   auto bps_side = [&](int i) -> int {
-    const int bb = h->block_base(i);
-    GEMM_ON(sb, pt_feats, C, bb + B_EMB_W, bb + B_EMB_B, nullptr, 0, p.ke[i], C, BS, C, C, POEM_ACT_NONE);
     const auto& f = h->fused[i];
-    // F1: keys/values of both BERT cross attentions + fc1 of the vector cross attention (hoisted to the S source rows)
-    // (the four key/value blocks leave the GEMM as MFMA fragment images, the fifth row-major)
-    {
-      const size_t seg = (size_t)BS * C;
-      float* outs[5] = {p.y1[i], p.y1[i] + seg, p.y1[i] + 2 * seg, p.y1[i] + 3 * seg, p.y1[i] + 4 * seg};
-      const int modes[5] = {1, 2, 1, 2, 0};
-      HIPCHK(poem_launch_gemm_segs(p.ke[i], C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, 5, outs, modes, sb));
-    }
-    // F2: w_ks | w_vs of the vector cross attention on xk (fifth block of y1)
-    HIPCHK(poem_launch_gemm_split(p.y1[i] + 4 * (size_t)BS * C, C, f.w[1], nullptr, nullptr, 0, p.y2[i], 2 * C, BS, 2 * C, C,
-                                  POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, sb));
+    // F1: keys / values of both BERT cross attentions and of the vector cross attention, straight from the basis-point
+    // features (embedding and fc1 composed in); the four BERT blocks leave the GEMM as MFMA fragment images
+    const size_t seg = (size_t)BS * C;
+    float* outs[6] = {p.y1[i], p.y1[i] + seg, p.y1[i] + 2 * seg, p.y1[i] + 3 * seg, p.y1[i] + 4 * seg, p.y1[i] + 5 * seg};
+    const int modes[6] = {1, 2, 1, 2, 0, 0};
+    HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, 6, outs, modes, sb));
     if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));
     return POEM_OK;
   };
@@ -366,26 +364,35 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       const int rc = bps_side(i);
       if (rc != POEM_OK) return rc;
     }
-    GEMM(feats, C, bb + B_EMB_W, bb + B_EMB_B, nullptr, 0, p.qe, C, BQ, C, C, POEM_ACT_NONE);
-    const float* hidden = p.qe;
+    // F2: qe = embedding(feats) | query projection of the first attention (composed with the embedding)
+    HIPCHK(poem_launch_gemm_split(feats, C, h->fused[i].w[1], h->fused[i].b[1], nullptr, 0, p.qeqp, 2 * C, BQ, 2 * C, C,
+                                  POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, s));
+    const float* hidden = p.qeqp;
+    int ldh = 2 * C;
     for (int a = 0; a < 2; ++a) {
       const int ab = bb + (a == 0 ? B_A1 : B_A2);
       float* hout = a == 0 ? p.h_attn : p.h_cross[i];
-      GEMM(hidden, C, ab + 0, ab + 1, nullptr, 0, p.qp, C, BQ, C, C, POEM_ACT_NONE);
+      const float* qptr = p.qeqp + C;
+      int ldq = 2 * C;
+      if (a == 1) {
+        GEMM(hidden, ldh, ab + 0, ab + 1, nullptr, 0, p.qp, C, BQ, C, C, POEM_ACT_NONE);
+        qptr = p.qp;
+        ldq = C;
+      }
       if (ov && a == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
-      HIPCHK(poem_launch_cross_attention_img(p.qp, C, p.y1[i] + (size_t)(2 * a) * BS * C,
+      HIPCHK(poem_launch_cross_attention_img(qptr, ldq, p.y1[i] + (size_t)(2 * a) * BS * C,
                                              p.y1[i] + (size_t)(2 * a + 1) * BS * C, p.ctx, B, Q, S, C, c.heads,
                                              p.attn_scratch, s));
-      GEMM(p.ctx, C, ab + 6, ab + 7, hidden, C, p.att, C, BQ, C, C, POEM_ACT_NONE);
+      GEMM(p.ctx, C, ab + 6, ab + 7, hidden, ldh, p.att, C, BQ, C, C, POEM_ACT_NONE);
       HIPCHK(poem_launch_layernorm(p.att, h->R(ab + 8), h->R(ab + 9), hout, BQ, C, c.ln_eps, s));
       hidden = hout;
+      ldh = C;
     }
     // vector self-attention over the queries
     const int vsb = bb + B_VS;
-    GEMM(hidden, C, vsb + 0, vsb + 1, nullptr, 0, p.xs, C, BQ, C, C, POEM_ACT_NONE);
-    // F3: w_qs | w_ks | w_vs
-    HIPCHK(poem_launch_gemm_split(p.xs, C, h->fused[i].w[2], nullptr, nullptr, 0, p.y3, 3 * C, BQ, 3 * C, C, POEM_ACT_NONE,
-                                  3 * C, POEM_ACT_NONE, s));
+    // F3: (w_qs | w_ks | w_vs) o fc1 on h_cross
+    HIPCHK(poem_launch_gemm_split(hidden, C, h->fused[i].w[2], h->fused[i].b[2], nullptr, 0, p.y3, 3 * C, BQ, 3 * C, C,
+                                  POEM_ACT_NONE, 3 * C, POEM_ACT_NONE, s));
     if (ov && i > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
     {
     PROF_START();
@@ -400,9 +407,10 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     GEMM(p.f_self[i], C, vcb + 12, -1, nullptr, 0, p.qc, C, BQ, C, C, POEM_ACT_NONE);
     {
     PROF_START();
-    HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y2[i], p.y2[i] + C, S, h->R(vcb + 4),
+    HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
+                                        p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4),
                                         h->R(vcb + 5), h->P(vcb + 6), h->R(vcb + 7), h->P(vcb + 8), h->R(vcb + 9),
-                                        h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, C, 2 * C, 2 * C, s));
+                                        h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, C, C, C, s));
     PROF_STOP();
     }
     GEMM(p.rc, C, vcb + 2, vcb + 3, p.f_self[i], C, p.f_cross[i], C, BQ, C, C, POEM_ACT_NONE);
@@ -499,10 +507,11 @@ size_t poem_packed_bytes(const poem_config_t* cfg) {
   const size_t hw = (size_t)cfg->feat_h * cfg->feat_w;
   {   // fused images F1..F4 per block + their concatenated biases (F1, F4)
     const size_t C = cfg->embed;
-    const size_t per = align_up(packed_bytes_linear(5 * C, C), 256) + align_up(packed_bytes_linear(2 * C, C), 256) +
+    const size_t per = align_up(packed_bytes_linear(6 * C, C), 256) + align_up(packed_bytes_linear(2 * C, C), 256) +
                        align_up(packed_bytes_linear(3 * C, C), 256) + align_up(packed_bytes_linear(5 * C, C), 256) +
-                       2 * align_up(5 * C * 4, 256);
+                       align_up(6 * C * 4, 256) + align_up(2 * C * 4, 256) + align_up(3 * C * 4, 256) + align_up(5 * C * 4, 256);
     total += per * cfg->nblocks;
+    total += align_up((6 * C * C + 2 * C * C + 8 * C) * 4, 256) + 256;   // raw composites (init-time scratch, at the arena's end)
   }
   total += align_up(pe_views(cfg->max_views) * cfg->embed * hw * 4, 256);              // folded positional table
   total += align_up(pe_views(cfg->max_views) * (3 * cfg->embed / 2) * hw * 4, 256);    // sine scratch (init only)
@@ -548,32 +557,56 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   const int C = cfg->embed, hw = cfg->feat_h * cfg->feat_w;
   {
     h->fused.resize(cfg->nblocks);
-    auto fuse = [&](const std::vector<int>& widx, const std::vector<int>& bidx, const void** wout, const float** bout) -> bool {
-      *wout = cur;
-      for (int wi : widx) {
-        if (poem_launch_pack_linear(h->raw[wi], C, C, cur, s) != hipSuccess) return false;
-        cur += packed_bytes_linear(C, C);
-      }
-      cur = (char*)packed + align_up((size_t)(cur - (char*)packed), 256);
-      *bout = nullptr;
-      if (!bidx.empty()) {
-        *bout = (const float*)cur;
-        for (size_t k = 0; k < bidx.size(); ++k)
-          if (hipMemcpyAsync(cur + k * C * 4, h->raw[bidx[k]], (size_t)C * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
-            return false;
-        cur += align_up(bidx.size() * (size_t)C * 4, 256);
-      }
-      return true;
-    };
+    // init-time scratch for raw composites: rows (<= 6C x C), T (C x C), t2 (C x C), bias vectors
+    float* raw_rows = (float*)((char*)packed + ((packed_bytes - align_up((size_t)(6 * C * C + 2 * C * C + 8 * C) * 4, 256)) & ~(size_t)255));
+    float* raw_T = raw_rows + (size_t)6 * C * C;
+    float* raw_tb = raw_T + (size_t)2 * C * C;       // C floats (+ spare)
     bool ok = true;
+    auto LOK = [&](hipError_t e) { ok = ok && e == hipSuccess; };
+    // rows [slot*C, (slot+1)*C) of raw_rows = A . Bm ; bias slot likewise = A . b1 + b2
+    auto comp = [&](int slot, const float* A, const float* Bm, const float* b1, const float* b2, float* bias_out) {
+      LOK(poem_launch_compose_weight(A, Bm, raw_rows + (size_t)slot * C * C, C, C, C, s));
+      LOK(poem_launch_compose_bias(A, b1, b2, bias_out + (size_t)slot * C, C, C, s));
+    };
+    auto pack_rows = [&](int nslots, const void** wout) {
+      *wout = cur;
+      LOK(poem_launch_pack_linear(raw_rows, nslots * C, C, cur, s));
+      cur += align_up(packed_bytes_linear(nslots * C, C), 256);
+    };
     for (int b = 0; b < cfg->nblocks && ok; ++b) {
       const int bb = h->block_base(b);
       const int a1 = bb + B_A1, a2 = bb + B_A2, vs = bb + B_VS, vc = bb + B_VC;
       auto& f = h->fused[b];
-      ok = ok && fuse({a1 + 2, a1 + 4, a2 + 2, a2 + 4, vc + 0}, {a1 + 3, a1 + 5, a2 + 3, a2 + 5, vc + 1}, &f.w[0], &f.b[0]);
-      ok = ok && fuse({vc + 13, vc + 14}, {}, &f.w[1], &f.b[1]);
-      ok = ok && fuse({vs + 12, vs + 13, vs + 14}, {}, &f.w[2], &f.b[2]);
-      // intermediate.dense is (4C, C): four C-row slabs of the raw tensor
+      const float* We = h->raw[bb + B_EMB_W];
+      const float* be = h->raw[bb + B_EMB_B];
+      // ---- F1: basis-point side
+      float* b0 = (float*)cur; cur += align_up((size_t)6 * C * 4, 256);
+      comp(0, h->raw[a1 + 2], We, be, h->raw[a1 + 3], b0);
+      comp(1, h->raw[a1 + 4], We, be, h->raw[a1 + 5], b0);
+      comp(2, h->raw[a2 + 2], We, be, h->raw[a2 + 3], b0);
+      comp(3, h->raw[a2 + 4], We, be, h->raw[a2 + 5], b0);
+      // T = fc1 . embedding, tb = fc1 . be + b_fc1 ; then w_ks . T, w_vs . T (no bias of their own)
+      LOK(poem_launch_compose_weight(h->raw[vc + 0], We, raw_T, C, C, C, s));
+      LOK(poem_launch_compose_bias(h->raw[vc + 0], be, h->raw[vc + 1], raw_tb, C, C, s));
+      comp(4, h->raw[vc + 13], raw_T, raw_tb, nullptr, b0);
+      comp(5, h->raw[vc + 14], raw_T, raw_tb, nullptr, b0);
+      f.b[0] = b0;
+      pack_rows(6, &f.w[0]);
+      // ---- F2: query side, embedding | attn.query o embedding
+      float* b1v = (float*)cur; cur += align_up((size_t)2 * C * 4, 256);
+      LOK(hipMemcpyAsync(raw_rows, We, (size_t)C * C * 4, hipMemcpyDeviceToDevice, s));
+      LOK(hipMemcpyAsync(b1v, be, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+      comp(1, h->raw[a1 + 0], We, be, h->raw[a1 + 1], b1v);
+      f.b[1] = b1v;
+      pack_rows(2, &f.w[1]);
+      // ---- F3: (w_qs | w_ks | w_vs) o fc1 of the vector self attention
+      float* b2v = (float*)cur; cur += align_up((size_t)3 * C * 4, 256);
+      comp(0, h->raw[vs + 12], h->raw[vs + 0], h->raw[vs + 1], nullptr, b2v);
+      comp(1, h->raw[vs + 13], h->raw[vs + 0], h->raw[vs + 1], nullptr, b2v);
+      comp(2, h->raw[vs + 14], h->raw[vs + 0], h->raw[vs + 1], nullptr, b2v);
+      f.b[2] = b2v;
+      pack_rows(3, &f.w[2]);
+      // F4: reg_branch.0 | intermediate.dense share f_cross; intermediate.dense is (4C, C): four C-row slabs of the raw tensor
       f.w[3] = cur;
       ok = ok && poem_launch_pack_linear(h->raw[bb + B_REG0_W], C, C, cur, s) == hipSuccess;
       cur += packed_bytes_linear(C, C);

@@ -155,3 +155,42 @@ extern "C" hipError_t poem_launch_rot6d_to_aa(const float* par, float* pose_aa, 
   hipLaunchKernelGGL(rot6d_to_aa_kernel, dim3((total + 63) / 64), dim3(64), 0, s, par, pose_aa, betas, B);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Composite Linears, built once at handle creation: two Linears in sequence without a non-linearity between them are one
+// Linear, W = A B and b = A b1 + b2 (fp64 accumulation, rounded once to fp32).  The decoder uses them for the
+// embedding -> key/value projections of every block (input: the basis-point features, which are the same for all
+// blocks) and for embedding -> query, fc1 -> w_qs|w_ks|w_vs on the query side: fewer GEMMs, fewer HBM round trips.
+// out[n][k] = sum_c A[n][c] * B[c][k]       A (N x Cm), B (Cm x K)
+__global__ void compose_weight_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ out,
+                                      int N, int Cm, int K) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * K) return;
+  const int k = (int)(i % K), n = (int)(i / K);
+  double acc = 0.0;
+  for (int c = 0; c < Cm; ++c) acc += (double)A[(size_t)n * Cm + c] * (double)Bm[(size_t)c * K + k];
+  out[i] = (float)acc;
+}
+
+// out[n] = sum_c A[n][c] * b1[c] + (b2 ? b2[n] : 0)
+__global__ void compose_bias_kernel(const float* __restrict__ A, const float* __restrict__ b1, const float* __restrict__ b2,
+                                    float* __restrict__ out, int N, int Cm) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double acc = b2 ? (double)b2[n] : 0.0;
+  for (int c = 0; c < Cm; ++c) acc += (double)A[(size_t)n * Cm + c] * (double)b1[c];
+  out[n] = (float)acc;
+}
+
+extern "C" hipError_t poem_launch_compose_weight(const float* A, const float* Bm, float* out, int N, int Cm, int K,
+                                                 hipStream_t s) {
+  const long total = (long)N * K;
+  hipLaunchKernelGGL(compose_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A, Bm, out, N, Cm, K);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t poem_launch_compose_bias(const float* A, const float* b1, const float* b2, float* out, int N, int Cm,
+                                               hipStream_t s) {
+  hipLaunchKernelGGL(compose_bias_kernel, dim3((N + 63) / 64), dim3(64), 0, s, A, b1, b2, out, N, Cm);
+  return hipGetLastError();
+}
