@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -42,7 +44,7 @@ hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src
                                         const int* idx, int shared_idx, const float* q, const float* k, const float* v,
                                         int nsrc, const float* wd1, const float* bd1, const void* wd2, const float* bd2,
                                         const void* wg1, const float* bg1, const void* wg2, const float* bg2, float* out,
-                                        int B, int Q, int C, int ldq, int ldk, int ldv, hipStream_t s);
+                                        int B, int Q, int C, int ldq, int ldk, int ldv, int composed, hipStream_t s);
 hipError_t poem_launch_dlt(const float* uv, const float* intr, const float* mat, const int* offs, float* out, int B, int J,
                            int invert, hipStream_t s);
 hipError_t poem_launch_pa_epe(const float* pred, const float* gt, float* out, int B, int P, hipStream_t s);
@@ -78,8 +80,11 @@ hipError_t poem_launch_compose_bias(const float* A, const float* b1, const float
 
 static thread_local int g_last_hip_error = 0;
 
+// (the sticky per-thread HIP error is cleared first: a stale error left behind by another library on this thread --
+//  PyTorch's allocator probing, for one -- would otherwise be read by the launcher's hipGetLastError() and blamed on us)
 #define HIPCHK(expr)                                 \
   do {                                               \
+    (void)hipGetLastError();                         \
     hipError_t e_ = (expr);                          \
     if (e_ != hipSuccess) {                          \
       g_last_hip_error = (int)e_;                    \
@@ -169,9 +174,13 @@ struct poem_handle_s {
   //   F1 (6C x C): (attn.key | attn.value | cross_attn.key | cross_attn.value) o embedding
   //                | (query_cross_attn.w_ks | w_vs) o query_cross_attn.fc1 o embedding          input pt_feats (all blocks)
   //   F2 (2C x C): embedding | attn.query o embedding                                            input query feats
-  //   F3 (3C x C): (query_self_attn.w_qs | w_ks | w_vs) o query_self_attn.fc1                    input h_cross
+  //   F3 (3C x C): (W_g1 w_qs | W_g1 w_ks | w_vs) o query_self_attn.fc1                          input h_cross
+  //   [4] (C x C): W_g1 w_qs of the vector cross attention (bias W_g1 b_d2 + b_g1)               input f_self
+  //   [5], [6]   : W_g1 W_d2 of the vector self / cross attention (vecattn.hip, composed form: fc_gamma.0 is linear, so
+  //                it is applied to q and k where they are produced and to pos through W_g1 W_d2 -- GEMM 2 of the fused
+  //                kernel then reads the same activations as GEMM 1)
   // so `ke`, `xk` and `xs` are never materialised and three GEMMs per block disappear.
-  struct Fused { const void* w[4]; const float* b[4]; };
+  struct Fused { const void* w[7]; const float* b[7]; };   // [4] cross-attn query, [5]/[6] W_g1 W_d2 of self / cross
   std::vector<Fused> fused;
   bool taps = false;
   struct Tap { const void* p; int64_t elems; };
@@ -397,20 +406,20 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     {
     PROF_START();
     HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
-                                        h->R(vsb + 5), h->P(vsb + 6), h->R(vsb + 7), h->P(vsb + 8), h->R(vsb + 9),
-                                        h->P(vsb + 10), h->R(vsb + 11), p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, s));
+                                        h->R(vsb + 5), h->P(vsb + 6), h->R(vsb + 7), h->fused[i].w[5], h->R(vsb + 9),
+                                        h->P(vsb + 10), h->R(vsb + 11), p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, 1, s));
     PROF_STOP();
     }
     GEMM(p.rs, C, vsb + 2, vsb + 3, hidden, C, p.f_self[i], C, BQ, C, C, POEM_ACT_NONE);
     // vector cross-attention over the basis points
     const int vcb = bb + B_VC;
-    GEMM(p.f_self[i], C, vcb + 12, -1, nullptr, 0, p.qc, C, BQ, C, C, POEM_ACT_NONE);
+    HIPCHK(poem_launch_gemm(p.f_self[i], C, h->fused[i].w[4], h->fused[i].b[4], nullptr, 0, p.qc, C, BQ, C, C, POEM_ACT_NONE, s));
     {
     PROF_START();
     HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
                                         p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4),
-                                        h->R(vcb + 5), h->P(vcb + 6), h->R(vcb + 7), h->P(vcb + 8), h->R(vcb + 9),
-                                        h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, C, C, C, s));
+                                        h->R(vcb + 5), h->P(vcb + 6), h->R(vcb + 7), h->fused[i].w[6], h->R(vcb + 9),
+                                        h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, C, C, C, 1, s));
     PROF_STOP();
     }
     GEMM(p.rc, C, vcb + 2, vcb + 3, p.f_self[i], C, p.f_cross[i], C, BQ, C, C, POEM_ACT_NONE);
@@ -509,7 +518,8 @@ size_t poem_packed_bytes(const poem_config_t* cfg) {
     const size_t C = cfg->embed;
     const size_t per = align_up(packed_bytes_linear(6 * C, C), 256) + align_up(packed_bytes_linear(2 * C, C), 256) +
                        align_up(packed_bytes_linear(3 * C, C), 256) + align_up(packed_bytes_linear(5 * C, C), 256) +
-                       align_up(6 * C * 4, 256) + align_up(2 * C * 4, 256) + align_up(3 * C * 4, 256) + align_up(5 * C * 4, 256);
+                       align_up(6 * C * 4, 256) + align_up(2 * C * 4, 256) + align_up(3 * C * 4, 256) + align_up(5 * C * 4, 256) +
+                       3 * align_up(packed_bytes_linear(C, C), 256) + 2 * align_up(C * 4, 256);
     total += per * cfg->nblocks;
     total += align_up((6 * C * C + 2 * C * C + 8 * C) * 4, 256) + 256;   // raw composites (init-time scratch, at the arena's end)
   }
@@ -585,10 +595,12 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
       comp(1, h->raw[a1 + 4], We, be, h->raw[a1 + 5], b0);
       comp(2, h->raw[a2 + 2], We, be, h->raw[a2 + 3], b0);
       comp(3, h->raw[a2 + 4], We, be, h->raw[a2 + 5], b0);
-      // T = fc1 . embedding, tb = fc1 . be + b_fc1 ; then w_ks . T, w_vs . T (no bias of their own)
+      // T = fc1 . embedding, tb = fc1 . be + b_fc1 ; then (W_g1 w_ks) . T and w_vs . T (no bias of their own)
+      float* raw_T2 = raw_T + (size_t)C * C;
       LOK(poem_launch_compose_weight(h->raw[vc + 0], We, raw_T, C, C, C, s));
       LOK(poem_launch_compose_bias(h->raw[vc + 0], be, h->raw[vc + 1], raw_tb, C, C, s));
-      comp(4, h->raw[vc + 13], raw_T, raw_tb, nullptr, b0);
+      LOK(poem_launch_compose_weight(h->raw[vc + 8], h->raw[vc + 13], raw_T2, C, C, C, s));      // W_g1 w_ks
+      comp(4, raw_T2, raw_T, raw_tb, nullptr, b0);
       comp(5, h->raw[vc + 14], raw_T, raw_tb, nullptr, b0);
       f.b[0] = b0;
       pack_rows(6, &f.w[0]);
@@ -599,13 +611,30 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
       comp(1, h->raw[a1 + 0], We, be, h->raw[a1 + 1], b1v);
       f.b[1] = b1v;
       pack_rows(2, &f.w[1]);
-      // ---- F3: (w_qs | w_ks | w_vs) o fc1 of the vector self attention
+      // ---- F3: (W_g1 w_qs | W_g1 w_ks | w_vs) o fc1 of the vector self attention; the query part carries
+      //      cvec = W_g1 b_d2 + b_g1 (vecattn.hip, composed form)
       float* b2v = (float*)cur; cur += align_up((size_t)3 * C * 4, 256);
-      comp(0, h->raw[vs + 12], h->raw[vs + 0], h->raw[vs + 1], nullptr, b2v);
-      comp(1, h->raw[vs + 13], h->raw[vs + 0], h->raw[vs + 1], nullptr, b2v);
+      float* cvec = raw_tb + 2 * C;
+      LOK(poem_launch_compose_bias(h->raw[vs + 8], h->raw[vs + 7], h->raw[vs + 9], cvec, C, C, s));
+      LOK(poem_launch_compose_weight(h->raw[vs + 8], h->raw[vs + 12], raw_T, C, C, C, s));       // W_g1 w_qs
+      comp(0, raw_T, h->raw[vs + 0], h->raw[vs + 1], cvec, b2v);
+      LOK(poem_launch_compose_weight(h->raw[vs + 8], h->raw[vs + 13], raw_T, C, C, C, s));       // W_g1 w_ks
+      comp(1, raw_T, h->raw[vs + 0], h->raw[vs + 1], nullptr, b2v);
       comp(2, h->raw[vs + 14], h->raw[vs + 0], h->raw[vs + 1], nullptr, b2v);
       f.b[2] = b2v;
       pack_rows(3, &f.w[2]);
+      // ---- [4]: query of the vector cross attention, (W_g1 w_qs) f_self + (W_g1 b_d2 + b_g1)
+      float* b4v = (float*)cur; cur += align_up((size_t)C * 4, 256);
+      LOK(poem_launch_compose_bias(h->raw[vc + 8], h->raw[vc + 7], h->raw[vc + 9], b4v, C, C, s));
+      LOK(poem_launch_compose_weight(h->raw[vc + 8], h->raw[vc + 12], raw_rows, C, C, C, s));
+      f.b[4] = b4v;
+      pack_rows(1, &f.w[4]);
+      // ---- [5], [6]: W_g1 W_d2 of the two vector attentions
+      LOK(poem_launch_compose_weight(h->raw[vs + 8], h->raw[vs + 6], raw_rows, C, C, C, s));
+      pack_rows(1, &f.w[5]);
+      LOK(poem_launch_compose_weight(h->raw[vc + 8], h->raw[vc + 6], raw_rows, C, C, C, s));
+      pack_rows(1, &f.w[6]);
+      f.b[5] = f.b[6] = nullptr;
       // F4: reg_branch.0 | intermediate.dense share f_cross; intermediate.dense is (4C, C): four C-row slabs of the raw tensor
       f.w[3] = cur;
       ok = ok && poem_launch_pack_linear(h->raw[bb + B_REG0_W], C, C, cur, s) == hipSuccess;
@@ -783,7 +812,7 @@ int poem_vector_attention(const float* query_xyz, const float* src_xyz, const fl
       !wg1_packed || !bg1 || !wg2_packed || !bg2 || !out || batch <= 0 || nq <= 0)
     return POEM_E_ARG;
   HIPCHK(poem_launch_vector_attention(query_xyz, src_xyz, anchor_xyz, idx, shared_idx, q, k, v, nsrc, wd1, bd1, wd2_packed,
-                                      bd2, wg1_packed, bg1, wg2_packed, bg2, out, batch, nq, embed, embed, embed, embed,
+                                      bd2, wg1_packed, bg1, wg2_packed, bg2, out, batch, nq, embed, embed, embed, embed, 0,
                                       (hipStream_t)stream));
   return POEM_OK;
 }

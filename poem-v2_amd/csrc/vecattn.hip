@@ -44,13 +44,14 @@ struct VecAttnArgs {
   int B, Q;
   int ldq, ldk, ldv;        // row strides (floats) of q, k, v: they may be column blocks of a fused projection
   int stagger;              // > 0: persistent launch, second block of each CU starts `stagger` cycles late
+  int composed;             // 1: q, k are W_g1 q + (W_g1 b_d2 + b_g1) and W_g1 k, `wg1` is W_g1 W_d2 (see vecattn_kernel)
 };
 
 // arrival parity per CU (key: XCC id, HW_ID[15:8]); atomicInc wraps 0 -> 1 -> 0, so the table resets itself when
 // every CU hosts two blocks.  Used for speed only: a wrong parity costs overlap, never correctness.
 __device__ unsigned int va_cu_slot[8 * 256];
 
-template <int C, int P, int NW, int TPW, bool FLIP>
+template <int C, int P, int NW, int TPW, bool FLIP, bool INIT0 = true>
 __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const float* __restrict__ X,
                                            f32x16 (&acc)[TPW][P], int wv, int lane) {
   constexpr int KC = C / 8;      // even for every supported C
@@ -94,7 +95,7 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
   VA_READX(xa, 0, 0)
   VA_LOADW(a1, 1)
   __builtin_amdgcn_sched_barrier(0);
-  VA_CHUNK(a0, 0, true)
+  VA_CHUNK(a0, 0, INIT0)
   VA_LOADW(a0, 2)
   __builtin_amdgcn_sched_barrier(0);
   VA_CHUNK(a1, 1, false)
@@ -112,7 +113,12 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
 #undef VA_CHUNK
 }
 
-template <int C, int P, int NW, int MINW>
+// COMP (the decoder's form): W_g1 is linear, so W_g1 (q_i - k_j + pos_ij) + b_g1 = qg_i - kg_j + (W_g1 W_d2) h_ij with
+// qg = W_g1 q + (W_g1 b_d2 + b_g1) and kg = W_g1 k -- both composed into the projections that produce q and k anyway
+// (api.cpp), W_g1 W_d2 composed once at handle creation.  GEMM 2 then reads the SAME activations h as GEMM 1: the two
+// run back to back with no LDS round trip and no barrier between them, and the gathered kg_j rows simply wait in GEMM 2's
+// accumulator registers (acc = qg_i - kg_j before its first k-step).
+template <int C, int P, int NW, int MINW, bool COMP>
 __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   constexpr int TPW = C / 32 / NW;
   constexpr int XS = 32 * P;
@@ -208,10 +214,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   }
   __syncthreads();
 
-  f32x16 acc[TPW][P], pos[TPW][P];   // acc is initialised by the first k-step of every GEMM (chain_gemm, INIT)
+  f32x16 acc[TPW][P], pos[TPW][P];   // initialised by the first k-step of a GEMM (chain_gemm, INIT0) unless stated
 
-  // k_j for this lane's (channel tile, neighbour) cells: 16-byte row gathers issued BEFORE the first GEMM so their
-  // L2/HBM latency hides under its MFMAs; they wait in the registers that become `pos` in the epilogue.
+  // k_j (COMP: kg_j) for this lane's (channel tile, neighbour) cells: 16-byte row gathers issued BEFORE the first GEMM
+  // so their L2/HBM latency hides under its MFMAs.  They wait in registers the first GEMM does not touch: `pos` in the
+  // plain form (GEMM 1 accumulates into acc), `acc` in the composed form (GEMM 1 accumulates into pos).
 #pragma unroll
   for (int tp = 0; tp < TPW; ++tp) {
     const int cbase = (wv * TPW + tp) * 32 + 4 * h;
@@ -222,13 +229,51 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       for (int g = 0; g < 4; ++g) {
         const float4 kk = *reinterpret_cast<const float4*>(krow + 8 * g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pos[tp][p][4 * g + e] = (&kk.x)[e];
+        for (int e = 0; e < 4; ++e) (COMP ? acc : pos)[tp][p][4 * g + e] = (&kk.x)[e];
       }
     }
   }
   __builtin_amdgcn_sched_barrier(0);
 
   VA_STAMP(1);
+  if (COMP) {
+    // ---- GEMM 1: pos = W_d2 h (+ b_d2 below)
+    chain_gemm<C, P, NW, TPW, false>(A.wd2, X, pos, wv, lane);
+    VA_STAMP(2);
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      const int cbase = (wv * TPW + tp) * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bb = *reinterpret_cast<const float4*>(A.bd2 + cbase + 8 * g);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float4 qq = *reinterpret_cast<const float4*>(qs + p * C + cbase + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {      // register pairs -> v_pk_add_f32
+            const int i = 4 * g + e;
+            const f32x2 pv = f32x2{pos[tp][p][i], pos[tp][p][i + 1]} + f32x2{(&bb.x)[e], (&bb.x)[e + 1]};
+            const f32x2 tv = f32x2{(&qq.x)[e], (&qq.x)[e + 1]} - f32x2{acc[tp][p][i], acc[tp][p][i + 1]};
+            pos[tp][p][i] = pv[0]; pos[tp][p][i + 1] = pv[1];
+            acc[tp][p][i] = tv[0]; acc[tp][p][i + 1] = tv[1];
+          }
+        }
+      }
+    }
+    VA_STAMP(3);
+    // ---- GEMM 2 on the same activations: acc (= qg_i - kg_j) += (W_g1 W_d2) h ;  g = relu(acc)
+    chain_gemm<C, P, NW, TPW, false, false>(A.wg1, X, acc, wv, lane);
+    VA_STAMP(4);
+    __syncthreads();   // every wave is done reading h
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = fmaxf(acc[tp][p][i], 0.f);
+    __syncthreads();
+  } else {
   // ---- GEMM 1: pos = W_d2 h + b_d2 ;  t = q_i - k_j + pos
   chain_gemm<C, P, NW, TPW, false>(A.wd2, X, acc, wv, lane);
   VA_STAMP(2);
@@ -286,6 +331,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
     }
   }
   __syncthreads();
+  }
 
   // ---- GEMM 3 (operands swapped): a[j][c'] = W_g2 g + b_g2, lane = channel c', registers = neighbours
   VA_STAMP(5);
@@ -347,14 +393,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   }   // item loop
 }
 
-template <int C, int P, int NW, int MINW>
-static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s) {
+template <int C, int P, int NW, int MINW, bool COMP>
+static hipError_t launch_va_t(const VecAttnArgs& a, hipStream_t s) {
   const int groups = (a.Q + P - 1) / P;
   size_t lds = (size_t)C * 32 * P * 4 + P * 32 * 3 * 4 + 2 * P * 32 * 4 + (size_t)P * C * 4;
 #ifdef POEM_VA_DBG
   if (const char* e = getenv("POEM_VA_LDSPAD")) lds += atoi(e);
 #endif
-  auto kern = vecattn_kernel<C, P, NW, MINW>;
+  auto kern = vecattn_kernel<C, P, NW, MINW, COMP>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -376,14 +422,19 @@ static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <int C, int P, int NW, int MINW>
+static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s) {
+  return a.composed ? launch_va_t<C, P, NW, MINW, true>(a, s) : launch_va_t<C, P, NW, MINW, false>(a, s);
+}
+
 extern "C" hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                                    const int* idx, int shared_idx, const float* q, const float* k,
                                                    const float* v, int nsrc, const float* wd1, const float* bd1,
                                                    const void* wd2, const float* bd2, const void* wg1, const float* bg1,
                                                    const void* wg2, const float* bg2, float* out, int B, int Q, int C,
-                                                   int ldq, int ldk, int ldv, hipStream_t s) {
+                                                   int ldq, int ldk, int ldv, int composed, hipStream_t s) {
   VecAttnArgs a{query_xyz, src_xyz, anchor_xyz, idx, shared_idx, q, k, v, nsrc, wd1, bd1, (const float4*)wd2, bd2,
-                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q, ldq, ldk, ldv, 0};
+                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q, ldq, ldk, ldv, 0, composed};
   if (const char* e = getenv("POEM_VA_STAGGER")) a.stagger = atoi(e);
   switch (C) {
     case 32: return launch_va<32, 2, 1, 1>(a, s);

@@ -215,3 +215,17 @@ def test_eval_single_cfg_edits_match_reference():
     import pytest
     with pytest.raises(AssertionError):
         m.edit_cfg(m.default_cfg(), "NoSuchSet", "medium", [1, 2])
+
+
+def test_internal_launcher_declarations_match_their_definitions():
+    """csrc/api.cpp declares the kernel launchers of the .hip files as extern "C": such symbols carry no signature, so
+    a drifted declaration still links and then corrupts the call (stream read from the wrong slot).  Compare the
+    parameter type lists textually."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_abi_decls", os.path.join(root, "tools", "check_abi_decls.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    decls, bad = mod.main()
+    assert len(decls) >= 30 and not bad, bad

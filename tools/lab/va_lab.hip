@@ -25,9 +25,9 @@ int main() {
   for (int i = 0; i < 3; ++i) { CK(hipMalloc(&wp[i], packed_linear_floats(C, C) * 4)); CK(poem_launch_pack_linear(w, C, C, wp[i], 0)); }
   float* out = dalloc<float>((size_t)B * Q * C, false);
   hipEvent_t s, e; CK(hipEventCreate(&s)); CK(hipEventCreate(&e));
-  for (int it = 0; it < 3; ++it) CK(poem_launch_vector_attention(qxyz, sxyz, nullptr, idx, 0, q, k, v, NS, wd1, bd1, wp[0], bd2, wp[1], bg1, wp[2], bg2, out, B, Q, C, C, C, C, 0));
+  for (int it = 0; it < 3; ++it) CK(poem_launch_vector_attention(qxyz, sxyz, nullptr, idx, 0, q, k, v, NS, wd1, bd1, wp[0], bd2, wp[1], bg1, wp[2], bg2, out, B, Q, C, C, C, C, 0, 0));
   CK(hipEventRecord(s));
-  for (int it = 0; it < 5; ++it) CK(poem_launch_vector_attention(qxyz, sxyz, nullptr, idx, 0, q, k, v, NS, wd1, bd1, wp[0], bd2, wp[1], bg1, wp[2], bg2, out, B, Q, C, C, C, C, 0));
+  for (int it = 0; it < 5; ++it) CK(poem_launch_vector_attention(qxyz, sxyz, nullptr, idx, 0, q, k, v, NS, wd1, bd1, wp[0], bd2, wp[1], bg1, wp[2], bg2, out, B, Q, C, C, C, C, 0, 0));
   CK(hipEventRecord(e)); CK(hipEventSynchronize(e));
   float ms; CK(hipEventElapsedTime(&ms, s, e)); ms /= 5;
   printf("vecattn %.1f us  %.1f TF\n", ms * 1e3, (double)B * Q * 32 * (6.0 * C * C + 6.0 * C) / ms / 1e9);
