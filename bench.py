@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU (weak scaling)")
     ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--views-range", type=int, nargs=2, default=None, metavar=("LO", "HI"),
+                    help="ragged batch: views per sample ~ U{LO..HI}, seed 5 (BASELINE configs[4]: --views-range 2 10 --batch 64)")
     ap.add_argument("--model", default="medium", choices=list(pk.weights.MODEL_EMBED))
     ap.add_argument("--cpu-samples", type=int, default=4, help="0 disables the CPU baseline leg")
     ap.add_argument("--overlap", type=int, default=1, help="0: issue every kernel on one stream (A/B of the side streams)")
@@ -153,8 +155,11 @@ def main():
     torch.cuda.set_device(dev)
 
     C = pk.weights.MODEL_EMBED[args.model]
-    spec = dict(embed=C, nsample=4096, views=[args.views] * args.batch, seed=0, parametric=False)
-    head = pk.build_head(pk.configs.head_cfg(C, max_views=max(10, args.views)), data_preset=pk.CN({}))
+    views = [args.views] * args.batch
+    if args.views_range:
+        views = np.random.RandomState(5 + rank).randint(args.views_range[0], args.views_range[1] + 1, size=args.batch).tolist()
+    spec = dict(embed=C, nsample=4096, views=views, seed=0, parametric=False)
+    head = pk.build_head(pk.configs.head_cfg(C, max_views=max(10, max(views))), data_preset=pk.CN({}))
     head.load_state_dict(pk.weights.seeded_state_dict(C, seed=0), strict=False)
     head.set_template(pk.inputs.synthetic_template(1234))
     head = head.to(dev).eval()
@@ -200,13 +205,14 @@ def main():
     total_samples = args.batch * world * args.steps
     value = total_samples / dt
     res = {
-        "metric": "samples/sec (multi-view frames) POEM-medium 8-view" if (args.model, args.views) == ("medium", 8)
-        else f"samples/sec (multi-view frames) POEM-{args.model} {args.views}-view",
+        "metric": "samples/sec (multi-view frames) POEM-medium 8-view" if (args.model, args.views, args.views_range) == ("medium", 8, None)
+        else f"samples/sec (multi-view frames) POEM-{args.model} " +
+             (f"{args.views_range[0]}-{args.views_range[1]} views (ragged)" if args.views_range else f"{args.views}-view"),
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[1]: POEM-{args.model} head (POEM_Generalized_Head + PtEmbedTRv4), "
-                               f"{args.views} views, 160x16x16 backbone features (256x256 input), batch {args.batch} per GPU, "
+                               f"{('ragged ' + str(args.views_range)) if args.views_range else args.views} views, 160x16x16 backbone features (256x256 input), batch {args.batch} per GPU, "
                                "seeded weights, inputs resident in HBM",
                    "batch_per_gpu": args.batch, "views": args.views, "embed": C, "parallelism": f"dp{world}"},
     }
