@@ -301,76 +301,60 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
       }
       continue;
     }
-    // Epilogue.  The partner wave on this SIMD is usually inside its MFMA loop and the two compete for issue slots, so
-    // every instruction here costs several times its nominal latency: bias lives in registers for the whole block, the
-    // store address is a wave-uniform (scalar) row base + one per-lane offset, and in-bounds tiles skip the row checks.
+    // Epilogue, one 32 x 32 tile at a time (bias, activation, residual, store) so that the live temporaries stay one
+    // tile wide -- the erf of the GELU variant over all MT x NT tiles at once spilled hundreds of registers.  Bias lives
+    // in registers for the whole block, the store address is a wave-uniform row base + one per-lane offset, in-bounds
+    // tiles skip the row checks; every VALU instruction here comes out of the matrix pipe's time.
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int trow0 = (mt0 + i) * 32;
       if (trow0 >= M) break;
-      // bias + activation in place (branch outside the register loops)
-      if (GELU && pact == 2) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][n][e] = gelu_erf(acc[i][n][e] + bv[n]);
-      } else if (pact == 1) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][n][e] = fmaxf(acc[i][n][e] + bv[n], 0.f);
-      } else {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[i][n][e] += bv[n];
-      }
-      if (OMODE == 2) {
-        // image float4 index (((mt * ldy/32 + vt) * 4 + g) * 64 + lane), vt = ycol0/32 + n
-        float4* yp = reinterpret_cast<float4*>(Y) + ((size_t)(mt0 + i) * (ldy >> 5) + (ycol0 >> 5)) * 256 + lane;
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            yp[(size_t)(n * 4 + g) * 64] =
-                make_float4(acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
-        continue;
-      }
       float* yl = Y + (size_t)trow0 * ldy + (size_t)ycol0 + lane_yo;               // per-lane base, once
       const float* rl = R ? R + (size_t)trow0 * ldr + (size_t)col0 + lane_ro : nullptr;
       const bool full = trow0 + 32 <= M;
-      if (full) {
-        if (rl) {
 #pragma unroll
-          for (int n = 0; n < NT; ++n) {
+      for (int n = 0; n < NT; ++n) {
+        float v[16];
+        if (GELU && pact == 2) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = gelu_erf(acc[i][n][e] + bv[n]);
+        } else if (pact == 1) {
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            const f32x2 t = f32x2{acc[i][n][e], acc[i][n][e + 1]} + f32x2{bv[n], bv[n]};
+            v[e] = fmaxf(t[0], 0.f); v[e + 1] = fmaxf(t[1], 0.f);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            const f32x2 t = f32x2{acc[i][n][e], acc[i][n][e + 1]} + f32x2{bv[n], bv[n]};
+            v[e] = t[0]; v[e + 1] = t[1];
+          }
+        }
+        if (OMODE == 2) {
+          // image float4 index (((mt * ldy/32 + vt) * 4 + g) * 64 + lane), vt = ycol0/32 + n
+          float4* yp = reinterpret_cast<float4*>(Y) + ((size_t)(mt0 + i) * (ldy >> 5) + (ycol0 >> 5) + n) * 256 + lane;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) yp[(size_t)g * 64] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        } else if (full) {
+          if (rl) {
             float rr[16];                                      // 16 residual loads in flight, then 16 stores
 #pragma unroll
             for (int e = 0; e < 16; ++e) rr[e] = rl[(size_t)((e & 3) + 8 * (e >> 2)) * ldr + n * 32];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int ro = (e & 3) + 8 * (e >> 2);          // row inside the tile is ro + 4h
-              yl[(size_t)ro * ldy + n * 32] = acc[i][n][e] + rr[e];
-            }
+            for (int e = 0; e < 16; ++e) yl[(size_t)((e & 3) + 8 * (e >> 2)) * ldy + n * 32] = v[e] + rr[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yl[(size_t)((e & 3) + 8 * (e >> 2)) * ldy + n * 32] = v[e];   // row = ro + 4h
           }
         } else {
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int ro = (e & 3) + 8 * (e >> 2);
-              yl[(size_t)ro * ldy + n * 32] = acc[i][n][e];
-            }
-        }
-      } else {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int ro = (e & 3) + 8 * (e >> 2);
-            if (trow0 + ro + 4 * h < M)
-              yl[(size_t)ro * ldy + n * 32] = acc[i][n][e] + (rl ? rl[(size_t)ro * ldr + n * 32] : 0.f);
+            if (trow0 + ro + 4 * h < M) yl[(size_t)ro * ldy + n * 32] = v[e] + (rl ? rl[(size_t)ro * ldr + n * 32] : 0.f);
           }
+        }
       }
     }
   }
@@ -404,10 +388,11 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
   const int ycol0 = col0 - sidx * segs.seg_cols;
   float* ys = segs.ptr[sidx];
   const int mode = segs.mode[sidx];
-  if (mode == 1)
-    panel_rows<NT, MT, GELU, 1>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
-  else if (mode == 2)
-    panel_rows<NT, MT, GELU, 2>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
+  // (the image modes exist in the activation-free instantiation only: the launcher sends segmented GEMMs there)
+  if (!GELU && mode == 1)
+    panel_rows<NT, MT, false, 1>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
+  else if (!GELU && mode == 2)
+    panel_rows<NT, MT, false, 2>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
   else
     panel_rows<NT, MT, GELU, 0>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
 }
@@ -464,6 +449,7 @@ static hipError_t launch_gemm_split_impl(const float* X, int ldx, const void* Wp
   auto cost = [&](int mt) { return (long)(((mtiles + mt - 1) / mt + wpp - 1) / wpp) * mt; };
   const bool mt2 = 5 * cost(2) <= 6 * cost(1);   // 64-row wave tiles unless the 32-row split balances >= 20 % better
   const bool gelu = act == 2 || (act_split < N && act2 == 2);
+  if (seg && gelu) return hipErrorInvalidValue;   // image outputs exist in the GELU-free instantiation only
 #define POEM_PANEL(NTV)                                                                                                  \
   if (gelu)                                                                                                              \
     return mt2 ? launch_panel_t<NTV, 2, true>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s)   \
