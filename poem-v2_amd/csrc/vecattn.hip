@@ -455,7 +455,7 @@ extern "C" hipError_t poem_launch_vector_attention(const float* query_xyz, const
 #endif
       return launch_va<256, 2, 4, 2>(a, s);
     case 512: return launch_va<512, 1, 4, 2>(a, s);
-    case 1024: return launch_va<1024, 1, 4, 1>(a, s);
+    case 1024: return launch_va<1024, 1, 8, 2>(a, s);   // 8 waves x 4 channel tiles: 2 waves per SIMD, no spills (4 x 8 tiles spilled 158 VGPRs)
     default: return hipErrorInvalidValue;
   }
 }
