@@ -159,9 +159,11 @@ int poem_merge_reduce(const float* h2, const int32_t* view_offsets, float* m, in
                       void* stream);
 int poem_merge_finalize(const float* g, const float* y, const int32_t* view_offsets, float* out, int batch,
                         int nsample, int embed, void* stream);
-/* q (B,Q,C) k,v (B,S,C) -> ctx (B,Q,C); softmax(q k^T / sqrt(C/heads)) v per head.
- * The kernel splits the key axis over blocks when that balances the chip better; the partial (O, m, l) triples live in
- * `scratch` (poem_cross_attention_scratch_bytes() bytes, may be 0 -> scratch may be NULL). */
+/* q (B,Q,C) k,v (B,S,C) -> ctx (B,Q,C); softmax(q k^T / sqrt(C/heads)) v per head  (S % 32 == 0, C % 32 == 0,
+ * C/heads in {8,16,32,64,128,256}).  k and v are first re-laid into MFMA fragment images, then the key axis is processed
+ * in fixed chunks whose partial (O, m, l) triples are merged in fixed order (a sample's result does not depend on the
+ * batch it travels in); images and partials live in `scratch` (poem_cross_attention_scratch_bytes() bytes, 16-byte
+ * aligned).  Inside the decoder the projection GEMM writes the images itself. */
 size_t poem_cross_attention_scratch_bytes(int batch, int nq, int nk, int embed, int heads);
 int poem_cross_attention(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk,
                          int embed, int heads, void* scratch, size_t scratch_bytes, void* stream);

@@ -1,7 +1,8 @@
-// fp32 MFMA GEMM (Y = act(X W^T + b) + R) on packed weights, LayerNorm, small dense helpers.
-// gfx950 only.  Each wave owns a 64 x (32*NT) output tile and streams its A rows and the packed W fragments
-// straight from global/L2 (fp32 MFMA needs only 8 B/lane per 64 cycles, so no LDS staging is required);
-// operands for the next K-chunk are prefetched into registers while the current chunk's MFMAs issue.
+// fp32 MFMA GEMM (Y = act(X W^T + b) + R) on packed weights, LayerNorm, small dense helpers.  gfx950 only.
+// Two kernels: gemm_panel_kernel (the workhorse: W panel resident in LDS, persistent blocks streaming row groups,
+// per-segment output layouts) and gemm2_kernel (operands straight from global/L2, for the shapes the panel kernel does
+// not take; also the packed-activation layouts).  In both, operands of the next K-chunk are prefetched into registers
+// while the current chunk's MFMAs issue.
 #include "common.h"
 #include <algorithm>
 
