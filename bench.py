@@ -242,6 +242,43 @@ def main():
                            "traffic": traffic, "launches_timed": n_launch, "avg_launch_ms": va_ms / n_launch,
                            "share_of_step": va_ms / (dt * 1e3)}
     res["mpvpe_synthetic_gt_mm"] = meter.result() * 1e3
+    if world == 1 and not args.views_range:
+        # one stage earlier (SURVEY 8f rows N1 + N2): backbone pyramid -> feat_decode / heatmap_stage -> DLT -> head.  The
+        # HRNet backbone itself is out of scope; its output pyramid is synthetic.  Reported beside the headline, never as it.
+        try:
+            from poem_v2_amd.triangulation import triangulate_reference_joints
+            dec = pk.decode.FeatureDecoders(pk.weights.seeded_decoder_state_dict(0), dev)
+            pyr = [f.to(dev) for f in pk.inputs.synthetic_pyramid(args.batch * args.views, seed=1)]
+            # 2-D joints for the DLT: the batch's own joints projected into every view (the heat maps of random features
+            # carry no hand); the heat-map stage still runs and is consumed
+            vs = torch.repeat_interleave(torch.arange(args.batch), args.views).to(dev)
+            T = torch.linalg.inv(metas["cam_extr"])
+            pc = (T[:, None, :3, :3] @ rj[vs][..., None]).squeeze(-1) + T[:, None, :3, 3]
+            q2 = (metas["cam_intr"][:, None] @ pc[..., None]).squeeze(-1)
+            uv_true = (q2[..., :2] / q2[..., 2:]).contiguous()
+
+            def pstep():
+                f160 = dec.feat_decode(pyr)
+                uv = dec.heatmap_stage(pyr, 256, 256)
+                uvb = uv_true + 1e-3 * (uv - uv.mean(dim=1, keepdim=True))
+                rjp = triangulate_reference_joints(uvb, metas["cam_intr"], metas["cam_extr"], spec["views"])
+                return head(f160, metas, rjp)
+
+            with torch.no_grad():
+                for _ in range(2):
+                    pstep()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ksteps = max(2, args.steps // 2)
+                for _ in range(ksteps):
+                    pstep()
+                torch.cuda.synchronize()
+                pdt = (time.perf_counter() - t0) / ksteps
+            res["pyramid_scope"] = {"value": args.batch / pdt, "unit": "samples/s", "ms_per_step": pdt * 1e3,
+                                    "stages": "HRNet-shaped pyramid (synthetic) -> feat_decode + heatmap_stage (HIP) -> "
+                                              "ragged DLT (HIP) -> head"}
+        except Exception as e:   # informational: never fail the bench line on it
+            res["pyramid_scope"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and args.cpu_samples > 0:
         base, ref = cpu_baseline(C, batch, args.cpu_samples)
         res["cpu_baseline"] = base
