@@ -112,7 +112,15 @@ class POEM_Generalized_Head(nn.Module):
         assert int(np.sum(np.asarray(img_metas["master_id"]))) == 0, "only support master_id is 0"   # :750-751
         device = mlvl_feat.device
         inp_img_w, inp_img_h = img_metas["inp_img_shape"]                                 # upstream naming, :831
-        img_metas["inp_res"] = torch.tensor([inp_img_w, inp_img_h], dtype=torch.float32, device=device)   # :832-833
+        # :832-833 upstream.  Cached per (shape, device): building a device tensor from a Python list is a pageable H2D copy,
+        # which blocks the host until the stream reaches it -- i.e. until the previous forward has finished (the host
+        # could then never run ahead of the GPU: ~0.5-1 ms of idle GPU between consecutive forwards).
+        key = (int(inp_img_w), int(inp_img_h), str(device))
+        cache = getattr(self, "_inp_res_cache", None)
+        if cache is None or cache[0] != key:
+            cache = (key, torch.tensor([inp_img_w, inp_img_h], dtype=torch.float32, device=device))
+            self._inp_res_cache = cache
+        img_metas["inp_res"] = cache[1]
         assert mlvl_feat.shape[1] == self.in_channels
         if tuple(mlvl_feat.shape[-2:]) != self._feat_hw:
             self._feat_hw = tuple(int(v) for v in mlvl_feat.shape[-2:])
