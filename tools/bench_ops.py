@@ -22,8 +22,11 @@ def timeit(fn, n=20):
 
 
 def gemm_cases():
-    for (M, N, K) in [(131072, 256, 256), (25568, 256, 256), (1048576, 256, 256), (25568, 1024, 256), (25568, 256, 1024),
-                      (1048576, 128, 256)]:
+    shapes = [(131072, 256, 256), (25568, 256, 256), (1048576, 256, 256), (25568, 1024, 256), (25568, 256, 1024),
+              (1048576, 128, 256)]
+    if os.environ.get("POEM_GEMM_SHAPES"):
+        shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["POEM_GEMM_SHAPES"].split(",")]
+    for (M, N, K) in shapes:
         x = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) / math.sqrt(K)
         b = torch.randn(N, device=dev)
