@@ -5,6 +5,7 @@
 // while the current chunk's MFMAs issue.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 __global__ void pack_linear_kernel(const float* __restrict__ w, int N, int K, float4* __restrict__ out, int total) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,7 +196,9 @@ extern "C" hipError_t poem_launch_gemm2(const float* X, int ldx, const void* Wp,
                                         int ldr, float* Y, int ldy, int M, int N, int K, int act, int in_pa, int out_pa,
                                         hipStream_t s) {
   const int ntiles = (N + 31) / 32, mtiles = (M + 31) / 32;
-  const bool big = (long)mtiles * ntiles >= 4096 * 4;   // enough 32x32 tiles to fill the chip with 64x128 wave tiles
+  // 64x128 wave tiles (6 operand loads per 32 MFMAs instead of 3 per 8) once they fill at least 3/4 of the 1024 SIMDs
+  // (the K = 4C feed-forward output Linear at M = 25568: 800 wave tiles, 214 -> 164 us)
+  const bool big = (long)((mtiles + 1) / 2) * (ntiles / 4) >= 768;
   if (ntiles % 4 == 0) {
     if (big) return launch_gemm2_t<2, 4>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, in_pa, out_pa, s);
     return launch_gemm2_t<1, 2>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, in_pa, out_pa, s);
