@@ -30,6 +30,11 @@
  *   poem_reg_update           reg_branch second Linear + xyz residual (pt_metro_transformer.py:38)
  *   poem_triangulate_dlt      batch_triangulate_dlt_torch + the ragged per-sample loop (lib/utils/triangulation.py:5-45,
  *                             lib/models/POEM.py:284-299) -- the stage that produces reference_joints
+ *   poem_conv3x3 /            ConvBlock (Conv2d 3x3 + BatchNorm(eval) + ReLU, lib/models/bricks/conv.py:4-45) and the glue
+ *   poem_upsample2_concat_pad around it in PtEmbedMultiviewStereoV2.feat_decode / uv_decode (lib/models/POEM.py:167-211:
+ *   poem_pool_conv1x1_sigmoid F.interpolate x2 + torch.cat, max_pool2d + uv_out + sigmoid); poem_heatmap_uv is the read-out of
+ *   poem_heatmap_uv           heatmap_stage (POEM.py:213-222, integral_heatmap2d) -- the stage that produces the head's
+ *                             mlvl_feat and the per-view 2-D joints
  *   poem_pa_epe /             PAEval.feed + align_w_scale (lib/metrics/pa_eval.py:45-83,104-124) and _PCKMetric.feed
  *   poem_pck_accumulate       (lib/metrics/pck.py:36-96) -- device-side evaluation metrics
  *   poem_head_forward         POEM_Generalized_Head.forward + PtEmbedTRv4.forward (ptEmb_head.py:825-964,
