@@ -513,12 +513,12 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
     case 16: POEM_XATTN(16, 4); break;
     case 32: POEM_XATTN(32, 4); break;
     case 64:
-      if (wsel == 2) { POEM_XATTN(64, 2); }
-#ifdef POEM_LAB
-      else if (wsel == 1) { POEM_XATTN(64, 1); }
+#ifdef POEM_LAB   // other waves-per-SIMD shapes for tools/lab only (W = 4 spills; W = 1, 2 are within 3 % of W = 3)
+      if (wsel == 2) { POEM_XATTN(64, 2); break; }
+      if (wsel == 1) { POEM_XATTN(64, 1); break; }
+      if (wsel == 4) { POEM_XATTN(64, 4); break; }
 #endif
-      else if (wsel == 4) { POEM_XATTN(64, 4); }
-      else { POEM_XATTN(64, 3); }
+      POEM_XATTN(64, 3);
       break;
     case 128: POEM_XSTREAM(128, 2); break;
     case 256: POEM_XSTREAM(256, 1); break;
