@@ -503,6 +503,7 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
   hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
   int wsel = 0, map = 1, prio_rot = 0;
+  (void)wsel;
 #ifdef POEM_LAB
   if (const char* e = getenv("POEM_ATTN_PRIO")) prio_rot = atoi(e);
   if (const char* e = getenv("POEM_ATTN_W")) wsel = atoi(e);
