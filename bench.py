@@ -144,6 +144,9 @@ def main():
                     help="ragged batch: views per sample ~ U{LO..HI}, seed 5 (BASELINE configs[4]: --views-range 2 10 --batch 64)")
     ap.add_argument("--model", default="medium", choices=list(pk.weights.MODEL_EMBED))
     ap.add_argument("--cpu-samples", type=int, default=4, help="0 disables the CPU baseline leg")
+    ap.add_argument("--parametric", action="store_true",
+                    help="medium_MANO-style parametric tail (BASELINE configs[2]); MANO itself is licence-gated, the bench "
+                         "plugs a cheap device-side stand-in layer in its place")
     ap.add_argument("--overlap", type=int, default=1, help="0: issue every kernel on one stream (A/B of the side streams)")
     args = ap.parse_args()
 
@@ -163,10 +166,20 @@ def main():
     views = [args.views] * args.batch
     if args.views_range:
         views = np.random.RandomState(5 + rank).randint(args.views_range[0], args.views_range[1] + 1, size=args.batch).tolist()
-    spec = dict(embed=C, nsample=4096, views=views, seed=0, parametric=False)
-    head = pk.build_head(pk.configs.head_cfg(C, max_views=max(10, max(views))), data_preset=pk.CN({}))
-    head.load_state_dict(pk.weights.seeded_state_dict(C, seed=0), strict=False)
+    parametric = bool(args.parametric or args.model == "medium_MANO")
+    spec = dict(embed=C, nsample=4096, views=views, seed=0, parametric=parametric)
+    head = pk.build_head(pk.configs.head_cfg(C, parametric=parametric, max_views=max(10, max(views))), data_preset=pk.CN({}))
+    head.load_state_dict(pk.weights.seeded_state_dict(C, seed=0, parametric=parametric), strict=False)
     head.set_template(pk.inputs.synthetic_template(1234))
+    if parametric:
+        tmpl = pk.inputs.synthetic_template(1234).to(dev)
+
+        def mano_standin(pose, betas):      # (B,48), (B,10) -> verts (B,778,3), joints (B,21,3); NOT a MANO implementation
+            s_ = 1.0 + 0.01 * betas.sum(-1).view(-1, 1, 1)
+            off = 0.001 * pose.reshape(pose.shape[0], -1).sum(-1).view(-1, 1, 1)
+            return tmpl[21:][None] * s_ + off, tmpl[:21][None] * s_ + off
+
+        head.set_mano_layer(mano_standin)
     head = head.to(dev).eval()
     batch = pk.inputs.synthetic_batch(spec["views"], seed=1000 + rank)        # every rank its own shard of samples
     feat = batch["mlvl_feat"].to(dev)
@@ -242,7 +255,7 @@ def main():
                            "traffic": traffic, "launches_timed": n_launch, "avg_launch_ms": va_ms / n_launch,
                            "share_of_step": va_ms / (dt * 1e3)}
     res["mpvpe_synthetic_gt_mm"] = meter.result() * 1e3
-    if world == 1 and not args.views_range:
+    if world == 1 and not args.views_range and not parametric:
         # one stage earlier (SURVEY 8f rows N1 + N2): backbone pyramid -> feat_decode / heatmap_stage -> DLT -> head.  The
         # HRNet backbone itself is out of scope; its output pyramid is synthetic.  Reported beside the headline, never as it.
         try:
@@ -279,7 +292,7 @@ def main():
                                               "ragged DLT (HIP) -> head"}
         except Exception as e:   # informational: never fail the bench line on it
             res["pyramid_scope"] = {"error": repr(e)[:200]}
-    if rank == 0 and world == 1 and args.cpu_samples > 0:
+    if rank == 0 and world == 1 and args.cpu_samples > 0 and not parametric:
         base, ref = cpu_baseline(C, batch, args.cpu_samples)
         res["cpu_baseline"] = base
         got = preds["all_coords_preds"][:, :args.cpu_samples].cpu()
