@@ -162,12 +162,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   if (tid < 32 * P) {
     const int p = tid >> 5, jj = tid & 31;
     const int qi = min(i0 + p, A.Q - 1);
+#ifdef POEM_VA_NOLOADS0   // tools/lab only: upper bound of what prefetching stage 0's dependent loads could buy
+    const int id = (qi * 37 + jj * 101) % A.NS;
+    dl[tid * 3 + 0] = 0.01f * (float)jj; dl[tid * 3 + 1] = 0.02f * (float)(qi & 7); dl[tid * 3 + 2] = 0.03f;
+    (void)0;
+#else
     const int id = A.shared_idx ? A.idx[jj] : A.idx[((size_t)b * A.Q + qi) * 32 + jj];
     const float* qx = A.query_xyz + ((size_t)b * A.Q + qi) * 3;
     const float* nx = A.anchor_xyz ? A.anchor_xyz + jj * 3 : A.src_xyz + ((size_t)b * A.NS + id) * 3;
     dl[tid * 3 + 0] = qx[0] - nx[0];
     dl[tid * 3 + 1] = qx[1] - nx[1];
     dl[tid * 3 + 2] = qx[2] - nx[2];
+#endif
     sidx[tid] = id;
     voffs[tid] = (int)(((unsigned)b * (unsigned)A.NS + (unsigned)id) * (unsigned)(A.ldv * 4));
   }
