@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--parametric", action="store_true",
                     help="medium_MANO-style parametric tail (BASELINE configs[2]); MANO itself is licence-gated, the bench "
                          "plugs a cheap device-side stand-in layer in its place")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end scope leg (images -> HRNet on PyTorch-ROCm -> verts)")
     ap.add_argument("--overlap", type=int, default=1, help="0: issue every kernel on one stream (A/B of the side streams)")
     args = ap.parse_args()
 
@@ -292,6 +293,45 @@ def main():
                                               "ragged DLT (HIP) -> head"}
         except Exception as e:   # informational: never fail the bench line on it
             res["pyramid_scope"] = {"error": repr(e)[:200]}
+        # END-TO-END scope (SURVEY 8d "E2E"): 256x256 images resident in HBM -> HRNet-W40 on plain PyTorch-ROCm (MIOpen; the
+        # backbone is outside the hot path and has no kernels of ours) -> the same pyramid-scope chain -> verts.
+        if not args.no_e2e and "error" not in res["pyramid_scope"]:
+            try:
+                from poem_v2_amd.backbone import HRNet, seeded_hrnet_state_dict
+                net = HRNet(state_dict=seeded_hrnet_state_dict(0), device=dev).to(dev)
+                img = pk.inputs.synthetic_images(args.batch * args.views, seed=1).to(dev)
+
+                def estep():
+                    pyr_ = net(img)
+                    f160 = dec.feat_decode(pyr_)
+                    uv = dec.heatmap_stage(pyr_, 256, 256)
+                    uvb = uv_true + 1e-3 * (uv - uv.mean(dim=1, keepdim=True))
+                    rjp = triangulate_reference_joints(uvb, metas["cam_intr"], metas["cam_extr"], spec["views"])
+                    return head(f160, metas, rjp)
+
+                with torch.no_grad():
+                    estep()                                  # MIOpen picks / builds its solvers here
+                    estep()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    esteps = 3
+                    for _ in range(esteps):
+                        estep()
+                    torch.cuda.synchronize()
+                    edt = (time.perf_counter() - t0) / esteps
+                    t0 = time.perf_counter()
+                    for _ in range(esteps):
+                        net(img)
+                    torch.cuda.synchronize()
+                    bdt = (time.perf_counter() - t0) / esteps
+                res["e2e_scope"] = {"value": args.batch / edt, "unit": "samples/s", "ms_per_step": edt * 1e3,
+                                    "backbone_ms": bdt * 1e3,
+                                    "stages": f"{args.batch * args.views} synthetic 256x256 images in HBM -> HRNet-W40 (PyTorch-ROCm "
+                                              "eager / MIOpen fp32, BatchNorm folded) -> feat_decode + heatmap_stage (HIP) -> "
+                                              "ragged DLT (HIP) -> head (HIP)"}
+                del net, img
+            except Exception as e:
+                res["e2e_scope"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and args.cpu_samples > 0 and not parametric:
         base, ref = cpu_baseline(C, batch, args.cpu_samples)
         res["cpu_baseline"] = base

@@ -37,6 +37,7 @@
  *                             mlvl_feat and the per-view 2-D joints
  *   poem_pa_epe /             PAEval.feed + align_w_scale (lib/metrics/pa_eval.py:45-83,104-124) and _PCKMetric.feed
  *   poem_pck_accumulate       (lib/metrics/pck.py:36-96) -- device-side evaluation metrics
+ *   poem_mano_to_openpose     mano_to_openpose (lib/utils/transform.py:836-872) -- joints from mesh for the metrics (N3)
  *   poem_head_forward         POEM_Generalized_Head.forward + PtEmbedTRv4.forward (ptEmb_head.py:825-964,
  *                             lib/models/layers/ptEmb_transformer.py:371-376)
  */
@@ -218,6 +219,10 @@ int poem_pool_conv1x1_sigmoid(const float* x, const float* w, const float* bias,
 int poem_pa_epe(const float* pred, const float* gt, float* out, int batch, int npoints, void* stream);
 int poem_pck_accumulate(const float* pred, const float* gt, int batch, int npoints, double val_min, double val_max,
                         int steps, uint32_t* counts, double* dist_sum, uint32_t* n, float* dist_out, void* stream);
+/* mano_to_openpose (lib/utils/transform.py:836-872; called on predicted and ground-truth vertices by testing_step,
+ * lib/models/POEM.py:602-603): j_regressor (16,nverts) MANO's th_J_regressor, verts (B,nverts,3) -> joints (B,21,3) in
+ * OpenPose order (16 regressed joints + the 5 finger-tip vertices, re-ordered).  nverts must be 778. */
+int poem_mano_to_openpose(const float* j_regressor, const float* verts, float* joints, int batch, int nverts, void* stream);
 /* idx (B,Q,32) int32: 32 nearest src points per query, ascending squared L2, ties -> lower index. */
 int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream);
 /* Vector attention core.  q (B,Q,C); k,v (B,NS,C) gathered by idx; idx (B,Q,32) or (32) when shared_idx!=0;

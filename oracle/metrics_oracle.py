@@ -53,3 +53,32 @@ def pck_measures(pred, gt, val_min, val_max, steps):
     epe = d.mean(0)
     return {"epe_mean_per_kp": epe, "pck_curve_per_kp": curve, "auc_per_kp": auc, "epe_mean_all": float(np.mean(epe)),
             "auc_all": float(np.mean(auc)), "pck_002": float(np.mean([(d[:, k] <= 0.02).mean() for k in range(d.shape[1])]))}
+
+
+MANO_TIP_VERTICES = (744, 320, 443, 555, 672)          # CONST.MANO_KPID_2_VERTICES, lib/utils/misc.py:76-82
+OPENPOSE_FROM_MANO = (0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20)
+
+
+def mano_to_openpose(J_regressor, mano_verts):
+    """lib/utils/transform.py:836-872: regressed joints (16,778)@(B,778,3), the five tip vertices appended, re-ordered."""
+    J = np.asarray(J_regressor, dtype=np.float32)
+    V = np.asarray(mano_verts, dtype=np.float32)
+    joints = np.einsum("jv,bvd->bjd", J.astype(np.float64), V.astype(np.float64)).astype(np.float32)
+    tips = V[:, list(MANO_TIP_VERTICES)]
+    return np.concatenate([joints, tips], axis=1)[:, list(OPENPOSE_FROM_MANO)]
+
+
+def synthetic_j_regressor(seed=11):
+    """Seeded stand-in for MANO's th_J_regressor (licence-gated): (16,778), rows non-negative, ~20 non-zeros each, sum 1."""
+    rng = np.random.RandomState(seed)
+    J = np.zeros((16, 778), dtype=np.float32)
+    for r in range(16):
+        cols = rng.choice(778, size=20, replace=False)
+        w = rng.rand(20).astype(np.float32)
+        J[r, cols] = w / w.sum()
+    return J
+
+
+def synthetic_mano_verts(B=3, seed=11):
+    rng = np.random.RandomState(seed + 1)
+    return (0.08 * rng.randn(B, 778, 3) + np.array([0.0, 0.0, 0.6])).astype(np.float32)

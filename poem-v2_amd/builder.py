@@ -88,6 +88,8 @@ def build_from_cfg(cfg, registry, **kwargs):
 
 HEAD = Registry("head")
 TRANSFORMER = Registry("Transformer")
+BACKBONE = Registry("backbone")          # lib/utils/builder.py:307-320 upstream
+MODEL = Registry("model")
 
 
 def build_head(cfg, **kwargs):
@@ -96,3 +98,11 @@ def build_head(cfg, **kwargs):
 
 def build_transformer(cfg, **kwargs):
     return build_from_cfg(cfg, TRANSFORMER, **kwargs)
+
+
+def build_backbone(cfg, **kwargs):
+    return build_from_cfg(cfg, BACKBONE, **kwargs)
+
+
+def build_model(cfg, **kwargs):
+    return build_from_cfg(cfg, MODEL, **kwargs)

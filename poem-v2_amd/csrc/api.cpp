@@ -51,6 +51,8 @@ hipError_t poem_launch_dlt(const float* uv, const float* intr, const float* mat,
 hipError_t poem_launch_pa_epe(const float* pred, const float* gt, float* out, int B, int P, hipStream_t s);
 hipError_t poem_launch_pck_accumulate(const float* pred, const float* gt, int B, int P, double vmin, double vmax, int steps,
                                       unsigned int* counts, double* sum, unsigned int* n, float* dist_out, hipStream_t s);
+hipError_t poem_launch_mano_to_openpose(const float* jreg, const float* verts, float* joints, int B, int nverts,
+                                        hipStream_t s);
 hipError_t poem_launch_heatmap_uv(const float* hmap, float* uv, int maps, int hh, int hw, float img_w, float img_h,
                                   hipStream_t s);
 size_t poem_conv3x3_packed_floats(int Cout, int Cin);
@@ -901,6 +903,13 @@ int poem_pck_accumulate(const float* pred, const float* gt, int batch, int npoin
   if (!pred || !gt || !counts || !dist_sum || !n || batch <= 0 || npoints <= 0 || steps <= 0) return POEM_E_ARG;
   HIPCHK(poem_launch_pck_accumulate(pred, gt, batch, npoints, val_min, val_max, steps, counts, dist_sum, n, dist_out,
                                     (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_mano_to_openpose(const float* j_regressor, const float* verts, float* joints, int batch, int nverts, void* stream) {
+  if (!j_regressor || !verts || !joints || batch <= 0) return POEM_E_ARG;
+  if (nverts != 778) return POEM_E_UNSUPPORTED;          // the tip vertex ids are MANO's
+  HIPCHK(poem_launch_mano_to_openpose(j_regressor, verts, joints, batch, nverts, (hipStream_t)stream));
   return POEM_OK;
 }
 

@@ -124,3 +124,40 @@ extern "C" hipError_t poem_launch_pck_accumulate(const float* pred, const float*
                      sum, n, dist_out);
   return hipGetLastError();
 }
+
+// ---- MANO vertices -> OpenPose-ordered joints ----------------------------------------------------------------------
+// mano_to_openpose (lib/utils/transform.py:836-872): 16 joints = J_regressor (16,778) . verts, 5 finger tips = vertices
+// {744, 320, 443, 555, 672} (CONST.MANO_KPID_2_VERTICES, lib/utils/misc.py:76-82), concatenated and re-ordered to the
+// OpenPose numbering.  testing_step applies it to predicted AND ground-truth vertices of every batch (POEM.py:602-603).
+// One wave per (sample, output joint); lane-strided partial sums in a fixed order -> batch-independent results.
+__constant__ int kOpenposeFromMano[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
+__constant__ int kTipVertex[5] = {744, 320, 443, 555, 672};
+
+__global__ __launch_bounds__(64) void mano_to_openpose_kernel(const float* __restrict__ jreg, const float* __restrict__ verts,
+                                                              float* __restrict__ joints, int nverts) {
+  const int b = blockIdx.x / 21, o = blockIdx.x % 21, lane = threadIdx.x;
+  const int src = kOpenposeFromMano[o];
+  const float* v = verts + (size_t)b * nverts * 3;
+  float* out = joints + ((size_t)b * 21 + o) * 3;
+  if (src >= 16) {
+    if (lane < 3) out[lane] = v[kTipVertex[src - 16] * 3 + lane];
+    return;
+  }
+  const float* w = jreg + (size_t)src * nverts;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int i = lane; i < nverts; i += 64) {
+    const float wi = w[i];
+    a0 = fmaf(wi, v[i * 3 + 0], a0); a1 = fmaf(wi, v[i * 3 + 1], a1); a2 = fmaf(wi, v[i * 3 + 2], a2);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64);
+  }
+  if (lane == 0) { out[0] = a0; out[1] = a1; out[2] = a2; }
+}
+
+extern "C" hipError_t poem_launch_mano_to_openpose(const float* jreg, const float* verts, float* joints, int B, int nverts,
+                                                   hipStream_t s) {
+  hipLaunchKernelGGL(mano_to_openpose_kernel, dim3(B * 21), dim3(64), 0, s, jreg, verts, joints, nverts);
+  return hipGetLastError();
+}

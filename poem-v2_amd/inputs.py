@@ -66,3 +66,9 @@ def synthetic_pyramid(views, seed=0):
     (BN,40,64,64), (BN,80,32,32), (BN,160,16,16), (BN,320,8,8), seeded N(0,1)."""
     g = torch.Generator().manual_seed(2000 + seed)
     return [torch.randn(views, c, r, r, generator=g) for c, r in zip((40, 80, 160, 320), (64, 32, 16, 8))]
+
+
+def synthetic_images(views, seed=0, img=256):
+    """(BN,3,img,img) seeded N(0, 0.3^2) "images" for the end-to-end timing scope."""
+    g = torch.Generator().manual_seed(3000 + seed)
+    return 0.3 * torch.randn(views, 3, img, img, generator=g)

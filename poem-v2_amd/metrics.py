@@ -181,3 +181,21 @@ class Vert3DPCK(_PCKMetric):
         if self.eval_type not in self._keys:
             raise ValueError(f"Unknown eval_type {self.eval_type} in {type(self).__name__}")
         super().__init__(device=device, **cfg)
+
+
+def mano_to_openpose(J_regressor, mano_verts):
+    """MANO vertices (B,778,3) -> joints (B,21,3) in OpenPose order: the reference function of the same name
+    (lib/utils/transform.py:836-872 upstream), which ``testing_step`` applies to predicted and ground-truth vertices
+    before the joint metrics (lib/models/POEM.py:602-603).  ``J_regressor`` is MANO's ``th_J_regressor`` (16,778) -- an
+    input, the asset is licence-gated.  One launch on the device; no CPU fallback."""
+    from . import hip
+    if not mano_verts.is_cuda:
+        raise RuntimeError("mano_to_openpose runs on the MI355X HIP path only (no CPU fallback)")
+    v = _dev32(mano_verts, mano_verts.device)
+    w = _dev32(J_regressor, mano_verts.device)
+    if tuple(w.shape) != (16, 778) or v.dim() != 3 or tuple(v.shape[1:]) != (778, 3):
+        raise ValueError("J_regressor must be (16,778) and mano_verts (B,778,3)")
+    out = torch.empty(v.shape[0], 21, 3, dtype=torch.float32, device=v.device)
+    hip.check(hip.lib().poem_mano_to_openpose(hip.ptr(w), hip.ptr(v), hip.ptr(out), v.shape[0], 778, hip.stream()),
+              "poem_mano_to_openpose")
+    return out

@@ -335,8 +335,62 @@ def run_decode():
     print("decode:", {k: getattr(v, "shape", None) for k, v in rec.items() if k != "meta"})
 
 
+def run_openpose():
+    """Output of the reference's own mano_to_openpose (lib/utils/transform.py:836-872) on the seeded regressor / vertices
+    of oracle/metrics_oracle.py."""
+    rh.setup()
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import metrics_oracle as mo
+    from lib.utils.transform import mano_to_openpose
+    J, V = mo.synthetic_j_regressor(11), mo.synthetic_mano_verts(3, 11)
+    out = mano_to_openpose(torch.from_numpy(J), torch.from_numpy(V)).numpy()
+    os.chdir(ROOT)
+    meta = dict(seed=11, note="J = metrics_oracle.synthetic_j_regressor(11); verts = metrics_oracle.synthetic_mano_verts(3, 11)")
+    np.savez_compressed(os.path.join(HERE, "openpose.npz"), joints=out,
+                        meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+    print("openpose:", out.shape)
+
+
+def run_backbone():
+    """Golden vectors of the reference's own HRNet (lib/models/backbones/hrnet.py, built inside the full reference model
+    under the harness) with the seeded weights of poem_v2_amd.backbone.seeded_hrnet_state_dict: pins the E2E scope's
+    PyTorch backbone (key names, shapes, arithmetic) to the reference's.  Input: 2 seeded 64x64 images."""
+    import yaml
+    sys.path.insert(0, ROOT)
+    import poem_v2_amd  # noqa: F401
+    from poem_v2_amd import backbone as bb
+    CN, _ = rh.setup()
+    with open(os.path.join(rh.REF_ROOT, "config/release/train_medium.yaml")) as f:
+        y = yaml.safe_load(f)
+    from lib.utils import builder
+    cfg = CN(y)
+    model = builder.build_model(cfg.MODEL, data_preset=cfg.DATA_PRESET, train=cfg.TRAIN)
+    model.eval()
+    net = model.img_backbone
+    seed = 5
+    sd = bb.seeded_hrnet_state_dict(seed)
+    ref_sd = net.state_dict()
+    for k, v in sd.items():
+        assert k in ref_sd and tuple(ref_sd[k].shape) == tuple(v.shape), f"key/shape mismatch: {k}"
+    dead = sorted({k.split(".")[0] for k in ref_sd if k not in sd and not k.endswith("num_batches_tracked")})
+    assert dead == ["classifier", "downsamp_modules", "final_layer", "incre_modules"], dead
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    img = 0.3 * torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(seed))
+    with torch.no_grad():
+        ys = net(img.clone())
+    os.chdir(ROOT)
+    meta = dict(seed=seed, note="weights = poem_v2_amd.backbone.seeded_hrnet_state_dict(seed); input = 0.3 * "
+                "torch.randn(2,3,64,64, generator=manual_seed(seed)); four pyramid levels stored in full",
+                live_keys=len(sd), dead_groups=dead)
+    rec = {f"level{i}": y.numpy() for i, y in enumerate(ys)}
+    rec["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "backbone.npz"), **rec)
+    print("backbone:", {k: getattr(v, "shape", None) for k, v in rec.items() if k != "meta"})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or list(CASES) + ["mepe", "evalcfg", "dlt", "metrics", "decode"]
+    which = sys.argv[1:] or list(CASES) + ["mepe", "evalcfg", "dlt", "metrics", "decode", "backbone", "openpose"]
     torch.set_num_threads(8)
     for n in which:
         if n == "mepe":
@@ -349,5 +403,9 @@ if __name__ == "__main__":
             run_metrics()
         elif n == "decode":
             run_decode()
+        elif n == "backbone":
+            run_backbone()
+        elif n == "openpose":
+            run_openpose()
         else:
             run_case(n, CASES[n])

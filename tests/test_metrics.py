@@ -102,3 +102,36 @@ def test_device_pck_matches_reference():
         Joint3DPCK(device="cuda:0", EVAL_TYPE="nope", **cfg)
     with pytest.raises(RuntimeError):
         Joint3DPCK(device="cpu", EVAL_TYPE="joints_3d", **cfg).feed({"pred_joints_3d": pred[:, :21]}, {"master_joints_3d": gt[:, :21]})
+
+
+# ---- mano_to_openpose (joints from the mesh, lib/utils/transform.py:836-872) ----------------------------------------
+def _openpose_golden():
+    return np.load(os.path.join(GOLDEN, "openpose.npz"))["joints"]
+
+
+def test_oracle_mano_to_openpose_matches_reference():
+    ref = _openpose_golden()
+    out = mo.mano_to_openpose(mo.synthetic_j_regressor(11), mo.synthetic_mano_verts(3, 11))
+    assert out.shape == (3, 21, 3)
+    assert np.max(np.abs(out - ref)) < 2e-7
+    # tips are exact copies of vertices at the OpenPose tip slots 4, 8, 12, 16, 20
+    V = mo.synthetic_mano_verts(3, 11)
+    assert np.array_equal(out[:, [4, 8, 12, 16, 20]], V[:, list(mo.MANO_TIP_VERTICES)])
+
+
+@pytest.mark.gpu
+def test_device_mano_to_openpose_matches_reference():
+    from poem_v2_amd.metrics import mano_to_openpose
+    ref = _openpose_golden()
+    J, V = mo.synthetic_j_regressor(11), mo.synthetic_mano_verts(3, 11)
+    out = mano_to_openpose(torch.from_numpy(J).cuda(), torch.from_numpy(V).cuda()).cpu().numpy()
+    assert np.max(np.abs(out - ref)) < 2e-7                                  # metres
+    assert np.max(np.abs(out - mo.mano_to_openpose(J, V))) < 2e-7
+    assert np.array_equal(out[:, [4, 8, 12, 16, 20]], V[:, list(mo.MANO_TIP_VERTICES)])
+    # a sample's joints do not depend on the batch it sits in (bit-exact), full-size batch
+    Vb = mo.synthetic_mano_verts(256, 5)
+    big = mano_to_openpose(torch.from_numpy(J).cuda(), torch.from_numpy(Vb).cuda())
+    one = mano_to_openpose(torch.from_numpy(J).cuda(), torch.from_numpy(Vb[100:101]).cuda())
+    assert torch.equal(big[100:101], one)
+    with pytest.raises(RuntimeError):
+        mano_to_openpose(torch.from_numpy(J), torch.from_numpy(V))           # CPU tensors: no fallback
