@@ -67,13 +67,16 @@ def test_model_images_to_preds_matches_staged_oracles():
     model.load_parts(bsd, dsd, hsd, template=po.synthetic_template(1234))
     batch = {"image": img, "target_cam_intr": b["img_metas"]["cam_intr"], "target_cam_extr": b["img_metas"]["cam_extr"],
              "master_id": [0] * len(views), "cam_view_num": np.asarray(views)}
-    preds = model(batch, 0, mode="test")
+    seen, backbone = {}, model.extract_img_feat
+    model.extract_img_feat = lambda x: seen.setdefault("pyr", backbone(x))     # the pyramid THIS forward used (MIOpen may
+    preds = model(batch, 0, mode="test")                                       # pick other solvers on a later call)
+    del model.extract_img_feat
     for k in ("all_coords_preds", "pred_joints_3d", "pred_verts_3d", "pred_joints_3d_rel", "pred_verts_3d_rel",
               "pred_joints_uv", "pred_ref_joints_3d"):
         assert k in preds
     assert tuple(preds["pred_verts_3d"].shape) == (2, 778, 3) and tuple(preds["pred_joints_uv"].shape) == (5, 21, 2)
     # stage by stage, each stage's oracle fed with the device's own input to that stage
-    pyr_d = model.extract_img_feat(img.cuda())
+    pyr_d = seen["pyr"]
     pyr_c = bb.HRNet(state_dict=bsd)(img)
     for yd, yc in zip(pyr_d, pyr_c):                                   # MIOpen vs CPU convolutions, ~100 layers deep
         assert float((yd.cpu() - yc).abs().max()) < 1e-3 * float(yc.abs().max())
@@ -82,8 +85,20 @@ def test_model_images_to_preds_matches_staged_oracles():
     mlvl_d = model.decoders.feat_decode(pyr_d)
     mlvl = do.feat_decode(pyr, dsd_o)
     assert float((mlvl_d.cpu() - mlvl).abs().max()) < 2e-5 * float(mlvl.abs().max())
+    hm_d, hm = model.decoders.uv_decode(pyr_d).cpu(), do.uv_decode(pyr, dsd_o)
+    e_hm = float((hm_d - hm).abs().max())
+    # tests/test_decode.py's bar (2e-5 on logits of order 1) relative to this pyramid's logit scale: the HRNet outputs are
+    # not unit-scale, and the rounding of the chained K <= 4320 contractions in front of the sigmoid scales with them
+    logit_scale = max(1.0, float(torch.logit(hm.double().clamp(1e-12, 1 - 1e-12)).abs().max()))
+    assert e_hm < 2e-5 * logit_scale, (e_hm, logit_scale)
+    # the read-out alone (device heat maps through the oracle's expectation): summation order only
+    uv_same_hm = do.heatmap_to_uv(hm_d, 256, 256)
+    assert float((preds["pred_joints_uv"].cpu() - uv_same_hm).abs().max()) < 5e-4      # pixels
+    # whole stage: u = sum(x h) / sum(h), so |du| <= 2 e_hm sum|x - u| / sum(h) <= 2 e_hm * 256 * HW / sum(h); these
+    # seeded heat maps are nearly flat (sigmoid of small logits), which is the worst case for that bound
     uv = do.heatmap_stage(pyr, dsd_o, 256, 256)
-    assert float((preds["pred_joints_uv"].cpu() - uv).abs().max()) < 5e-4              # pixels
+    bound = 2.0 * e_hm * 256.0 * float((hm.shape[-1] * hm.shape[-2] / hm.sum(dim=(-1, -2))).max()) + 5e-4
+    assert float((preds["pred_joints_uv"].cpu() - uv).abs().max()) < min(bound, 2e-2)
     rj = dlt_oracle.triangulate_reference_joints(preds["pred_joints_uv"].cpu(), b["img_metas"]["cam_intr"],
                                                  b["img_metas"]["cam_extr"], views)
     assert float((preds["pred_ref_joints_3d"].cpu() - rj).abs().max()) < 5e-6          # metres
@@ -91,7 +106,7 @@ def test_model_images_to_preds_matches_staged_oracles():
     ob = dict(b)
     ob["mlvl_feat"] = mlvl_d.cpu()
     ob["reference_joints"] = preds["pred_ref_joints_3d"].cpu()
-    ref = run_oracle(spec_cfg, hsd, oracle_consts(4096), ob)
+    ref = run_oracle(spec_cfg, hsd, oracle_consts(4096), ob)["all_coords_preds"]
     got = preds["all_coords_preds"].cpu()
     mpvpe_mm = float((got[-1, :, 21:] - ref[-1, :, 21:]).norm(dim=-1).mean()) * 1e3
     assert mpvpe_mm < 1e-3, mpvpe_mm
