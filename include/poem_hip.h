@@ -38,6 +38,9 @@
  *   poem_pa_epe /             PAEval.feed + align_w_scale (lib/metrics/pa_eval.py:45-83,104-124) and _PCKMetric.feed
  *   poem_pck_accumulate       (lib/metrics/pck.py:36-96) -- device-side evaluation metrics
  *   poem_mano_to_openpose     mano_to_openpose (lib/utils/transform.py:836-872) -- joints from mesh for the metrics (N3)
+ *   poem_warp_affine          cv2.warpAffine + colour jitter + to_tensor / normalize of SimpleTransform2D.__call__
+ *                             (lib/utils/transform.py:153-170) and the mirror warp of process_data_item
+ *                             (lib/data_wds/multiview_wds.py:112-118) -- the image side of the input pipeline
  *   poem_head_forward         POEM_Generalized_Head.forward + PtEmbedTRv4.forward (ptEmb_head.py:825-964,
  *                             lib/models/layers/ptEmb_transformer.py:371-376)
  */
@@ -223,6 +226,15 @@ int poem_pck_accumulate(const float* pred, const float* gt, int batch, int npoin
  * lib/models/POEM.py:602-603): j_regressor (16,nverts) MANO's th_J_regressor, verts (B,nverts,3) -> joints (B,21,3) in
  * OpenPose order (16 regressed joints + the 5 finger-tip vertices, re-ordered).  nverts must be 778. */
 int poem_mano_to_openpose(const float* j_regressor, const float* verts, float* joints, int batch, int nverts, void* stream);
+/* Crop / warp / normalise every view of a batch in one launch (replaces the per-view host chain of
+ * lib/utils/transform.py:153-170: cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT 0) -> colour jitter -> to_tensor ->
+ * normalize(0.5, 1)).  src: the raw uint8 HxWx3 images back to back in one device blob; src_offsets (views) byte offset
+ * of each image; src_hw (views,2) = (height, width); m_inv (views,6) fp64 = the INVERSE (destination -> source) 2x3 map,
+ * i.e. what cv::warpAffine derives from the matrix it is given; gain (views,3) fp64 per-channel colour gains or NULL.
+ * Outputs (either may be NULL, not both): out_f32 (views,3,out_h,out_w) = p / 255 - 0.5; out_u8 (views,out_h,out_w,3).
+ * Arithmetic is OpenCV's 8-bit fixed-point bilinear path (1/32-pixel coordinates, 15-bit weights): integer, bit-exact. */
+int poem_warp_affine(const uint8_t* src, const int64_t* src_offsets, const int32_t* src_hw, const double* m_inv,
+                     const double* gain, float* out_f32, uint8_t* out_u8, int views, int out_h, int out_w, void* stream);
 /* idx (B,Q,32) int32: 32 nearest src points per query, ascending squared L2, ties -> lower index. */
 int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream);
 /* Vector attention core.  q (B,Q,C); k,v (B,NS,C) gathered by idx; idx (B,Q,32) or (32) when shared_idx!=0;

@@ -53,6 +53,9 @@ hipError_t poem_launch_pck_accumulate(const float* pred, const float* gt, int B,
                                       unsigned int* counts, double* sum, unsigned int* n, float* dist_out, hipStream_t s);
 hipError_t poem_launch_mano_to_openpose(const float* jreg, const float* verts, float* joints, int B, int nverts,
                                         hipStream_t s);
+hipError_t poem_launch_warp_affine(const unsigned char* src, const long long* src_off, const int* src_hw,
+                                   const double* minv, const double* gain, float* out_f32, unsigned char* out_u8, int views,
+                                   int OH, int OW, hipStream_t s);
 hipError_t poem_launch_heatmap_uv(const float* hmap, float* uv, int maps, int hh, int hw, float img_w, float img_h,
                                   hipStream_t s);
 size_t poem_conv3x3_packed_floats(int Cout, int Cin);
@@ -910,6 +913,16 @@ int poem_mano_to_openpose(const float* j_regressor, const float* verts, float* j
   if (!j_regressor || !verts || !joints || batch <= 0) return POEM_E_ARG;
   if (nverts != 778) return POEM_E_UNSUPPORTED;          // the tip vertex ids are MANO's
   HIPCHK(poem_launch_mano_to_openpose(j_regressor, verts, joints, batch, nverts, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_warp_affine(const uint8_t* src, const int64_t* src_offsets, const int32_t* src_hw, const double* m_inv,
+                     const double* gain, float* out_f32, uint8_t* out_u8, int views, int out_h, int out_w, void* stream) {
+  if (!src || !src_offsets || !src_hw || !m_inv || (!out_f32 && !out_u8) || views <= 0 || out_h <= 0 || out_w <= 0)
+    return POEM_E_ARG;
+  if (views > 65535 || out_h > 65535) return POEM_E_UNSUPPORTED;          // grid y / z limits
+  HIPCHK(poem_launch_warp_affine(src, (const long long*)src_offsets, src_hw, m_inv, gain, out_f32, out_u8, views, out_h,
+                                 out_w, (hipStream_t)stream));
   return POEM_OK;
 }
 

@@ -70,6 +70,7 @@ SIGNATURES = {
     "poem_pool_conv1x1_sigmoid": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_pa_epe": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "poem_mano_to_openpose": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "poem_warp_affine": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "poem_pck_accumulate": (_i, [_vp, _vp, _i, _i, ctypes.c_double, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp]),
     "poem_knn": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "poem_vector_attention": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
