@@ -332,6 +332,59 @@ def main():
                 del net, img
             except Exception as e:
                 res["e2e_scope"] = {"error": repr(e)[:200]}
+    # INPUT scope: the per-view crop / warp / normalise of the raw camera images, one launch per batch.
+    # The boundary hands over host buffers here (decoded images), so both rates are given: the kernel alone (HIP events)
+    # against HBM, and the whole warp_views call (pinned staging fill + one H2D copy + launch).
+    if rank == 0 and world == 1 and not args.no_e2e:
+        try:
+            import numpy as _np
+            g = _np.random.default_rng(0)
+            nv = args.batch * args.views
+            raws = [g.integers(0, 256, size=(480, 640, 3), dtype=_np.uint8) for _ in range(8)]
+            imgs = [raws[i % 8] for i in range(nv)]
+            Ms = [_np.array([[1.28, 0.0, -150.0 - (i % 7)], [0.0, 1.28, -90.0 - (i % 5)]], _np.float32) for i in range(nv)]
+            for _ in range(2):
+                pk.transform.warp_views(imgs, Ms, (256, 256), device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                pk.transform.warp_views(imgs, Ms, (256, 256), device=dev)
+            torch.cuda.synchronize()
+            call_ms = (time.perf_counter() - t0) / reps * 1e3
+            # kernel alone: parameters + images already resident
+            import ctypes as _ct
+            head_b = (nv * 88 + 15) & ~15
+            blob = torch.zeros(head_b + nv * 480 * 640 * 3, dtype=torch.uint8, device=dev)
+            hb = _np.zeros(head_b, _np.uint8)
+            hb[0:8 * nv].view(_np.int64)[:] = _np.arange(nv) * 480 * 640 * 3
+            hb[8 * nv:16 * nv].view(_np.int32)[:] = _np.tile(_np.array([480, 640], _np.int32), nv)
+            hb[16 * nv:64 * nv].view(_np.float64)[:] = _np.asarray([pk.transform.invert_affine(m) for m in Ms]).reshape(-1)
+            blob[:head_b] = torch.from_numpy(hb).to(dev)
+            blob[head_b:] = torch.from_numpy(_np.concatenate([im.reshape(-1) for im in imgs])).to(dev)
+            outw = torch.empty(nv, 3, 256, 256, device=dev)
+            base = blob.data_ptr()
+            L = pk.hip.lib()
+
+            def wk():
+                pk.hip.check(L.poem_warp_affine(base + head_b, base, base + 8 * nv, base + 16 * nv, None, outw.data_ptr(), None,
+                                                nv, 256, 256, pk.hip.stream()), "poem_warp_affine")
+            wk()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                wk()
+            e1.record()
+            torch.cuda.synchronize()
+            k_ms = e0.elapsed_time(e1) / 20
+            alg = nv * (3 * 256 * 256 * 4 + 3 * 200 * 200)          # fp32 image written + the 200x200 source footprint read
+            res["input_scope"] = {"views": nv, "source": "640x480x3 uint8", "kernel_ms": k_ms,
+                                  "kernel_GBps_algorithmic": alg / k_ms / 1e6, "hbm_frac_of_8TBps": alg / k_ms / 1e6 / 8000.0,
+                                  "call_ms_incl_pinned_fill_and_h2d": call_ms, "h2d_bytes": nv * 480 * 640 * 3,
+                                  "stages": "raw uint8 views -> poem_warp_affine (crop/warp/to_tensor/normalize) -> (BN,3,256,256) fp32"}
+            del blob, outw
+        except Exception as e:
+            res["input_scope"] = {"error": repr(e)[:200]}
     if rank == 0 and world == 1 and args.cpu_samples > 0 and not parametric:
         base, ref = cpu_baseline(C, batch, args.cpu_samples)
         res["cpu_baseline"] = base

@@ -22,7 +22,7 @@ class PtEmbedMultiviewStereoV2:
             raise RuntimeError("PtEmbedMultiviewStereoV2 runs on the MI355X HIP path only (no CPU fallback)")
         self.name = type(self).__name__
         self.cfg = cfg
-        self.device = torch.device(device)
+        self.device = torch.device(cfg.get("DEVICE", device))
         preset = cfg.get("DATA_PRESET", CN({}))
         self.center_idx = int(preset.get("CENTER_IDX", 9))                       # POEM.py:50
         self.num_joints = 21

@@ -175,6 +175,76 @@ def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, ba
     return res
 
 
+def evaluate_shards(cfg, view_range, model_type, device, shard_dir, dataset, reload=None, epoch_size=16, batch_size=2,
+                    n_cams=8, raw_size=(640, 480)):
+    """Images -> metrics from record shards (SURVEY 8f N4 in front of the model): ``MultiviewWebDataset`` over the URLS of the
+    edited config (tar records: ``image_<i>.png|jpg`` + ``label.pyd``), the per-view crop / warp / normalise on the
+    device (one launch per batch), ``collation_random_n_views``, then the model-level caller
+    (``PtEmbedMultiviewStereoV2``: HRNet on PyTorch-ROCm -> decode / heat maps / DLT / head on HIP) and the device metrics
+    against the records' ``master_joints_3d`` / ``master_verts_3d`` (lib/models/POEM.py:596-610 upstream).
+    The dataset tars are not available offline: when ``shard_dir`` holds no shard of the dataset's name, seeded synthetic
+    shards of the same record layout are written there first."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    rank, _, world = pdist.env_world()
+    ds_node = cfg["DATASET"]["TEST"]["TARGET"]
+    pattern = os.path.join(shard_dir, os.path.basename(ds_node["URLS"]))
+    urls = pk.wds.expand_urls(pattern)
+    if rank == 0 and not all(os.path.exists(u) for u in urls):
+        from transform_oracle import synthetic_frame        # the seeded record generator (test infrastructure: data only)
+        os.makedirs(shard_dir, exist_ok=True)
+        per = -(-epoch_size // len(urls))
+        for si, u in enumerate(urls):
+            pk.wds.write_shard(u, [synthetic_frame(si * per + i, n_cams=n_cams, raw=raw_size) for i in range(per)])
+    pdist.barrier()
+    node = pk.wds.dataset_cfg(pattern, view_range=view_range, device=str(device))
+    dset = pk.MultiviewWebDataset(node, data_preset=node.DATA_PRESET, is_train=False, defer_images=True, rank=rank, world=world)
+    head_node = dict(cfg["MODEL"]["HEAD"])
+    head_node["MAX_VIEWS"] = max(10, int(view_range[1]))
+    model = pk.build_model(pk.CN({"TYPE": "PtEmbedMultiviewStereoV2", "HEAD": head_node, "DATA_PRESET": {"CENTER_IDX": 9},
+                                  "DEVICE": str(device)}))
+    if reload:
+        sd = torch.load(reload, map_location="cpu")
+        model.load_state_dict(sd.get("state_dict", sd.get("model", sd)) if isinstance(sd, dict) else sd)
+    else:
+        from poem_v2_amd.backbone import seeded_hrnet_state_dict
+        model.load_parts(seeded_hrnet_state_dict(0), pk.weights.seeded_decoder_state_dict(0),
+                         pk.weights.seeded_state_dict(model.ptEmb_head.embed_dims, seed=0),
+                         template=pk.inputs.synthetic_template(1234))
+    mpvpe, mpjpe = MeanEPE("verts", device=device), MeanEPE("joints", device=device)
+    n, t0, frames = 0, None, []
+
+    def run(frames):
+        batch = pk.collation_random_n_views(frames, transform=dset.transform)
+        if min(batch["cam_view_num"]) < 2 <= max(batch["cam_view_num"]):
+            return 0                                         # upstream has no DLT answer for such a mix either
+        preds = model(batch, 0, mode="test")
+        gj = batch["master_joints_3d"].reshape(-1, 21, 3).to(device)     # the collation concatenates per-frame (21,3) arrays
+        gv = batch["master_verts_3d"].reshape(-1, 778, 3).to(device)
+        mpjpe.feed(preds["pred_joints_3d"], gj)
+        mpvpe.feed(preds["pred_verts_3d"], gv)
+        return len(frames)
+
+    for f in dset:
+        frames.append(f)
+        if len(frames) == batch_size:
+            done = run(frames)
+            frames = []
+            if t0 is None:
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+            else:
+                n += done
+    if frames:
+        n += run(frames)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0 if t0 else 0.0
+    mpvpe.reduce(), mpjpe.reduce()
+    return {"dataset_source": f"record shards {pattern} (synthetic records)", "scope": "shards->images->verts",
+            "model": model_type, "view_range": list(view_range), "samples": int(mpvpe.acc[1].item()),
+            "MPVPE_mm_vs_record_gt": mpvpe.result() * 1e3, "MPJPE_mm_vs_record_gt": mpjpe.result() * 1e3,
+            "samples_per_s_rank0": (n / dt) if dt > 0 and n else None, "world_size": world}
+
+
 def main(args):
     view_range = [args.view_min, args.view_max]
     if args.cfg and os.path.exists(args.cfg):
@@ -193,8 +263,12 @@ def main(args):
     torch.cuda.set_device(device)
     if args.draw and rank == 0:
         print("--draw: rendering is outside the hot path and not built (DESIGN.md section 0); metrics only")
-    res = evaluate(cfg, view_range, args.model, device, reload=args.reload, epoch_size=args.epoch_size,
-                   batch_size=args.batch_size, pyramid=args.pyramid)
+    if args.shards:
+        res = evaluate_shards(cfg, view_range, args.model, device, args.shards, args.dataset, reload=args.reload,
+                              epoch_size=args.epoch_size, batch_size=args.batch_size)
+    else:
+        res = evaluate(cfg, view_range, args.model, device, reload=args.reload, epoch_size=args.epoch_size,
+                       batch_size=args.batch_size, pyramid=args.pyramid)
     if rank == 0:
         exp_id = f"{args.dataset}_view_{view_range[0]}_{view_range[1]}_{args.model}"
         print(json.dumps({"exp_id": exp_id, **res}))
@@ -216,5 +290,8 @@ if __name__ == "__main__":
     parser.add_argument("--epoch_size", type=int, default=64, help="Synthetic samples to evaluate (this build).")
     parser.add_argument("--pyramid", action="store_true",
                         help="start at the backbone's multi-level features: feat_decode + heatmap_stage on HIP (this build).")
+    parser.add_argument("--shards", type=str, default=None, metavar="DIR",
+                        help="evaluate the full model from record shards under DIR (the dataset's URLS pattern; synthetic "
+                             "shards are written there when absent): tar records -> device transform -> model -> metrics")
     parser.add_argument("--batch_size", type=int, default=2, help="--val_batch_size of the reference (lib/opt.py:27-30).")
     main(parser.parse_args())

@@ -299,3 +299,11 @@ def test_eval_single_script_runs_the_path(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["scope"] == "pyramid->verts" and res["samples"] == 4 and np.isfinite(res["MPVPE_mm_vs_synthetic_gt"])
+    # from record shards: tar records -> device transform -> full model (HRNet on PyTorch-ROCm) -> metrics  (N4)
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "eval_single.py"), "--cfg", str(cfgp), "--dataset",
+                          "DexYCB", "--view_min", "2", "--view_max", "4", "--model", "small", "-g", "0", "--epoch_size", "8",
+                          "--shards", str(tmp_path / "shards")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["scope"] == "shards->images->verts" and res["samples"] == 8 and np.isfinite(res["MPVPE_mm_vs_record_gt"])
+    assert sorted(os.listdir(tmp_path / "shards")) == [f"DexYCB_mv_test-00000{i}.tar" for i in range(4)]
