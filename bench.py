@@ -26,6 +26,7 @@ from poem_v2_amd import dist as pdist  # noqa: E402
 from poem_v2_amd.metrics import MeanEPE  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2516.6   # v_mfma_f32_32x32x16_f16: 1024 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz (dense)
 
 
 def vecattn_flops_per_launch(B, C, Q=799, K=32):
@@ -148,6 +149,9 @@ def main():
                     help="medium_MANO-style parametric tail (BASELINE configs[2]); MANO itself is licence-gated, the bench "
                          "plugs a cheap device-side stand-in layer in its place")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end scope leg (images -> HRNet on PyTorch-ROCm -> verts)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "split_f16x3"],
+                    help="fp32 (default, exact fp32 matrix-core products) | split_f16x3 (opt-in hi/lo f16 split of the vector "
+                         "attention's C x C GEMMs; include/poem_hip.h)")
     ap.add_argument("--overlap", type=int, default=1, help="0: issue every kernel on one stream (A/B of the side streams)")
     args = ap.parse_args()
 
@@ -201,6 +205,10 @@ def main():
         for _ in range(args.warmup):
             step()
         eng = head._engine
+        if args.precision != "fp32":
+            head.set_precision(args.precision)
+            for _ in range(args.warmup):
+                step()
         if not args.overlap:
             eng.set_overlap(False)
             for _ in range(args.warmup):
@@ -256,6 +264,39 @@ def main():
                            "traffic": traffic, "launches_timed": n_launch, "avg_launch_ms": va_ms / n_launch,
                            "share_of_step": va_ms / (dt * 1e3)}
     res["mpvpe_synthetic_gt_mm"] = meter.result() * 1e3
+    if args.precision != "fp32":
+        res["dtype"] = "f32 (vector-attention C x C products as hi/lo f16 splits on the f16 matrix cores, fp32 accumulation)"
+        if "roofline" in res:
+            res["roofline"].update(kernel="vecattn_split_kernel", peak=F16_MFMA_PEAK_TFLOPS / 3.0,
+                                   frac=res["roofline"]["achieved"] / (F16_MFMA_PEAK_TFLOPS / 3.0), traffic=None,
+                                   note="peak = dense f16 MFMA peak / 3 (three MFMAs per fp32-equivalent product)")
+    elif C >= 128 and not parametric:
+        # OPT-IN split-precision leg, reported beside the headline (never as `value`): same step with
+        # poem_set_precision(SPLIT_F16X3); distance of its vertices from the fp32 path's on the same batch.
+        try:
+            with torch.no_grad():
+                exact = step()["all_coords_preds"].clone()
+                head.set_precision("split_f16x3")
+                for _ in range(2):
+                    got = step()["all_coords_preds"]
+                eng.profile_read(reset=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                sdt = (time.perf_counter() - t0) / args.steps
+                n_s, ms_s = eng.profile_read(reset=True)
+                head.set_precision("fp32")
+            d = float(torch.norm(got[-1, :, 21:] - exact[-1, :, 21:], dim=-1).mean()) * 1e3
+            res["split_f16x3_scope"] = {"value": args.batch * world / sdt, "unit": "samples/s", "ms_per_step": sdt * 1e3,
+                                        "mpvpe_vs_fp32_path_mm": d,
+                                        "vecattn_split_avg_launch_ms": (ms_s / n_s) if n_s else None,
+                                        "note": "opt-in poem_set_precision(POEM_PRECISION_SPLIT_F16X3): the vector attention's "
+                                                "three C x C GEMMs as w_hi x_hi + w_hi x_lo + w_lo x_hi on v_mfma_f32_32x32x16_f16; "
+                                                "everything else fp32; the headline `value` is the exact-fp32 default"}
+        except Exception as e:
+            res["split_f16x3_scope"] = {"error": repr(e)[:200]}
     if world == 1 and not args.views_range and not parametric:
         # one stage earlier (SURVEY 8f rows N1 + N2): backbone pyramid -> feat_decode / heatmap_stage -> DLT -> head.  The
         # HRNet backbone itself is out of scope; its output pyramid is synthetic.  Reported beside the headline, never as it.

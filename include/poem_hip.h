@@ -121,6 +121,16 @@ int poem_decoder_forward(poem_handle_t h, const float* query_xyz, const float* q
  * internal side streams ordered against `stream` by events; everything is joined back before the call returns its
  * last launch, so the caller only ever synchronises its own stream.  0 = issue everything on `stream` in order. */
 int poem_set_overlap(poem_handle_t h, int enable);
+/* Arithmetic of the three C x C per-neighbour GEMMs inside the fused vector attention (everything else is fp32 always):
+ *   POEM_PRECISION_FP32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products, k-ordered fma chains;
+ *   POEM_PRECISION_SPLIT_F16X3 (opt-in, embed >= 128): hi/lo f16 splits of both operands on the f16 matrix cores
+ *     (w_hi x_hi + w_hi x_lo + w_lo x_hi, fp32 accumulation; csrc/vecattn_split.hip) -- products carry ~22 significant
+ *     bits instead of 24; measured MPVPE against the reference fixtures is unchanged at the 1e-5 mm level.  Requires
+ *     |activations| < 1023 inside the attention MLPs (f16 range after the x64 pre-scale).
+ * Returns POEM_E_UNSUPPORTED when the handle has no split images (embed < 128). */
+#define POEM_PRECISION_FP32 0
+#define POEM_PRECISION_SPLIT_F16X3 1
+int poem_set_precision(poem_handle_t h, int mode);
 int poem_finalize_parametric(poem_handle_t h, const float* mano_verts, const float* mano_joints,
                              const float* reference_joints, int batch, float* out_xyz, void* stream);
 /* Timing of the dominant kernel (the fused vector attention) with HIP events recorded on the launch stream around

@@ -46,6 +46,13 @@ hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src
                                         int nsrc, const float* wd1, const float* bd1, const void* wd2, const float* bd2,
                                         const void* wg1, const float* bg1, const void* wg2, const float* bg2, float* out,
                                         int B, int Q, int C, int ldq, int ldk, int ldv, int composed, hipStream_t s);
+hipError_t poem_launch_pack_split(const float* w, int C, void* img, float* scale_out, hipStream_t s);
+hipError_t poem_launch_vector_attention_split(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
+                                              const int* idx, int shared_idx, const float* q, const float* k,
+                                              const float* v, int nsrc, const float* wd1, const float* bd1,
+                                              const void* wd2, const float* bd2, const void* wg1, const void* wg2,
+                                              const float* scales, float* out, int B, int Q, int C, int ldq,
+                                              int ldk, int ldv, hipStream_t s);
 hipError_t poem_launch_dlt(const float* uv, const float* intr, const float* mat, const int* offs, float* out, int B, int J,
                            int invert, hipStream_t s);
 hipError_t poem_launch_pa_epe(const float* pred, const float* gt, float* out, int B, int P, hipStream_t s);
@@ -188,6 +195,12 @@ struct poem_handle_s {
   // so `ke`, `xk` and `xs` are never materialised and three GEMMs per block disappear.
   struct Fused { const void* w[7]; const float* b[7]; };   // [4] cross-attn query, [5]/[6] W_g1 W_d2 of self / cross
   std::vector<Fused> fused;
+  // Opt-in split-precision vector attention (vecattn_split.hip): hi | lo f16 images of W_d2, W_g1 W_d2, W_g2 per block
+  // and attention (self, cross) + their power-of-two scales, in handle-owned device memory (built at creation).
+  struct SplitW { const void* w[3]; const float* scales; };
+  std::vector<SplitW> split;         // [2 * block + (0 self | 1 cross)]
+  void* split_mem = nullptr;
+  int precision = 0;                 // POEM_PRECISION_FP32 | POEM_PRECISION_SPLIT_F16X3
   bool taps = false;
   struct Tap { const void* p; int64_t elems; };
   std::map<std::string, Tap> tapmap;
@@ -420,6 +433,12 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     if (ov && i > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
     {
     PROF_START();
+    if (h->precision == POEM_PRECISION_SPLIT_F16X3) {
+      const auto& sw = h->split[2 * i];
+      HIPCHK(poem_launch_vector_attention_split(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q,
+                                                h->R(vsb + 4), h->R(vsb + 5), sw.w[0], h->R(vsb + 7), sw.w[1], sw.w[2],
+                                                sw.scales, p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, s));
+    } else
     HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
                                         h->R(vsb + 5), h->P(vsb + 6), h->R(vsb + 7), h->fused[i].w[5], h->R(vsb + 9),
                                         h->P(vsb + 10), h->R(vsb + 11), p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, 1, s));
@@ -431,6 +450,12 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     HIPCHK(poem_launch_gemm(p.f_self[i], C, h->fused[i].w[4], h->fused[i].b[4], nullptr, 0, p.qc, C, BQ, C, C, POEM_ACT_NONE, s));
     {
     PROF_START();
+    if (h->precision == POEM_PRECISION_SPLIT_F16X3) {
+      const auto& sw = h->split[2 * i + 1];
+      HIPCHK(poem_launch_vector_attention_split(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
+                                                p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4), h->R(vcb + 5), sw.w[0],
+                                                h->R(vcb + 7), sw.w[1], sw.w[2], sw.scales, p.rc, B, Q, C, C, C, C, s));
+    } else
     HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
                                         p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4),
                                         h->R(vcb + 5), h->P(vcb + 6), h->R(vcb + 7), h->fused[i].w[6], h->R(vcb + 9),
@@ -581,6 +606,12 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   }
   h->bps = bps; h->anchor = anchor; h->anchor_idx = anchor_idx; h->tmpl = template_xyz;
   const int C = cfg->embed, hw = cfg->feat_h * cfg->feat_w;
+  if (C >= 128) {
+    h->split.resize(2 * cfg->nblocks);
+    if (hipMalloc(&h->split_mem, (size_t)2 * cfg->nblocks * ((size_t)3 * C * C * 4 + 256)) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError(); delete h; return POEM_E_LAUNCH;
+    }
+  }
   {
     h->fused.resize(cfg->nblocks);
     // init-time scratch for raw composites: rows (<= 6C x C), T (C x C), t2 (C x C), bias vectors
@@ -651,6 +682,19 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
       LOK(poem_launch_compose_weight(h->raw[vc + 8], h->raw[vc + 6], raw_rows, C, C, C, s));
       pack_rows(1, &f.w[6]);
       f.b[5] = f.b[6] = nullptr;
+      if (h->split_mem) {                      // split images: W_d2, W_g1 W_d2 (re-composed into raw_rows), W_g2
+        const size_t img = (size_t)C * C * 4;
+        for (int a = 0; a < 2; ++a) {
+          const int vb = a == 0 ? vs : vc;
+          char* base = (char*)h->split_mem + ((size_t)(2 * b + a)) * (3 * img + 256);
+          float* sc = (float*)(base + 3 * img);
+          LOK(poem_launch_pack_split(h->raw[vb + 6], C, base, sc + 0, s));
+          LOK(poem_launch_compose_weight(h->raw[vb + 8], h->raw[vb + 6], raw_rows, C, C, C, s));
+          LOK(poem_launch_pack_split(raw_rows, C, base + img, sc + 1, s));
+          LOK(poem_launch_pack_split(h->raw[vb + 10], C, base + 2 * img, sc + 2, s));
+          h->split[2 * b + a] = {{base, base + img, base + 2 * img}, sc};
+        }
+      }
       // F4: reg_branch.0 | intermediate.dense share f_cross; intermediate.dense is (4C, C): four C-row slabs of the raw tensor
       f.w[3] = cur;
       ok = ok && poem_launch_pack_linear(h->raw[bb + B_REG0_W], C, C, cur, s) == hipSuccess;
@@ -691,6 +735,7 @@ void poem_destroy(poem_handle_t h) {
   auto de = [](hipEvent_t e) { if (e) (void)hipEventDestroy(e); };
   de(h->ev_fork); de(h->ev_join_bps); de(h->ev_join_knn);
   for (int i = 0; i < 8; ++i) { de(h->ev_bps[i]); de(h->ev_xyz[i]); de(h->ev_knn[i]); }
+  if (h->split_mem) (void)hipFree(h->split_mem);
   if (h->bps_stream) (void)hipStreamDestroy(h->bps_stream);
   if (h->knn_stream) (void)hipStreamDestroy(h->knn_stream);
   delete h;
@@ -699,6 +744,13 @@ void poem_destroy(poem_handle_t h) {
 int poem_set_overlap(poem_handle_t h, int enable) {
   if (!h) return POEM_E_ARG;
   h->overlap = enable != 0;
+  return POEM_OK;
+}
+
+int poem_set_precision(poem_handle_t h, int mode) {
+  if (!h || (mode != POEM_PRECISION_FP32 && mode != POEM_PRECISION_SPLIT_F16X3)) return POEM_E_ARG;
+  if (mode == POEM_PRECISION_SPLIT_F16X3 && !h->split_mem) return POEM_E_UNSUPPORTED;      // embed < 128
+  h->precision = mode;
   return POEM_OK;
 }
 

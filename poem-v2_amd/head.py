@@ -100,7 +100,21 @@ class POEM_Generalized_Head(nn.Module):
             bps, anchor, aidx = hip.load_assets(self.nsample)
             self._engine = hip.Engine(cfg, self._live_weights(), bps, anchor, aidx, self.template, device)
             self._engine_sig = sig
+            if self._precision != "fp32":
+                self._engine.set_precision(self._precision)
         return self._engine
+
+    _precision = "fp32"
+
+    def set_precision(self, mode):
+        """``"fp32"`` (default: exact fp32 matrix-core products everywhere) or ``"split_f16x3"`` (opt-in: the three C x C
+        per-neighbour GEMMs of the vector attention as hi/lo f16 splits with fp32 accumulation, include/poem_hip.h)."""
+        if mode not in hip.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(hip.PRECISIONS)}")
+        self._precision = mode
+        if self._engine is not None:
+            self._engine.set_precision(mode)
+        return self
 
     _feat_hw = (16, 16)
 

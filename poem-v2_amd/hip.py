@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("POEM_HIP_LIB") or os.path.join(CSRC, "libpoem_hip.so"
 ASSETS = os.path.join(_HERE, "assets")
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+PRECISIONS = {"fp32": 0, "split_f16x3": 1}            # include/poem_hip.h POEM_PRECISION_*
 
 
 class PoemConfig(ctypes.Structure):
@@ -49,6 +50,7 @@ SIGNATURES = {
     "poem_packed_linear_bytes": (_sz, [_i, _i]),
     "poem_pack_linear": (_i, [_vp, _i, _i, _vp, _vp]),
     "poem_set_overlap": (_i, [_vp, _i]),
+    "poem_set_precision": (_i, [_vp, _i]),
     "poem_gemm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_gemm_ex": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "poem_pack_rows": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -211,6 +213,10 @@ class Engine:
 
     def set_overlap(self, flag=True):
         check(lib().poem_set_overlap(self.handle, int(flag)), "poem_set_overlap")
+
+    def set_precision(self, mode):
+        check(lib().poem_set_precision(self.handle, PRECISIONS[mode] if isinstance(mode, str) else int(mode)),
+              "poem_set_precision")
 
     def profile_enable(self, max_launches):
         check(lib().poem_profile_enable(self.handle, int(max_launches)), "poem_profile_enable")

@@ -208,6 +208,45 @@ def test_head_release_shapes_vs_golden_and_oracle(name):
     assert _md(got, ref) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged"])
+def test_split_precision_mode_vs_golden(name):
+    """Opt-in POEM_PRECISION_SPLIT_F16X3 (csrc/vecattn_split.hip: the vector attention's C x C GEMMs as hi/lo f16 splits on
+    the f16 matrix cores, fp32 accumulation): same bar as the default path -- MPVPE vs the reference <= 1e-3 mm -- and it
+    must stay at the fp32 kernel's own distance from the reference (no more than 4x it + 2e-5 mm)."""
+    z, meta = load_golden(name)
+    spec = meta["spec"]
+    cfg, w, consts, batch = case_setup(spec)
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    ref = torch.from_numpy(z["all_coords_preds"])
+    with torch.no_grad():
+        exact = head(feat, metas, rj)["all_coords_preds"].cpu()
+        head.set_precision("split_f16x3")
+        got = head(feat, metas, rj)["all_coords_preds"].cpu()
+        head.set_precision("fp32")
+        again = head(feat, metas, rj)["all_coords_preds"].cpu()
+    assert torch.equal(exact, again)                                   # the switch really switches back
+    assert not torch.equal(exact, got)                                 # ... and the split kernel really ran
+    d_exact = float(torch.norm(exact[-1, :, 21:] - ref[-1, :, 21:], dim=-1).mean(dim=1).max())
+    d_split = float(torch.norm(got[-1, :, 21:] - ref[-1, :, 21:], dim=-1).mean(dim=1).max())
+    assert d_split < 1e-6, (d_split, d_exact)                          # metres: the 1e-3 mm bar
+    assert d_split < 4 * d_exact + 2e-8, (d_split, d_exact)
+    assert _md(got, ref) < 1e-4
+
+
+def test_split_precision_needs_embed_128():
+    z, meta = load_golden("tiny")
+    head = build_hip_head(meta["spec"], DEV)
+    cfg, w, consts, batch = case_setup(meta["spec"])
+    feat, metas, rj = batch_to(batch, DEV)
+    with torch.no_grad():
+        head(feat, metas, rj)
+        with pytest.raises(RuntimeError):
+            head.set_precision("split_f16x3")                           # embed 32: no split images
+    with pytest.raises(ValueError):
+        head.set_precision("bf16")
+
+
 def test_ragged_views_and_batch_independence():
     """Samples do not interact: a ragged batch equals the per-sample runs (the property the DP shard relies on)."""
     spec = dict(embed=128, nsample=4096, views=[3, 1, 8, 2], seed=21, parametric=False)
