@@ -279,7 +279,7 @@ def main():
                 head.set_precision("split_f16x3")
                 for _ in range(2):
                     got = step()["all_coords_preds"]
-                eng.profile_read(reset=True)
+                eng.profile_enable(6 * args.steps)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(args.steps):
@@ -287,6 +287,7 @@ def main():
                 torch.cuda.synchronize()
                 sdt = (time.perf_counter() - t0) / args.steps
                 n_s, ms_s = eng.profile_read(reset=True)
+                eng.profile_enable(0)
                 head.set_precision("fp32")
             d = float(torch.norm(got[-1, :, 21:] - exact[-1, :, 21:], dim=-1).mean()) * 1e3
             res["split_f16x3_scope"] = {"value": args.batch * world / sdt, "unit": "samples/s", "ms_per_step": sdt * 1e3,

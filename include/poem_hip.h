@@ -245,6 +245,17 @@ int poem_mano_to_openpose(const float* j_regressor, const float* verts, float* j
  * Arithmetic is OpenCV's 8-bit fixed-point bilinear path (1/32-pixel coordinates, 15-bit weights): integer, bit-exact. */
 int poem_warp_affine(const uint8_t* src, const int64_t* src_offsets, const int32_t* src_hw, const double* m_inv,
                      const double* gain, float* out_f32, uint8_t* out_u8, int views, int out_h, int out_w, void* stream);
+/* Operator-level entry points of the opt-in split-precision vector attention (see poem_set_precision).
+ * poem_pack_split_linear: w (embed,embed) row-major fp32 -> image (embed*embed*4 bytes: hi | lo f16 fragments of w * scale)
+ *   and *scale (device float, the power of two the image carries).
+ * poem_vector_attention_split: the COMPOSED form of poem_vector_attention -- qg = W_g1 q + (W_g1 b_d2 + b_g1),
+ *   kg = W_g1 k (row stride embed), images of W_d2, W_g1 W_d2 and W_g2, scales = their three scales (device). */
+int poem_pack_split_linear(const float* w, int embed, void* image, float* scale, void* stream);
+int poem_vector_attention_split(const float* query_xyz, const float* src_xyz, const float* anchor_xyz, const int32_t* idx,
+                                int shared_idx, const float* qg, const float* kg, const float* v, int nsrc, const float* wd1,
+                                const float* bd1, const void* wd2_image, const float* bd2, const void* wg1d2_image,
+                                const void* wg2_image, const float* scales, float* out, int batch, int nq, int embed,
+                                void* stream);
 /* idx (B,Q,32) int32: 32 nearest src points per query, ascending squared L2, ties -> lower index. */
 int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream);
 /* Vector attention core.  q (B,Q,C); k,v (B,NS,C) gathered by idx; idx (B,Q,32) or (32) when shared_idx!=0;

@@ -867,6 +867,27 @@ int poem_cross_attention(const float* q, const float* k, const float* v, float* 
   return POEM_OK;
 }
 
+int poem_pack_split_linear(const float* w, int embed, void* image, float* scale, void* stream) {
+  if (!w || !image || !scale || embed < 128 || embed > 1024 || (embed & (embed - 1))) return POEM_E_ARG;
+  HIPCHK(poem_launch_pack_split(w, embed, image, scale, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_vector_attention_split(const float* query_xyz, const float* src_xyz, const float* anchor_xyz, const int32_t* idx,
+                                int shared_idx, const float* qg, const float* kg, const float* v, int nsrc, const float* wd1,
+                                const float* bd1, const void* wd2_image, const float* bd2, const void* wg1d2_image,
+                                const void* wg2_image, const float* scales, float* out, int batch, int nq, int embed,
+                                void* stream) {
+  if (!query_xyz || (!src_xyz && !anchor_xyz) || !idx || !qg || !kg || !v || !wd1 || !bd1 || !wd2_image || !bd2 ||
+      !wg1d2_image || !wg2_image || !scales || !out || batch <= 0 || nq <= 0 || nsrc <= 0)
+    return POEM_E_ARG;
+  if (embed < 128 || embed > 1024 || (embed & (embed - 1))) return POEM_E_UNSUPPORTED;
+  HIPCHK(poem_launch_vector_attention_split(query_xyz, src_xyz, anchor_xyz, idx, shared_idx, qg, kg, v, nsrc, wd1, bd1,
+                                            wd2_image, bd2, wg1d2_image, wg2_image, scales, out, batch, nq, embed, embed,
+                                            embed, embed, (hipStream_t)stream));
+  return POEM_OK;
+}
+
 int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream) {
   if (!query_xyz || !src_xyz || !idx || batch <= 0 || nq <= 0 || nsrc < 32 || nsrc > 4096) return POEM_E_ARG;
   HIPCHK(poem_launch_knn(query_xyz, src_xyz, idx, batch, nq, nsrc, (hipStream_t)stream));

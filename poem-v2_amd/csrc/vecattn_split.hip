@@ -14,17 +14,35 @@
 // kernel's own level (~1e-5 mm, tolerance 1e-3 mm); tools/lab/split_precision_probe.py is the CPU pre-study.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define POEM_SPLIT_SX 64.0f
 
+// tools/lab only (POEM_VS_LAB): 1 = MFMAs replaced by a register touch (non-MFMA floor), 2 = every weight fragment load
+// hits the same 2 KiB (L1-resident: what the L2 stream costs), 3 = no v_j gathers in the epilogue
+#if defined(POEM_VS_LAB) && POEM_VS_LAB == 1
+#define VS_LAB_MMA(M, C_, W_, X_) lab_touch(C_, W_, X_)
+#else
+#define VS_LAB_MMA(M, C_, W_, X_) (M)
+#endif
+#if defined(POEM_VS_LAB) && POEM_VS_LAB == 2
+#define VS_LAB_WOFF(o) ((o) & 1024)
+#else
+#define VS_LAB_WOFF(o) (o)
+#endif
+
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ h8 as_h8(float4 v) { return __builtin_bit_cast(h8, v); }
+__device__ __forceinline__ f32x16 lab_touch(f32x16 c, h8 w, h8 x) {
+  c[0] += (float)w[0] * (float)x[0];
+  return c;
+}
 
 // ---- weight image: [(nt * KC + kc) * 2 + part][lane] = half8(W'[32 nt + (lane & 31)][16 kc + 8 (lane >> 5) + 0..7]),
 // KC = C / 16, part 0 = hi, 1 = lo, W' = W * scale (scale = power of two, written to *scale_out).
@@ -100,15 +118,17 @@ __device__ __forceinline__ void chain_gemm_split(const void* __restrict__ Wimg, 
   const int wbase = __builtin_amdgcn_readfirstlane(wv) * TPW * KC * 2048;
   const int loff = lane * 16;
   const char* xc = X + j * ROW + h * 32;
-  // Weight fragments: two-slot ring, chunk kc+1 requested before the MFMAs of chunk kc issue.  LDS operands: ONE slot --
-  // the three MFMA groups of a chunk run (w_hi x_lo), (w_hi x_hi), (w_lo x_hi), so x_lo of the next chunk is requested
-  // right after the first group and x_hi after the last; the next chunk's first group (x_lo) covers the x_hi latency.
-  // (Two-slot x rings cost 16 more VGPRs and spilled.)  Order pinned with sched_barrier.
-  h8 wh[2][TPW], wl[2][TPW], xh[P], xl[P];
+  // Weight fragments: ring of WR slots, chunk kc+WR-1 requested before the MFMAs of chunk kc issue (the fragment stream
+  // is L2-latency-bound at distance 1: tools/lab, POEM_VS_LAB).  LDS operands: ONE slot -- the three MFMA groups of a
+  // chunk run (w_hi x_lo), (w_hi x_hi), (w_lo x_hi), so x_lo of the next chunk is requested right after the first group
+  // and x_hi after the last; the next chunk's first group covers the x_hi latency.  Order pinned with sched_barrier.
+  constexpr int WR = 2;
+  static_assert(KC % WR == 0 && KC >= 2 * WR, "ring depth must divide the chunk count");
+  h8 wh[WR][TPW], wl[WR][TPW], xh[P], xl[P];
 #define VS_LOADW(S, WOFF)                                                                  \
   _Pragma("unroll") for (int tp = 0; tp < TPW; ++tp) {                                     \
-    wh[S][tp] = as_h8(frag_load(wrs, loff, (WOFF) + tp * KC * 2048));                      \
-    wl[S][tp] = as_h8(frag_load(wrs, loff, (WOFF) + tp * KC * 2048 + 1024));               \
+    wh[S][tp] = as_h8(frag_load(wrs, loff, VS_LAB_WOFF((WOFF) + tp * KC * 2048)));         \
+    wl[S][tp] = as_h8(frag_load(wrs, loff, VS_LAB_WOFF((WOFF) + tp * KC * 2048 + 1024)));  \
   }
 #define VS_READXH(XP) _Pragma("unroll") for (int p = 0; p < P; ++p) xh[p] = *reinterpret_cast<const h8*>((XP) + p * 32 * ROW);
 #define VS_READXL(XP) _Pragma("unroll") for (int p = 0; p < P; ++p) xl[p] = *reinterpret_cast<const h8*>((XP) + p * 32 * ROW + 16);
@@ -116,41 +136,74 @@ __device__ __forceinline__ void chain_gemm_split(const void* __restrict__ Wimg, 
   _Pragma("unroll") for (int tp = 0; tp < TPW; ++tp)                                       \
     _Pragma("unroll") for (int p = 0; p < P; ++p) {                                        \
       const f32x16 c_ = (FIRST) ? zero16() : acc[tp][p];                                   \
-      acc[tp][p] = FLIP ? mfma16(XA[p], WA[tp], c_) : mfma16(WA[tp], XA[p], c_);           \
+      acc[tp][p] = VS_LAB_MMA(FLIP ? mfma16(XA[p], WA[tp], c_) : mfma16(WA[tp], XA[p], c_), c_, WA[tp], XA[p]); \
     }
-#define VS_STEP(S, FIRST, NEXTX, HAVE_NEXT)                                                \
-  __builtin_amdgcn_sched_barrier(0);                                                       \
-  VS_MMA(wh[S], xl, FIRST)                                                                 \
-  __builtin_amdgcn_sched_barrier(0);                                                       \
-  if (HAVE_NEXT) { VS_READXL(NEXTX) }                                                      \
-  __builtin_amdgcn_sched_barrier(0);                                                       \
-  VS_MMA(wh[S], xh, false) VS_MMA(wl[S], xh, false)                                        \
-  __builtin_amdgcn_sched_barrier(0);                                                       \
-  if (HAVE_NEXT) { VS_READXH(NEXTX) }
+#if defined(POEM_VS_LAB) && POEM_VS_LAB == 4      // lab: no GEMM loop at all (what everything around the GEMMs costs)
+  if (INIT0) {
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int p = 0; p < P; ++p) acc[tp][p] = zero16();
+  }
+  return;
+#endif
+#if defined(POEM_VS_LAB) && POEM_VS_LAB == 5      // lab: MFMAs only (operands loaded once, outside the loop)
+  {
+    h8 w0[TPW], w1[TPW], x0[P], x1[P];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) { w0[tp] = as_h8(frag_load(wrs, loff, wbase + tp * 2048)); w1[tp] = as_h8(frag_load(wrs, loff, wbase + tp * 2048 + 1024)); }
+#pragma unroll
+    for (int p = 0; p < P; ++p) { x0[p] = *reinterpret_cast<const h8*>(xc + p * 32 * ROW); x1[p] = *reinterpret_cast<const h8*>(xc + p * 32 * ROW + 16); }
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int p = 0; p < P; ++p) if (INIT0) acc[tp][p] = zero16();
+#pragma unroll 2
+    for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[tp][p] = FLIP ? mfma16(x1[p], w0[tp], acc[tp][p]) : mfma16(w0[tp], x1[p], acc[tp][p]);
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[tp][p] = FLIP ? mfma16(x0[p], w0[tp], acc[tp][p]) : mfma16(w0[tp], x0[p], acc[tp][p]);
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[tp][p] = FLIP ? mfma16(x0[p], w1[tp], acc[tp][p]) : mfma16(w1[tp], x0[p], acc[tp][p]);
+    }
+    return;
+  }
+#endif
   int woff = wbase;
   const char* xp = xc;
-  VS_LOADW(0, woff)
+  // one group = WR consecutive chunks with compile-time ring slots
+  auto group = [&](auto first_c, auto last_c) __attribute__((always_inline)) {
+    constexpr bool FIRSTG = decltype(first_c)::value, LASTG = decltype(last_c)::value;
+#pragma unroll
+    for (int u = 0; u < WR; ++u) {
+      if (!LASTG || u == 0) { VS_LOADW((u + WR - 1) % WR, woff + (u + WR - 1) * 2048) }
+      const bool have_next = !(LASTG && u == WR - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      VS_MMA(wh[u], xl, FIRSTG && INIT0 && u == 0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (have_next) { VS_READXL(xp + (u + 1) * 64) }
+      __builtin_amdgcn_sched_barrier(0);
+      VS_MMA(wh[u], xh, false) VS_MMA(wl[u], xh, false)
+      __builtin_amdgcn_sched_barrier(0);
+      if (have_next) { VS_READXH(xp + (u + 1) * 64) }
+    }
+    woff += WR * 2048;
+    xp += WR * 64;
+  };
+#pragma unroll
+  for (int sl = 0; sl < WR - 1; ++sl) { VS_LOADW(sl, woff + sl * 2048) }
   VS_READXL(xp)
   VS_READXH(xp)
-  // chunks (0, 1) peeled: the very first MFMA takes the inline-constant 0 as C
-  VS_LOADW(1, woff + 2048)
-  VS_STEP(0, INIT0, xp + 64, true)
-  VS_LOADW(0, woff + 4096)
-  VS_STEP(1, false, xp + 128, true)
-  woff += 4096;
-  xp += 128;
-  for (int kc = 2; kc < KC - 2; kc += 2) {
-    VS_LOADW(1, woff + 2048)
-    VS_STEP(0, false, xp + 64, true)
-    VS_LOADW(0, woff + 4096)
-    VS_STEP(1, false, xp + 128, true)
-    woff += 4096;
-    xp += 128;
-  }
-  VS_LOADW(1, woff + 2048)                // last pair: nothing left to prefetch after it
-  VS_STEP(0, false, xp + 64, true)
-  VS_STEP(1, false, xp, false)
-#undef VS_STEP
+  group(std::true_type{}, std::false_type{});         // peeled: the very first MFMA takes the inline-constant 0 as C
+  for (int kc = WR; kc < KC - WR; kc += WR) group(std::false_type{}, std::false_type{});
+  group(std::false_type{}, std::true_type{});          // nothing left to prefetch after the last chunk
 #undef VS_READXH
 #undef VS_READXL
 #undef VS_LOADW
@@ -317,7 +370,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_split_kernel(VecAttnSpl
         float vg[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i)
+#if defined(POEM_VS_LAB) && POEM_VS_LAB == 3
+          vg[i] = 0.f;
+#else
           vg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrs, voffs[p * 32 + mfma_row(i, h)] + cch * 4, 0, 0));
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float pt[16];
 #pragma unroll
@@ -374,7 +431,12 @@ extern "C" hipError_t poem_launch_vector_attention_split(const float* query_xyz,
                      out, B, Q, ldq, ldk, ldv};
   switch (C) {
     case 128: return launch_vs<128, 4, 4, 2>(a, s);
-    case 256: return launch_vs<256, 2, 4, 2>(a, s);
+    case 256: {
+      static const int cfg = getenv("POEM_VS_CFG") ? atoi(getenv("POEM_VS_CFG")) : 0;      // lab A/B of the block shape
+      if (cfg == 1) return launch_vs<256, 4, 8, 2>(a, s);     // one 8-wave block per CU, 4 queries share a weight stream
+      if (cfg == 2) return launch_vs<256, 2, 8, 4>(a, s);     // two 8-wave blocks per CU (4 waves per SIMD)
+      return launch_vs<256, 2, 4, 2>(a, s);
+    }
     case 512: return launch_vs<512, 1, 4, 2>(a, s);
     case 1024: return launch_vs<1024, 1, 8, 2>(a, s);
     default: return hipErrorInvalidValue;

@@ -51,6 +51,9 @@ SIGNATURES = {
     "poem_pack_linear": (_i, [_vp, _i, _i, _vp, _vp]),
     "poem_set_overlap": (_i, [_vp, _i]),
     "poem_set_precision": (_i, [_vp, _i]),
+    "poem_pack_split_linear": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "poem_vector_attention_split": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _i, _i, _i, _vp]),
     "poem_gemm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_gemm_ex": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "poem_pack_rows": (_i, [_vp, _i, _i, _vp, _vp]),
@@ -347,6 +350,27 @@ def vector_attention(query_xyz, src_xyz, anchor_xyz, idx, q, k, v, wd1, bd1, wd2
           "poem_vector_attention")
     return out
 
+
+
+def pack_split_linear(w):
+    """(C,C) fp32 device tensor -> (image uint8 (C*C*4,), scale float32 (1,)) for the split-precision vector attention."""
+    C = w.shape[0]
+    img = torch.empty(C * C * 4, dtype=torch.uint8, device=w.device)
+    sc = torch.empty(1, dtype=torch.float32, device=w.device)
+    check(lib().poem_pack_split_linear(ptr(w), C, img.data_ptr(), sc.data_ptr(), stream()), "poem_pack_split_linear")
+    return img, sc
+
+
+def vector_attention_split(query_xyz, src_xyz, anchor_xyz, idx, qg, kg, v, wd1, bd1, wd2_img, bd2, wg1d2_img, wg2_img, scales):
+    """Composed form on the f16 matrix cores (include/poem_hip.h poem_vector_attention_split)."""
+    B, NQ, C = qg.shape
+    out = torch.empty_like(qg)
+    shared = 1 if idx.dim() == 1 else 0
+    check(lib().poem_vector_attention_split(ptr(query_xyz), ptr(src_xyz), ptr(anchor_xyz), idx.data_ptr(), shared, ptr(qg),
+                                            ptr(kg), ptr(v), kg.shape[1], ptr(wd1), ptr(bd1), wd2_img.data_ptr(), ptr(bd2),
+                                            wg1d2_img.data_ptr(), wg2_img.data_ptr(), ptr(scales), ptr(out), B, NQ, C,
+                                            stream()), "poem_vector_attention_split")
+    return out
 
 def project_sample(x, bps, centre, view_sample, cam_intr, cam_extr, img_shape):
     BN, C, fh, fw = x.shape

@@ -138,6 +138,48 @@ def test_vector_attention_core(C, anchors):
     assert _md(out, ref) < 5e-5
 
 
+@pytest.mark.parametrize("C", [128, 256, 512])
+@pytest.mark.parametrize("anchors", [False, True])
+def test_vector_attention_split_core(C, anchors):
+    """Operator level: the opt-in split-precision kernel (composed form, f16 hi/lo splits, fp32 accumulation) against the
+    oracle's fp32 vector attention -- same tolerance as the exact kernel's test above."""
+    g = torch.Generator().manual_seed(7 * C + anchors)
+    B, Q, NS = 2, 101, 300
+    qxyz = torch.rand(B, Q, 3, generator=g) * 2 - 1
+    sxyz = torch.rand(B, NS, 3, generator=g) * 2 - 1
+    q, k, v = torch.randn(B, Q, C, generator=g), torch.randn(B, NS, C, generator=g), torch.randn(B, NS, C, generator=g)
+    w = {}
+    for n, shp in (("fc_delta.0", (C, 3)), ("fc_delta.2", (C, C)), ("fc_gamma.0", (C, C)), ("fc_gamma.2", (C, C))):
+        w["p." + n + ".weight"] = torch.randn(*shp, generator=g) / math.sqrt(shp[1])
+        w["p." + n + ".bias"] = torch.randn(shp[0], generator=g) * 0.1
+    if anchors:
+        idx = torch.randperm(NS, generator=g)[:32]
+        axyz = torch.rand(32, 3, generator=g) * 2 - 1
+        idx_full = idx.view(1, 1, 32).expand(B, Q, 32)
+        nxyz = axyz.view(1, 1, 32, 3).expand(B, Q, 32, 3)
+    else:
+        idx_full = po.knn_indices(qxyz, sxyz, 32)
+        nxyz = po.gather_xyz(sxyz, idx_full)
+    ref = po._vec_attn_core(w, "p.", q, po.index_points(k, idx_full), po.index_points(v, idx_full),
+                            qxyz[:, :, None] - nxyz, C)
+    Wg1, Wd2 = w["p.fc_gamma.0.weight"].double(), w["p.fc_delta.2.weight"].double()
+    cvec = Wg1 @ w["p.fc_delta.2.bias"].double() + w["p.fc_gamma.0.bias"].double()
+    qg = (q.double() @ Wg1.T + cvec).float()
+    kg = (k.double() @ Wg1.T).float()
+    d = lambda t: t.to(DEV).contiguous()   # noqa: E731
+    i1, s1 = hip.pack_split_linear(d(Wd2.float()))
+    i2, s2 = hip.pack_split_linear(d((Wg1 @ Wd2).float()))
+    i3, s3 = hip.pack_split_linear(d(w["p.fc_gamma.2.weight"]))
+    for sc, W in ((s1, Wd2), (s2, Wg1 @ Wd2), (s3, w["p.fc_gamma.2.weight"])):
+        m = float(W.abs().max()) * float(sc)
+        assert 8.0 <= m < 16.0 and math.log2(float(sc)) == int(math.log2(float(sc)))     # power of two, max |w'| in [8,16)
+    out = hip.vector_attention_split(d(qxyz), d(sxyz), d(axyz) if anchors else None,
+                                     d(idx.int()) if anchors else d(idx_full.int()), d(qg), d(kg), d(v),
+                                     d(w["p.fc_delta.0.weight"]), d(w["p.fc_delta.0.bias"]), i1, d(w["p.fc_delta.2.bias"]),
+                                     i2, i3, torch.cat([s1, s2, s3]))
+    assert _md(out, ref) < 5e-5
+
+
 def test_project_and_sample_matches_oracle():
     _, meta = load_golden("tiny")
     cfg, w, consts, batch = case_setup(meta["spec"])

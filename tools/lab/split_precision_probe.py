@@ -25,9 +25,11 @@ def split(x, dt, parts):
     return out
 
 
-def make_linear(dt, parts, terms):
+def make_linear(dt, parts, terms, every=False):
     def lin(x, w, b=None):
-        if w.shape[0] != w.shape[1] or x.dim() != 4:              # only the per-(query, neighbour) CxC GEMMs
+        if not every and (w.shape[0] != w.shape[1] or x.dim() != 4):   # only the per-(query, neighbour) CxC GEMMs
+            return F.linear(x, w, b)
+        if w.shape[1] < 16:                                        # 3 -> C first layers stay fp32 in any design
             return F.linear(x, w, b)
         xs, ws = split(x, dt, parts), split(w, dt, parts)
         y = None
@@ -46,10 +48,12 @@ def main():
     cfg, w, consts, batch = case_setup(spec)
     ref = run_oracle(cfg, w, consts, batch)["all_coords_preds"]
     plain = po.linear
+    every = "--all-linears" in sys.argv                            # every nn.Linear of the path, not only the vector attention
+    print("scope:", "every Linear with K >= 16" if every else "vector-attention C x C GEMMs", flush=True)
     for name, dt, parts, terms in (("f16 x3 (hi*hi + hi*lo + lo*hi)", torch.float16, 2, 2), ("f16 x4", torch.float16, 2, 3),
                                    ("bf16 x3", torch.bfloat16, 2, 2), ("bf16 x6 (3-way split)", torch.bfloat16, 3, 3),
                                    ("bf16 x1", torch.bfloat16, 1, 1), ("f16 x1", torch.float16, 1, 1)):
-        po.linear = make_linear(dt, parts, terms)
+        po.linear = make_linear(dt, parts, terms, every)
         try:
             out = run_oracle(cfg, w, consts, batch)["all_coords_preds"]
         finally:
