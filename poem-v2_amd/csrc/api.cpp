@@ -993,7 +993,7 @@ int poem_warp_affine(const uint8_t* src, const int64_t* src_offsets, const int32
                      const double* gain, float* out_f32, uint8_t* out_u8, int views, int out_h, int out_w, void* stream) {
   if (!src || !src_offsets || !src_hw || !m_inv || (!out_f32 && !out_u8) || views <= 0 || out_h <= 0 || out_w <= 0)
     return POEM_E_ARG;
-  if (views > 65535 || out_h > 65535) return POEM_E_UNSUPPORTED;          // grid y / z limits
+  if (views > 65535 || out_h > 4 * 65535) return POEM_E_UNSUPPORTED;      // grid y / z limits
   HIPCHK(poem_launch_warp_affine(src, (const long long*)src_offsets, src_hw, m_inv, gain, out_f32, out_u8, views, out_h,
                                  out_w, (hipStream_t)stream));
   return POEM_OK;

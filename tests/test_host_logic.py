@@ -175,6 +175,22 @@ m = MeanEPE("v"); m.feed(pred[lo:hi], gt[lo:hi]); m.reduce()
 full = MeanEPE("v"); full.feed(pred, gt)
 assert abs(m.result() - full.result()) < 1e-6, (m.result(), full.result())
 t = torch.tensor([float(rank + 1)], dtype=torch.float64); pdist.all_reduce_max_(t); assert t.item() == 2.0
+# input side (N4): shards are dealt by rank (webdataset.split_by_node), no data-path collective; the union is the epoch
+sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import transform_oracle as to
+d = sys.argv[2]
+if rank == 0:
+    for si in range(4):
+        pk.wds.write_shard(os.path.join(d, f"Toy_mv_test-{si:06d}.tar"),
+                           [to.synthetic_frame(10 * si + i, n_cams=2, raw=(48, 32)) for i in range(3)])
+pdist.barrier()
+cfg = pk.wds.dataset_cfg(os.path.join(d, "Toy_mv_test-{000000..000003}.tar"))
+ds = pk.MultiviewWebDataset(cfg, data_preset=cfg.DATA_PRESET, is_train=False, defer_images=True)
+assert len(ds.shards) == 2 and ds.shards == pk.wds.expand_urls(cfg.URLS)[rank::2]
+keys = [f["__key__"] for f in ds]
+allk = [None, None]; dist.all_gather_object(allk, keys)
+assert len(keys) == 6 and sorted(allk[0] + allk[1]) == sorted(f"frame{10 * si + i:06d}" for si in range(4) for i in range(3))
+assert not set(allk[0]) & set(allk[1])
 pdist.barrier()
 if rank == 0: print("DP_OK", m.result())
 dist.destroy_process_group()
@@ -186,7 +202,7 @@ def test_dp_metric_allreduce_gloo_world2(tmp_path):
     script.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script), ROOT],
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script), ROOT, str(tmp_path)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "DP_OK" in out.stdout

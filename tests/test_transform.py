@@ -217,7 +217,7 @@ def test_warp_kernel_bit_exact_against_oracle():
     Ms[0] = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
     Ms[3] = np.array([[50, 0, 100], [0, 50, 100]], np.float32)                      # a single source pixel, mostly border
     gains = g.uniform(0.7, 1.3, size=(len(imgs), 3))
-    for out_size in ((256, 256), (100, 60)):
+    for out_size in ((256, 256), (100, 60), (101, 7), (3, 5)):
         u8 = pk.transform.warp_views(imgs, Ms, out_size, device=DEV, out="u8").cpu().numpy()
         f32 = pk.transform.warp_views(imgs, Ms, out_size, device=DEV).cpu().numpy()
         ug = pk.transform.warp_views(imgs, Ms, out_size, gains=gains, device=DEV, out="u8").cpu().numpy()
