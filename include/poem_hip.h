@@ -125,8 +125,8 @@ int poem_set_overlap(poem_handle_t h, int enable);
  *   POEM_PRECISION_FP32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products, k-ordered fma chains;
  *   POEM_PRECISION_SPLIT_F16X3 (opt-in, embed >= 128): hi/lo f16 splits of both operands on the f16 matrix cores
  *     (w_hi x_hi + w_hi x_lo + w_lo x_hi, fp32 accumulation; csrc/vecattn_split.hip) -- products carry ~22 significant
- *     bits instead of 24; measured MPVPE against the reference fixtures is unchanged at the 1e-5 mm level.  Requires
- *     |activations| < 1023 inside the attention MLPs (f16 range after the x64 pre-scale).
+ *     bits instead of 24; measured MPVPE against the reference fixtures is unchanged at the 1e-5 mm level.  The
+ *     ReLU outputs inside the attention MLPs saturate at 937.5 (f16 range after the x64 pre-scale).
  * Returns POEM_E_UNSUPPORTED when the handle has no split images (embed < 128). */
 #define POEM_PRECISION_FP32 0
 #define POEM_PRECISION_SPLIT_F16X3 1

@@ -8,11 +8,12 @@
 // The dropped w_lo x_lo term is O(2^-22) relative per product, i.e. at the level of fp32 round-off of a K = 256
 // contraction.  Both operands are pre-multiplied by powers of two (weights: per matrix so that max |w'| is in [8,16);
 // activations: SX = 64) so that the lo parts stay in the f16 normal range; the scales are undone exactly in the
-// epilogues (folded into the bias fma / the softmax scale).  |activation| must stay below 65504 / 64.
+// epilogues (folded into the bias fma / the softmax scale).  Activations saturate at 60000 / 64 = 937.5 (never inf).
 // Everything else (first layer 3 -> C, gathers, pos, softmax, weighted sum) is the fp32 arithmetic of vecattn.hip.
 // Measured parity (tests/test_hip_parity.py::test_split_precision_*): MPVPE vs the reference fixtures at the fp32
 // kernel's own level (~1e-5 mm, tolerance 1e-3 mm); tools/lab/split_precision_probe.py is the CPU pre-study.
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -20,6 +21,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 #define POEM_SPLIT_SX 64.0f
+#define POEM_SPLIT_MAX 60000.0f       // scaled activations saturate here (|x| = 937.5) instead of overflowing to inf
 
 // tools/lab only (POEM_VS_LAB): 1 = MFMAs replaced by a register touch (non-MFMA floor), 2 = every weight fragment load
 // hits the same 2 KiB (L1-resident: what the L2 stream costs), 3 = no v_j gathers in the epilogue
@@ -289,7 +291,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_split_kernel(VecAttnSpl
             const float4 bb = *reinterpret_cast<const float4*>(A.bd1 + cbase + 8 * g);
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(hh[4 * g + e] + (&bb.x)[e], 0.f) * POEM_SPLIT_SX;
+            for (int e = 0; e < 4; ++e)      // relu, x64, saturating below f16's largest finite value (one v_med3)
+              v[e] = __builtin_amdgcn_fmed3f((hh[4 * g + e] + (&bb.x)[e]) * POEM_SPLIT_SX, 0.f, POEM_SPLIT_MAX);
             store_split(X + (32 * p + j) * ROW + (tile * 4 + g) * 32 + h * 8, v);
           }
         }
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_split_kernel(VecAttnSpl
         for (int g = 0; g < 4; ++g) {
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[tp][p][4 * g + e], 0.f) * f2;
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(acc[tp][p][4 * g + e] * f2, 0.f, POEM_SPLIT_MAX);
           store_split(X + (32 * p + j) * ROW + ((wv * TPW + tp) * 4 + g) * 32 + h * 8, v);
         }
     __syncthreads();
@@ -416,7 +419,17 @@ static hipError_t launch_vs(const VecAttnSplitArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * groups)), dim3(NW * 64), lds, s, a);
+  // Persistent: as many blocks as the chip holds, items dealt round-robin (they all cost the same).  The compiler hoists
+  // ~20 per-lane address values out of the item loop and spills them; with one item per block that was 280 MB of scratch
+  // writes per launch (PMC WRITE_SIZE 308 MB against 26 MB of results).
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = cus * ((size_t)2 * lds <= 160 * 1024 ? 2 : 1);
+    if (const char* e = getenv("POEM_VS_PERSIST")) if (atoi(e) == 0) slots = 1 << 30;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long long>((long long)a.B * groups, slots)), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
 }
 
