@@ -270,7 +270,7 @@ def main():
             res["roofline"].update(kernel="vecattn_split_kernel", peak=F16_MFMA_PEAK_TFLOPS / 3.0,
                                    frac=res["roofline"]["achieved"] / (F16_MFMA_PEAK_TFLOPS / 3.0), traffic=None,
                                    note="peak = dense f16 MFMA peak / 3 (three MFMAs per fp32-equivalent product)")
-    elif C >= 128 and not parametric:
+    elif C >= 128 and not parametric and world == 1:
         # OPT-IN split-precision leg, reported beside the headline (never as `value`): same step with
         # poem_set_precision(SPLIT_F16X3); distance of its vertices from the fp32 path's on the same batch.
         try:

@@ -276,6 +276,36 @@ def test_split_precision_mode_vs_golden(name):
     assert _md(got, ref) < 1e-4
 
 
+def test_split_precision_stage_taps_vs_reference():
+    """Stage by stage (POEM-medium fixture: the reference's own per-block tensors): at every tap the split-precision path is
+    no further from the reference than 2x the exact path's distance + fp32 round-off of the tensor's scale."""
+    z, meta = load_golden("medium")
+    spec = meta["spec"]
+    cfg, w, consts, batch = case_setup(spec)
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    eng = head._engine_for(torch.device(DEV))
+    eng.enable_taps(True)
+    B, C, Q = len(spec["views"]), spec["embed"], 799
+    dist = {}
+    for mode in ("fp32", "split_f16x3"):
+        head.set_precision(mode)
+        with torch.no_grad():
+            head(feat, metas, rj)
+        for i in range(3):
+            for k in ("f_self", "f_cross", "feats", "xyz"):
+                ref = torch.from_numpy(z[f"tap.b{i}.{k}"])
+                got = eng.tap(f"b{i}.{k}", (B, Q, 3 if k == "xyz" else C))
+                got = got if k == "xyz" else got[:, ::(Q + ref.shape[1] - 1) // ref.shape[1]]
+                assert got.shape == ref.shape, (k, got.shape, ref.shape)
+                dist[(mode, i, k)] = (_md(got, ref), float(ref.abs().max()))
+    head.set_precision("fp32")
+    for i in range(3):
+        for k in ("f_self", "f_cross", "feats", "xyz"):
+            (de, scale), (ds, _) = dist[("fp32", i, k)], dist[("split_f16x3", i, k)]
+            assert ds <= 2 * de + 4e-6 * scale, (i, k, ds, de, scale)
+
+
 def test_split_precision_needs_embed_128():
     z, meta = load_golden("tiny")
     head = build_hip_head(meta["spec"], DEV)

@@ -136,3 +136,34 @@ def test_q3_quirk_flat_reshape_runs_of_799():
     flat = feats.reshape(B, -1)
     assert torch.equal(betas[:, 0], flat[:, 5 * 799 + 3])     # run 5, element 3 of the sample's flat storage
     assert float(flat[0, 5 * 799 + 3]) != float(feats[0, 3, 5])   # ... which is not (vertex 3, channel 5)
+
+
+def test_split_precision_arithmetic_emulated_in_the_oracle():
+    """The opt-in mode's arithmetic (vector-attention C x C products as f16 hi/lo splits, fp32 sums) emulated inside the
+    CPU oracle on the POEM-small fixture: its MPVPE from the plain-fp32 oracle stays at fp32 re-ordering level, two orders
+    below the 1e-3 mm bar (the pre-study behind csrc/vecattn_split.hip; tools/lab/split_precision_probe.py has the sweep)."""
+    import torch.nn.functional as F
+    z, meta = load_golden("small")
+    cfg, w, consts, batch = case_setup(meta["spec"])
+    ref = run_oracle(cfg, w, consts, batch)["all_coords_preds"]
+
+    def split(x):
+        hi = x.to(torch.float16).float()
+        return hi, (x - hi).to(torch.float16).float()
+
+    plain = po.linear
+
+    def lin(x, wt, b=None):
+        if wt.shape[0] != wt.shape[1] or x.dim() != 4:
+            return F.linear(x, wt, b)
+        (xh, xl), (wh, wl) = split(x), split(wt)
+        y = F.linear(xh, wh) + F.linear(xl, wh) + F.linear(xh, wl)
+        return y if b is None else y + b
+
+    po.linear = lin
+    try:
+        got = run_oracle(cfg, w, consts, batch)["all_coords_preds"]
+    finally:
+        po.linear = plain
+    d_mm = float((got[-1, :, 21:] - ref[-1, :, 21:]).norm(dim=-1).mean()) * 1e3
+    assert 0 < d_mm < 1e-4, d_mm
