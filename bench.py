@@ -149,7 +149,7 @@ def main():
                     help="medium_MANO-style parametric tail (BASELINE configs[2]); MANO itself is licence-gated, the bench "
                          "plugs a cheap device-side stand-in layer in its place")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end scope leg (images -> HRNet on PyTorch-ROCm -> verts)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "split_f16x3"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "split_f16x3", "split_f16x3_all"],
                     help="fp32 (default, exact fp32 matrix-core products) | split_f16x3 (opt-in hi/lo f16 split of the vector "
                          "attention's C x C GEMMs; include/poem_hip.h)")
     ap.add_argument("--overlap", type=int, default=1, help="0: issue every kernel on one stream (A/B of the side streams)")
@@ -288,7 +288,21 @@ def main():
                 sdt = (time.perf_counter() - t0) / args.steps
                 n_s, ms_s = eng.profile_read(reset=True)
                 eng.profile_enable(0)
+                head.set_precision("split_f16x3_all")
+                for _ in range(2):
+                    got_all = step()["all_coords_preds"]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                adt = (time.perf_counter() - t0) / args.steps
                 head.set_precision("fp32")
+            res["split_f16x3_all_scope"] = {
+                "value": args.batch * world / adt, "unit": "samples/s", "ms_per_step": adt * 1e3,
+                "mpvpe_vs_fp32_path_mm": float(torch.norm(got_all[-1, :, 21:] - exact[-1, :, 21:], dim=-1).mean()) * 1e3,
+                "note": "opt-in POEM_PRECISION_SPLIT_F16X3_ALL: the same hi/lo f16 scheme also in every panel GEMM (all Linears "
+                        "but the K = 4C one); cross attention, K/V images, softmaxes, LayerNorms, sampling: exact fp32"}
             d = float(torch.norm(got[-1, :, 21:] - exact[-1, :, 21:], dim=-1).mean()) * 1e3
             res["split_f16x3_scope"] = {"value": args.batch * world / sdt, "unit": "samples/s", "ms_per_step": sdt * 1e3,
                                         "mpvpe_vs_fp32_path_mm": d,

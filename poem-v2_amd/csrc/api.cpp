@@ -47,6 +47,9 @@ hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src
                                         const void* wg1, const float* bg1, const void* wg2, const float* bg2, float* out,
                                         int B, int Q, int C, int ldq, int ldk, int ldv, int composed, hipStream_t s);
 hipError_t poem_launch_pack_split(const float* w, int C, void* img, float* scale_out, hipStream_t s);
+hipError_t poem_launch_pack_split_tiles(const float* w, int N, int K, void* img, float* scales, int scale_stride, hipStream_t s);
+void poem_gemm_split_context(const void* packed, size_t bytes, const void* split, const float* scales);
+void poem_gemm_split_explicit(const void* img, const float* scales);
 hipError_t poem_launch_vector_attention_split(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                               const int* idx, int shared_idx, const float* q, const float* k,
                                               const float* v, int nsrc, const float* wd1, const float* bd1,
@@ -200,7 +203,13 @@ struct poem_handle_s {
   struct SplitW { const void* w[3]; const float* scales; };
   std::vector<SplitW> split;         // [2 * block + (0 self | 1 cross)]
   void* split_mem = nullptr;
-  int precision = 0;                 // POEM_PRECISION_FP32 | POEM_PRECISION_SPLIT_F16X3
+  int precision = 0;                 // POEM_PRECISION_FP32 | POEM_PRECISION_SPLIT_F16X3 | POEM_PRECISION_SPLIT_F16X3_ALL
+  // SPLIT_F16X3_ALL: a byte-for-byte mirror of the packed arena holding the hi | lo f16 image of every packed Linear
+  // (gemm.hip: same tile size as the fp32 fragment image) + one scale slot per 256 bytes of image
+  const char* packed_base = nullptr;
+  size_t packed_size = 0;
+  char* gemm_split = nullptr;
+  float* gemm_scales = nullptr;
   bool taps = false;
   struct Tap { const void* p; int64_t elems; };
   std::map<std::string, Tap> tapmap;
@@ -433,7 +442,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     if (ov && i > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
     {
     PROF_START();
-    if (h->precision == POEM_PRECISION_SPLIT_F16X3) {
+    if (h->precision != POEM_PRECISION_FP32) {
       const auto& sw = h->split[2 * i];
       HIPCHK(poem_launch_vector_attention_split(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q,
                                                 h->R(vsb + 4), h->R(vsb + 5), sw.w[0], h->R(vsb + 7), sw.w[1], sw.w[2],
@@ -450,7 +459,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     HIPCHK(poem_launch_gemm(p.f_self[i], C, h->fused[i].w[4], h->fused[i].b[4], nullptr, 0, p.qc, C, BQ, C, C, POEM_ACT_NONE, s));
     {
     PROF_START();
-    if (h->precision == POEM_PRECISION_SPLIT_F16X3) {
+    if (h->precision != POEM_PRECISION_FP32) {
       const auto& sw = h->split[2 * i + 1];
       HIPCHK(poem_launch_vector_attention_split(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
                                                 p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4), h->R(vcb + 5), sw.w[0],
@@ -589,17 +598,32 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   auto* h = new poem_handle_s();
   h->cfg = *cfg;
   h->specs = tensor_table(*cfg);
-  if (n != (int)h->specs.size() || packed_bytes < poem_packed_bytes(cfg)) { delete h; return POEM_E_ARG; }
+  if (n != (int)h->specs.size() || packed_bytes < poem_packed_bytes(cfg)) { poem_destroy(h); return POEM_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   char* cur = (char*)packed;
+  h->packed_base = (const char*)packed;
+  h->packed_size = packed_bytes;
+  if (cfg->embed >= 128) {
+    if (hipMalloc((void**)&h->gemm_split, packed_bytes) != hipSuccess ||
+        hipMalloc((void**)&h->gemm_scales, (packed_bytes / 256 + 1) * sizeof(float)) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
+    }
+  }
+  // mirror of a freshly packed fp32 image at `at`: the split image of the same row-major weight
+  auto mirror = [&](const float* w_rows, int rows, int cols, const char* at) -> hipError_t {
+    if (!h->gemm_split || cols % 16) return hipSuccess;
+    const size_t off = (size_t)(at - (const char*)packed);
+    return poem_launch_pack_split_tiles(w_rows, rows, cols, h->gemm_split + off, h->gemm_scales + off / 256, cols / 2, s);
+  };
   h->raw.resize(n);
   h->packed.assign(n, nullptr);
   for (int i = 0; i < n; ++i) {
-    if (!raw_host[i]) { delete h; return POEM_E_ARG; }
+    if (!raw_host[i]) { poem_destroy(h); return POEM_E_ARG; }
     h->raw[i] = (const float*)raw_host[i];
     if (h->specs[i].pack) {
       hipError_t e = poem_launch_pack_linear(h->raw[i], h->specs[i].rows, h->specs[i].cols, cur, s);
-      if (e != hipSuccess) { g_last_hip_error = (int)e; delete h; return POEM_E_LAUNCH; }
+      if (e == hipSuccess) e = mirror(h->raw[i], h->specs[i].rows, h->specs[i].cols, cur);
+      if (e != hipSuccess) { g_last_hip_error = (int)e; poem_destroy(h); return POEM_E_LAUNCH; }
       h->packed[i] = cur;
       cur += align_up(packed_bytes_linear(h->specs[i].rows, h->specs[i].cols), 256);
     }
@@ -609,7 +633,7 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   if (C >= 128) {
     h->split.resize(2 * cfg->nblocks);
     if (hipMalloc(&h->split_mem, (size_t)2 * cfg->nblocks * ((size_t)3 * C * C * 4 + 256)) != hipSuccess) {
-      g_last_hip_error = (int)hipGetLastError(); delete h; return POEM_E_LAUNCH;
+      g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
     }
   }
   {
@@ -628,6 +652,7 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
     auto pack_rows = [&](int nslots, const void** wout) {
       *wout = cur;
       LOK(poem_launch_pack_linear(raw_rows, nslots * C, C, cur, s));
+      LOK(mirror(raw_rows, nslots * C, C, cur));
       cur += align_up(packed_bytes_linear(nslots * C, C), 256);
     };
     for (int b = 0; b < cfg->nblocks && ok; ++b) {
@@ -698,8 +723,10 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
       // F4: reg_branch.0 | intermediate.dense share f_cross; intermediate.dense is (4C, C): four C-row slabs of the raw tensor
       f.w[3] = cur;
       ok = ok && poem_launch_pack_linear(h->raw[bb + B_REG0_W], C, C, cur, s) == hipSuccess;
+      LOK(mirror(h->raw[bb + B_REG0_W], C, C, cur));
       cur += packed_bytes_linear(C, C);
       ok = ok && poem_launch_pack_linear(h->raw[bb + B_INT_W], 4 * C, C, cur, s) == hipSuccess;
+      LOK(mirror(h->raw[bb + B_INT_W], 4 * C, C, cur));
       cur += packed_bytes_linear(4 * C, C);
       cur = (char*)packed + align_up((size_t)(cur - (char*)packed), 256);
       f.b[3] = (const float*)cur;
@@ -707,7 +734,7 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
       ok = ok && hipMemcpyAsync(cur + (size_t)C * 4, h->raw[bb + B_INT_B], (size_t)4 * C * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
       cur += align_up((size_t)5 * C * 4, 256);
     }
-    if (!ok) { g_last_hip_error = (int)hipGetLastError(); delete h; return POEM_E_LAUNCH; }
+    if (!ok) { g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH; }
   }
   h->idx_dev = (int32_t*)cur;
   cur += align_up((size_t)poem_handle_s::IDX_CAP * 4, 256);
@@ -716,7 +743,7 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   float* sine = (float*)cur;
   rc = poem_pe_table(h->P(T_ADAPT_W), h->R(T_ADAPT_B), C, cfg->feat_h, cfg->feat_w, cfg->max_views, sine, h->pe_table,
                      stream);
-  if (rc != POEM_OK) { delete h; return rc; }
+  if (rc != POEM_OK) { poem_destroy(h); return rc; }
   {
     bool ok = hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess;
@@ -736,6 +763,8 @@ void poem_destroy(poem_handle_t h) {
   de(h->ev_fork); de(h->ev_join_bps); de(h->ev_join_knn);
   for (int i = 0; i < 8; ++i) { de(h->ev_bps[i]); de(h->ev_xyz[i]); de(h->ev_knn[i]); }
   if (h->split_mem) (void)hipFree(h->split_mem);
+  if (h->gemm_split) (void)hipFree(h->gemm_split);
+  if (h->gemm_scales) (void)hipFree(h->gemm_scales);
   if (h->bps_stream) (void)hipStreamDestroy(h->bps_stream);
   if (h->knn_stream) (void)hipStreamDestroy(h->knn_stream);
   delete h;
@@ -748,8 +777,8 @@ int poem_set_overlap(poem_handle_t h, int enable) {
 }
 
 int poem_set_precision(poem_handle_t h, int mode) {
-  if (!h || (mode != POEM_PRECISION_FP32 && mode != POEM_PRECISION_SPLIT_F16X3)) return POEM_E_ARG;
-  if (mode == POEM_PRECISION_SPLIT_F16X3 && !h->split_mem) return POEM_E_UNSUPPORTED;      // embed < 128
+  if (!h || mode < POEM_PRECISION_FP32 || mode > POEM_PRECISION_SPLIT_F16X3_ALL) return POEM_E_ARG;
+  if (mode != POEM_PRECISION_FP32 && (!h->split_mem || !h->gemm_split)) return POEM_E_UNSUPPORTED;      // embed < 128
   h->precision = mode;
   return POEM_OK;
 }
@@ -864,6 +893,24 @@ int poem_cross_attention(const float* q, const float* k, const float* v, float* 
   if (need && (!scratch || scratch_bytes < need || ((uintptr_t)scratch & 15))) return POEM_E_WORKSPACE;
   HIPCHK(poem_launch_cross_attention(q, k, v, ctx, batch, nq, nk, embed, heads, embed, (float*)scratch,
                                      (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_pack_split_gemm(const float* w, int out_features, int in_features, void* image, float* scales, void* stream) {
+  if (!w || !image || !scales || out_features <= 0 || in_features <= 0 || in_features % 16) return POEM_E_ARG;
+  HIPCHK(poem_launch_pack_split_tiles(w, out_features, in_features, image, scales, 1, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_gemm_split(const float* x, int ldx, const void* image, const float* scales, const float* bias, const float* residual,
+                    int ldr, float* y, int ldy, int m, int n, int k, int act, void* stream) {
+  if (!x || !image || !scales || !y || m <= 0 || n <= 0 || k <= 0 || k % 16 || n % 32) return POEM_E_ARG;
+  if (act < POEM_ACT_NONE || act > POEM_ACT_GELU) return POEM_E_ARG;
+  poem_gemm_split_explicit(image, scales);
+  const hipError_t e = poem_launch_gemm(x, ldx, image, bias, residual, ldr, y, ldy, m, n, k, act, (hipStream_t)stream);
+  poem_gemm_split_explicit(nullptr, nullptr);
+  if (e == hipErrorInvalidValue) return POEM_E_UNSUPPORTED;          // shape outside the panel kernel's range
+  HIPCHK(e);
   return POEM_OK;
 }
 
@@ -1016,6 +1063,15 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   const poem_config_t& c = h->cfg;
   if (c.nblocks > 8) return POEM_E_UNSUPPORTED;
   if (c.parametric && (!pose_aa || !betas)) return POEM_E_ARG;
+  // SPLIT_F16X3_ALL: every panel GEMM enqueued by this call whose weight lies in this handle's packed arena takes the split
+  // image at the same offset (gemm.hip); cleared on every way out
+  struct SplitCtx {
+    explicit SplitCtx(poem_handle_t hh) {
+      if (hh->precision == POEM_PRECISION_SPLIT_F16X3_ALL)
+        poem_gemm_split_context(hh->packed_base, hh->packed_size, hh->gemm_split, hh->gemm_scales);
+    }
+    ~SplitCtx() { poem_gemm_split_context(nullptr, 0, nullptr, nullptr); }
+  } split_ctx(h);
   const int B = batch, BN = view_offsets_host[B];
   if (view_offsets_host[0] != 0 || BN < B) return POEM_E_ARG;
   std::vector<int32_t> vs(BN), pei(BN);

@@ -7,6 +7,67 @@
 #include <algorithm>
 #include <cstdlib>
 
+// ---- opt-in split precision (POEM_PRECISION_SPLIT_F16X3_ALL; see vecattn_split.hip for the scheme) -----------------------
+// A Linear's weight as hi | lo f16 fragments for v_mfma_f32_32x32x16_f16, pre-multiplied PER 32-ROW TILE by a power of two
+// (max |w'| of the tile in [8,16)):  image[((nt * K/16 + kc) * 2 + part) * 64 + lane] = half8(W'[32 nt + (lane & 31)]
+// [16 kc + 8 (lane >> 5) + 0..7]).  A tile is K * 128 bytes -- exactly the size of the fp32 fragment image's tile, so a
+// split arena mirrors the fp32 packed arena byte for byte and any (base + tiles) pointer maps by adding one offset.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define POEM_GEMM_SX 16.0f            // activation pre-scale (power of two); scaled activations saturate at +-60000
+__global__ __launch_bounds__(256) void pack_split_tiles_kernel(const float* __restrict__ W, int N, int K,
+                                                              h8* __restrict__ img, float* __restrict__ scales,
+                                                              int scale_stride) {
+  __shared__ float red[256];
+  const int nt = blockIdx.x, KC = K / 16;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < 32 * K; i += 256) {
+    const int row = 32 * nt + i / K;
+    if (row < N) m = fmaxf(m, fabsf(W[(size_t)row * K + i % K]));
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  m = red[0];
+  int e = 0;
+  if (m > 0.f) (void)frexpf(m, &e);
+  const float sc = m > 0.f ? ldexpf(1.0f, 4 - e) : 1.0f;
+  if (threadIdx.x == 0) scales[(size_t)nt * scale_stride] = sc;
+  for (int idx = threadIdx.x; idx < KC * 64; idx += 256) {
+    const int lane = idx & 63, kc = idx >> 6, row = 32 * nt + (lane & 31);
+    h8 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float v = row < N ? W[(size_t)row * K + 16 * kc + 8 * (lane >> 5) + t] * sc : 0.f;
+      hi[t] = (_Float16)v;
+      lo[t] = (_Float16)(v - (float)hi[t]);
+    }
+    img[((size_t)(nt * KC + kc) * 2 + 0) * 64 + lane] = hi;
+    img[((size_t)(nt * KC + kc) * 2 + 1) * 64 + lane] = lo;
+  }
+}
+
+// scales[nt * scale_stride]: one float per 32-row tile (scale_stride in floats; K/2 when the scales mirror a packed arena
+// at one float per 256 bytes of image)
+extern "C" hipError_t poem_launch_pack_split_tiles(const float* w, int N, int K, void* img, float* scales, int scale_stride,
+                                                   hipStream_t s) {
+  if (K % 16) return hipErrorInvalidValue;
+  pack_split_tiles_kernel<<<(N + 31) / 32, 256, 0, s>>>(w, N, K, (h8*)img, scales, scale_stride);
+  return hipGetLastError();
+}
+
+// The split arena of the handle whose forward is being enqueued (api.cpp sets / clears it around poem_head_forward):
+// fp32 image pointers inside [packed, packed + bytes) are redirected to the split image at the same offset; the tile
+// scales sit at one float per 256 bytes of image.  Host-side state, single enqueueing thread (as the reference).
+static struct { const char* packed; size_t bytes; const char* split; const float* scales; } g_split_ctx = {nullptr, 0, nullptr, nullptr};
+static struct { const void* img; const float* scales; } g_explicit_split = {nullptr, nullptr};
+extern "C" void poem_gemm_split_explicit(const void* img, const float* scales) { g_explicit_split = {img, scales}; }
+extern "C" void poem_gemm_split_context(const void* packed, size_t bytes, const void* split, const float* scales) {
+  g_split_ctx = {(const char*)packed, bytes, (const char*)split, scales};
+}
+
 __global__ void pack_linear_kernel(const float* __restrict__ w, int N, int K, float4* __restrict__ out, int total) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -228,11 +289,12 @@ struct PanelSegs {
   int seg_cols;
 };
 
-template <int NT, int MT, bool GELU, int OMODE>
+template <int NT, int MT, bool GELU, int OMODE, bool SPLIT = false>
 __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx, const float4* __restrict__ wl,
                                            const float* __restrict__ bias, const float* __restrict__ R, int ldr,
                                            float* __restrict__ Y, int ldy, int M, int K, int pact, int col0, int ycol0,
-                                           int bip, int blocks_in_panel) {
+                                           int bip, int blocks_in_panel, const float* __restrict__ tile_scales = nullptr,
+                                           int scale_stride = 0) {
   constexpr int NWV = 8;
   const int KC = K >> 3;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -255,6 +317,64 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[i][n] = zero16();
+    if constexpr (SPLIT) {
+      // f16 hi | lo splits on v_mfma_f32_32x32x16_f16, fp32 accumulation: per 16-k chunk the X fragment (8 fp32 per lane,
+      // two 16-byte loads, one chunk ahead) is scaled, split in registers and multiplied with the panel's hi | lo weight
+      // fragments from LDS as x_lo w_hi + x_hi w_hi + x_hi w_lo; the scales are undone below, before the shared epilogue.
+      const int KC16 = K >> 4;
+      const h8* wl8 = reinterpret_cast<const h8*>(wl);
+      unsigned xo8[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xo8[i] = (unsigned)min((mt0 + i) * 32 + r, M - 1) * (unsigned)(ldx * 4) + 32u * h;
+      float4 ra[2][MT][2];
+#define POEM_LOADA8(S, KCI) { const int kq_ = min((KCI), KC16 - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) { \
+        ra[S][i][0] = frag_load(xrs, (int)xo8[i], kq_ * 64); ra[S][i][1] = frag_load(xrs, (int)xo8[i], kq_ * 64 + 16); } }
+      POEM_LOADA8(0, 0)
+      for (int kc = 0; kc < KC16; ++kc) {
+        const int cur = kc & 1;
+        if (cur == 0) { POEM_LOADA8(1, kc + 1) } else { POEM_LOADA8(0, kc + 1) }
+        h8 ah[MT], al[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float4 lo4 = cur == 0 ? ra[0][i][0] : ra[1][i][0], hi4 = cur == 0 ? ra[0][i][1] : ra[1][i][1];
+          const float xv[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float v = __builtin_amdgcn_fmed3f(xv[t] * POEM_GEMM_SX, -60000.f, 60000.f);
+            ah[i][t] = (_Float16)v;
+            al[i][t] = (_Float16)(v - (float)ah[i][t]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const h8 bh = wl8[((size_t)(n * KC16 + kc) * 2 + 0) * 64 + lane];
+          const h8 bl = wl8[((size_t)(n * KC16 + kc) * 2 + 1) * 64 + lane];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            if (OMODE == 1) {
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al[i], acc[i][n], 0, 0, 0);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah[i], acc[i][n], 0, 0, 0);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah[i], acc[i][n], 0, 0, 0);
+            } else {
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][n], 0, 0, 0);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][n], 0, 0, 0);
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][n], 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef POEM_LOADA8
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float inv = 1.0f / (tile_scales[(size_t)(col0 / 32 + n) * scale_stride] * POEM_GEMM_SX);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][n][e] *= inv;
+      }
+    } else {
     float4 a0[MT], a1[MT], b0[NT], b1[NT];
 #define POEM_LOADA(A, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) A[i] = frag_load(xrs, (int)xo[i], kq_ * 32); }
 #define POEM_LOADB(B, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int n = 0; n < NT; ++n) B[n] = wl[(n * KC + kq_) * 64 + lane]; }
@@ -282,6 +402,7 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
 #undef POEM_LOADA
 #undef POEM_LOADB
 #undef POEM_MMA
+    }
     if (OMODE == 1) {
       // D[n][m]: lane = row of the tile, register e = channel 8(e>>2) + 4h + (e&3) of column tile n.
       // image float4 index ((mt * ldy/8 + kco) * 64 + lane), kco = (ycol0 + 32n)/8 + g      (ldy = segment width)
@@ -364,12 +485,13 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
   }
 }
 
-template <int NT, int MT, bool GELU>
+template <int NT, int MT, bool GELU, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restrict__ X, int ldx,
                                                             const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                             const float* __restrict__ R, int ldr, float* __restrict__ Y,
                                                             int ldy, int M, int N, int K, int act, int act_split, int act2,
-                                                            PanelSegs segs) {
+                                                            PanelSegs segs, const float* __restrict__ tile_scales = nullptr,
+                                                            int scale_stride = 0) {
   constexpr int NWV = 8;
   const int KC = K >> 3;
   extern __shared__ __attribute__((aligned(16))) float4 wl[];   // NT * KC * 64 float4
@@ -385,7 +507,8 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
   const int col0 = panel * NT * 32;
   const int pact = (col0 >= act_split) ? act2 : act;
   if (segs.seg_cols == 0) {
-    panel_rows<NT, MT, GELU, 0>(X, ldx, wl, bias, R, ldr, Y, ldy, M, K, pact, col0, col0, bip, blocks_in_panel);
+    panel_rows<NT, MT, GELU, 0, SPLIT>(X, ldx, wl, bias, R, ldr, Y, ldy, M, K, pact, col0, col0, bip, blocks_in_panel,
+                                       tile_scales, scale_stride);
     return;
   }
   const int sidx = col0 / segs.seg_cols;
@@ -394,11 +517,14 @@ __global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restr
   const int mode = segs.mode[sidx];
   // (the image modes exist in the activation-free instantiation only: the launcher sends segmented GEMMs there)
   if (!GELU && mode == 1)
-    panel_rows<NT, MT, false, 1>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
+    panel_rows<NT, MT, false, 1, SPLIT>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip,
+                                        blocks_in_panel, tile_scales, scale_stride);
   else if (!GELU && mode == 2)
-    panel_rows<NT, MT, false, 2>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
+    panel_rows<NT, MT, false, 2, SPLIT>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip,
+                                        blocks_in_panel, tile_scales, scale_stride);
   else
-    panel_rows<NT, MT, GELU, 0>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip, blocks_in_panel);
+    panel_rows<NT, MT, GELU, 0, SPLIT>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip,
+                                       blocks_in_panel, tile_scales, scale_stride);
 }
 
 static int poem_num_cus() {
@@ -412,12 +538,13 @@ static int poem_num_cus() {
   return cus;
 }
 
-template <int NT, int MT, bool GELU>
+template <int NT, int MT, bool GELU, bool SPLIT = false>
 static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
                                  float* Y, int ldy, int M, int N, int K, int act, int act_split, int act2,
-                                 const PanelSegs& segs, hipStream_t s) {
+                                 const PanelSegs& segs, hipStream_t s, const float* tile_scales = nullptr,
+                                 int scale_stride = 0) {
   const size_t lds = (size_t)NT * (K / 8) * 64 * 16;
-  auto kern = gemm_panel_kernel<NT, MT, GELU>;
+  auto kern = gemm_panel_kernel<NT, MT, GELU, SPLIT>;
   static size_t lds_set = 0;
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -428,7 +555,7 @@ static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const 
   const int panels = N / (32 * NT);
   const int grid = std::max(poem_num_cus(), panels);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, X, ldx, (const float4*)Wp, bias, R, ldr, Y, ldy, M, N, K, act,
-                     act_split, act2, segs);
+                     act_split, act2, segs, tile_scales, scale_stride);
   return hipGetLastError();
 }
 
@@ -445,7 +572,7 @@ static hipError_t launch_gemm_split_impl(const float* X, int ldx, const void* Wp
   // kernel is faster there (ffn output Linear, K = 4C)
   if (!seg && NT == 1 && N >= 64 && K >= 512 && !(act_split < N && act2 != act)) NT = 0;
   if (NT == 0 || K % 8 || ((uintptr_t)X & 15) || ldx % 4 || (unsigned long long)M * ldx * 4ull >= (1ull << 32)) {
-    if (seg || (act_split < N && act2 != act)) return hipErrorInvalidValue;
+    if (seg || (act_split < N && act2 != act) || g_explicit_split.img) return hipErrorInvalidValue;
     return poem_launch_gemm2(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, 0, 0, s);
   }
   const int mtiles = (M + 31) / 32, panels = N / (32 * NT);
@@ -454,6 +581,29 @@ static hipError_t launch_gemm_split_impl(const float* X, int ldx, const void* Wp
   const bool mt2 = 5 * cost(2) <= 6 * cost(1);   // 64-row wave tiles unless the 32-row split balances >= 20 % better
   const bool gelu = act == 2 || (act_split < N && act2 == 2);
   if (seg && gelu) return hipErrorInvalidValue;   // image outputs exist in the GELU-free instantiation only
+  // opt-in split precision: the weight image lies inside the registered arena (or explicit images were given)
+  const float* tsc = nullptr;
+  int tstride = 0;
+  const void* Wsplit = nullptr;
+  if (g_explicit_split.img) {
+    Wsplit = g_explicit_split.img; tsc = g_explicit_split.scales; tstride = 1;
+  } else if (g_split_ctx.packed && (const char*)Wp >= g_split_ctx.packed && (const char*)Wp < g_split_ctx.packed + g_split_ctx.bytes) {
+    const size_t off = (const char*)Wp - g_split_ctx.packed;
+    Wsplit = g_split_ctx.split + off; tsc = g_split_ctx.scales + off / 256; tstride = K / 2;
+  }
+  if (g_explicit_split.img && K % 16) return hipErrorInvalidValue;
+  if (Wsplit && K % 16 == 0 && (unsigned long long)M * ldx * 4ull + 64ull < (1ull << 32)) {
+#define POEM_PANEL_S(NTV)                                                                                                \
+    if (gelu)                                                                                                            \
+      return mt2 ? launch_panel_t<NTV, 2, true, true>(X, ldx, Wsplit, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s, tsc, tstride)   \
+                 : launch_panel_t<NTV, 1, true, true>(X, ldx, Wsplit, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s, tsc, tstride);  \
+    return mt2 ? launch_panel_t<NTV, 2, false, true>(X, ldx, Wsplit, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s, tsc, tstride)    \
+               : launch_panel_t<NTV, 1, false, true>(X, ldx, Wsplit, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s, tsc, tstride)
+    if (NT == 4) { POEM_PANEL_S(4); }
+    if (NT == 2) { POEM_PANEL_S(2); }
+    POEM_PANEL_S(1);
+#undef POEM_PANEL_S
+  }
 #define POEM_PANEL(NTV)                                                                                                  \
   if (gelu)                                                                                                              \
     return mt2 ? launch_panel_t<NTV, 2, true>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s)   \

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("POEM_HIP_LIB") or os.path.join(CSRC, "libpoem_hip.so"
 ASSETS = os.path.join(_HERE, "assets")
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-PRECISIONS = {"fp32": 0, "split_f16x3": 1}            # include/poem_hip.h POEM_PRECISION_*
+PRECISIONS = {"fp32": 0, "split_f16x3": 1, "split_f16x3_all": 2}            # include/poem_hip.h POEM_PRECISION_*
 
 
 class PoemConfig(ctypes.Structure):
@@ -52,6 +52,8 @@ SIGNATURES = {
     "poem_set_overlap": (_i, [_vp, _i]),
     "poem_set_precision": (_i, [_vp, _i]),
     "poem_pack_split_linear": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "poem_pack_split_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "poem_gemm_split": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_vector_attention_split": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                          _i, _i, _i, _vp]),
     "poem_gemm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -350,6 +352,21 @@ def vector_attention(query_xyz, src_xyz, anchor_xyz, idx, q, k, v, wd1, bd1, wd2
           "poem_vector_attention")
     return out
 
+
+
+def gemm_split(x, w, bias=None, residual=None, act=ACT_NONE):
+    """y = act(x w^T + bias) + residual through the split-precision panel GEMM (w: (N,K) row-major fp32 device tensor)."""
+    N, K = w.shape
+    M = x.shape[0]
+    nt = (N + 31) // 32
+    img = torch.empty(nt * 32 * K * 4, dtype=torch.uint8, device=w.device)
+    sc = torch.empty(nt, dtype=torch.float32, device=w.device)
+    check(lib().poem_pack_split_gemm(ptr(w), N, K, img.data_ptr(), sc.data_ptr(), stream()), "poem_pack_split_gemm")
+    y = torch.empty(M, N, dtype=torch.float32, device=w.device)
+    check(lib().poem_gemm_split(ptr(x), x.stride(0), img.data_ptr(), sc.data_ptr(), ptr(bias), ptr(residual),
+                                residual.stride(0) if residual is not None else 0, ptr(y), N, M, N, K, act, stream()),
+          "poem_gemm_split")
+    return y
 
 
 def pack_split_linear(w):
