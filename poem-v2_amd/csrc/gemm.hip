@@ -330,6 +330,7 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
 #define POEM_LOADA8(S, KCI) { const int kq_ = min((KCI), KC16 - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) { \
         ra[S][i][0] = frag_load(xrs, (int)xo8[i], kq_ * 64); ra[S][i][1] = frag_load(xrs, (int)xo8[i], kq_ * 64 + 16); } }
       POEM_LOADA8(0, 0)
+      h8 bh_next = wl8[lane], bl_next = wl8[64 + lane];
       for (int kc = 0; kc < KC16; ++kc) {
         const int cur = kc & 1;
         if (cur == 0) { POEM_LOADA8(1, kc + 1) } else { POEM_LOADA8(0, kc + 1) }
@@ -340,30 +341,40 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
           const float xv[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
 #pragma unroll
           for (int t = 0; t < 8; ++t) {
+#if defined(POEM_GS_LAB) && POEM_GS_LAB == 1        // lab: no conversion arithmetic (wrong numbers, timing only)
+            ah[i][t] = __builtin_bit_cast(_Float16, (unsigned short)__float_as_uint(xv[t]));
+            al[i][t] = ah[i][t];
+#else
             const float v = __builtin_amdgcn_fmed3f(xv[t] * POEM_GEMM_SX, -60000.f, 60000.f);
             ah[i][t] = (_Float16)v;
             al[i][t] = (_Float16)(v - (float)ah[i][t]);
+#endif
           }
         }
+        // weight fragments one column tile ahead (the first tile of the next chunk after the last one): an LDS read issued
+        // right in front of its MFMAs stalls the wave for the LDS latency every six MFMAs
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          const h8 bh = wl8[((size_t)(n * KC16 + kc) * 2 + 0) * 64 + lane];
-          const h8 bl = wl8[((size_t)(n * KC16 + kc) * 2 + 1) * 64 + lane];
+          const int nn = n + 1 < NT ? n + 1 : 0, kn = n + 1 < NT ? kc : min(kc + 1, KC16 - 1);
+          const h8 bh = bh_next, bl = bl_next;
+          bh_next = wl8[((size_t)(nn * KC16 + kn) * 2 + 0) * 64 + lane];
+          bl_next = wl8[((size_t)(nn * KC16 + kn) * 2 + 1) * 64 + lane];
+          __builtin_amdgcn_sched_barrier(0);
+          // part-major: MT independent accumulators between two MFMAs on the same one
+#define POEM_MMA8(XA, WB)                                                                                      \
+          _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                       \
+            acc[i][n] = OMODE == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(WB, XA[i], acc[i][n], 0, 0, 0)     \
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_f16(XA[i], WB, acc[i][n], 0, 0, 0);
+#if defined(POEM_GS_LAB) && POEM_GS_LAB == 2        // lab: no MFMAs
 #pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            if (OMODE == 1) {
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al[i], acc[i][n], 0, 0, 0);
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah[i], acc[i][n], 0, 0, 0);
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah[i], acc[i][n], 0, 0, 0);
-            } else {
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh, acc[i][n], 0, 0, 0);
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh, acc[i][n], 0, 0, 0);
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl, acc[i][n], 0, 0, 0);
-            }
-          }
+          for (int i = 0; i < MT; ++i) acc[i][n][0] += (float)al[i][0] * (float)bh[0] + (float)ah[i][1] * (float)bl[1];
+#else
+          POEM_MMA8(al, bh) POEM_MMA8(ah, bh) POEM_MMA8(ah, bl)
+#endif
+#undef POEM_MMA8
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
 #undef POEM_LOADA8
 #pragma unroll
@@ -578,7 +589,8 @@ static hipError_t launch_gemm_split_impl(const float* X, int ldx, const void* Wp
   const int mtiles = (M + 31) / 32, panels = N / (32 * NT);
   const int wpp = std::max(1, std::max(poem_num_cus(), panels) / panels) * 8;       // waves per panel
   auto cost = [&](int mt) { return (long)(((mtiles + mt - 1) / mt + wpp - 1) / wpp) * mt; };
-  const bool mt2 = 5 * cost(2) <= 6 * cost(1);   // 64-row wave tiles unless the 32-row split balances >= 20 % better
+  const bool mt2_default = 5 * cost(2) <= 6 * cost(1);   // 64-row wave tiles unless the 32-row split balances >= 20 % better
+  const bool mt2 = mt2_default;
   const bool gelu = act == 2 || (act_split < N && act2 == 2);
   if (seg && gelu) return hipErrorInvalidValue;   // image outputs exist in the GELU-free instantiation only
   // opt-in split precision: the weight image lies inside the registered arena (or explicit images were given)
@@ -593,6 +605,11 @@ static hipError_t launch_gemm_split_impl(const float* X, int ldx, const void* Wp
   }
   if (g_explicit_split.img && K % 16) return hipErrorInvalidValue;
   if (Wsplit && K % 16 == 0 && (unsigned long long)M * ldx * 4ull + 64ull < (1ull << 32)) {
+    // 32-row wave tiles always: the fp32->f16 split of the X fragment is serial work in front of each chunk's MFMAs,
+    // and a 64-row tile doubles it per wave (measured: 131072 x 1536 x 256 0.47 vs 0.64 ms, 1M x 256 x 384 1.33 vs 2.5 ms)
+    static const int force_mt = getenv("POEM_GS_MT") ? atoi(getenv("POEM_GS_MT")) : 1;       // lab A/B: 2 = 64-row tiles
+    const bool mt2 = force_mt == 2;
+    (void)mt2_default;
 #define POEM_PANEL_S(NTV)                                                                                                \
     if (gelu)                                                                                                            \
       return mt2 ? launch_panel_t<NTV, 2, true, true>(X, ldx, Wsplit, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s, tsc, tstride)   \
