@@ -13,6 +13,9 @@
 // [16 kc + 8 (lane >> 5) + 0..7]).  A tile is K * 128 bytes -- exactly the size of the fp32 fragment image's tile, so a
 // split arena mirrors the fp32 packed arena byte for byte and any (base + tiles) pointer maps by adding one offset.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#ifndef POEM_GS_WAVES
+#define POEM_GS_WAVES 12           // waves per block of the split panel kernel (activation-free / ReLU instantiation)
+#endif
 #define POEM_GEMM_SX 16.0f            // activation pre-scale (power of two); scaled activations saturate at +-60000
 __global__ __launch_bounds__(256) void pack_split_tiles_kernel(const float* __restrict__ W, int N, int K,
                                                               h8* __restrict__ img, float* __restrict__ scales,
@@ -295,7 +298,7 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
                                            float* __restrict__ Y, int ldy, int M, int K, int pact, int col0, int ycol0,
                                            int bip, int blocks_in_panel, const float* __restrict__ tile_scales = nullptr,
                                            int scale_stride = 0) {
-  constexpr int NWV = 8;
+  constexpr int NWV = (SPLIT && !GELU) ? POEM_GS_WAVES : 8;      // split variant: 3 waves per SIMD (<= 170 VGPRs)
   const int KC = K >> 3;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
   const int mtiles = (M + 31) / 32;
@@ -497,13 +500,13 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
 }
 
 template <int NT, int MT, bool GELU, bool SPLIT = false>
-__global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const float* __restrict__ X, int ldx,
+__global__ __launch_bounds__((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512, 2) void gemm_panel_kernel(const float* __restrict__ X, int ldx,
                                                             const float4* __restrict__ Wp, const float* __restrict__ bias,
                                                             const float* __restrict__ R, int ldr, float* __restrict__ Y,
                                                             int ldy, int M, int N, int K, int act, int act_split, int act2,
                                                             PanelSegs segs, const float* __restrict__ tile_scales = nullptr,
                                                             int scale_stride = 0) {
-  constexpr int NWV = 8;
+  constexpr int NWV = (SPLIT && !GELU) ? POEM_GS_WAVES : 8;      // split variant: 3 waves per SIMD (<= 170 VGPRs)
   const int KC = K >> 3;
   extern __shared__ __attribute__((aligned(16))) float4 wl[];   // NT * KC * 64 float4
   const int tid = threadIdx.x;
@@ -565,8 +568,8 @@ static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const 
   }
   const int panels = N / (32 * NT);
   const int grid = std::max(poem_num_cus(), panels);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, X, ldx, (const float4*)Wp, bias, R, ldr, Y, ldy, M, N, K, act,
-                     act_split, act2, segs, tile_scales, scale_stride);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512), lds, s, X, ldx, (const float4*)Wp, bias, R,
+                     ldr, Y, ldy, M, N, K, act, act_split, act2, segs, tile_scales, scale_stride);
   return hipGetLastError();
 }
 
