@@ -132,13 +132,18 @@ int poem_set_overlap(poem_handle_t h, int enable);
 #define POEM_PRECISION_SPLIT_F16X3 1
 /*   POEM_PRECISION_SPLIT_F16X3_ALL (opt-in): additionally every Linear that runs on the panel GEMM kernel (all of them
  *     except the K = 4C feed-forward output Linear and the narrow ones) uses the same hi/lo scheme -- weights split per 32-row
- *     tile at handle creation, activations scaled by 16, split in registers (saturating at |x| = 3750); the attention
- *     K/V fragment images it writes stay fp32, the cross attention itself stays exact fp32. */
+ *     tile at handle creation, activations scaled by 16, split in registers (saturating at |x| = 3750); and the two
+ *     contractions of the cross attention for head dims 32 / 64 (from the same fp32 K/V fragment images, split in
+ *     registers).  Softmaxes, LayerNorms, sampling, neighbour searches, the K = 4C Linear: exact fp32. */
 #define POEM_PRECISION_SPLIT_F16X3_ALL 2
 int poem_set_precision(poem_handle_t h, int mode);
 /* Operator level of the split panel GEMM: image (ceil(n/32)*32 * k * 4 bytes) and scales (ceil(n/32) floats, device) from
  * poem_pack_split_gemm; y = act(x w^T + bias) + residual as poem_gemm.  POEM_E_UNSUPPORTED for shapes the panel kernel
  * does not take (k % 16, n % 32, a 32-column panel beyond 128 KiB of LDS). */
+/* poem_cross_attention with both contractions as hi/lo f16 splits (head dims 32 and 64; POEM_E_UNSUPPORTED otherwise);
+ * same arguments, scratch and partial/combine structure as poem_cross_attention. */
+int poem_cross_attention_split_f16x3(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk,
+                                     int embed, int heads, void* scratch, size_t scratch_bytes, void* stream);
 int poem_pack_split_gemm(const float* w, int out_features, int in_features, void* image, float* scales, void* stream);
 int poem_gemm_split(const float* x, int ldx, const void* image, const float* scales, const float* bias, const float* residual,
                     int ldr, float* y, int ldy, int m, int n, int k, int act, void* stream);

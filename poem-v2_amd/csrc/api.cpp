@@ -50,6 +50,7 @@ hipError_t poem_launch_pack_split(const float* w, int C, void* img, float* scale
 hipError_t poem_launch_pack_split_tiles(const float* w, int N, int K, void* img, float* scales, int scale_stride, hipStream_t s);
 void poem_gemm_split_context(const void* packed, size_t bytes, const void* split, const float* scales);
 void poem_gemm_split_explicit(const void* img, const float* scales);
+void poem_cross_attention_split(int on);
 hipError_t poem_launch_vector_attention_split(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                               const int* idx, int shared_idx, const float* q, const float* k,
                                               const float* v, int nsrc, const float* wd1, const float* bd1,
@@ -935,6 +936,15 @@ int poem_vector_attention_split(const float* query_xyz, const float* src_xyz, co
   return POEM_OK;
 }
 
+int poem_cross_attention_split_f16x3(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk,
+                                     int embed, int heads, void* scratch, size_t scratch_bytes, void* stream) {
+  if (heads <= 0 || embed % heads || (embed / heads != 32 && embed / heads != 64)) return POEM_E_UNSUPPORTED;
+  poem_cross_attention_split(1);
+  const int rc = poem_cross_attention(q, k, v, ctx, batch, nq, nk, embed, heads, scratch, scratch_bytes, stream);
+  poem_cross_attention_split(0);
+  return rc;
+}
+
 int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream) {
   if (!query_xyz || !src_xyz || !idx || batch <= 0 || nq <= 0 || nsrc < 32 || nsrc > 4096) return POEM_E_ARG;
   HIPCHK(poem_launch_knn(query_xyz, src_xyz, idx, batch, nq, nsrc, (hipStream_t)stream));
@@ -1067,10 +1077,12 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   // image at the same offset (gemm.hip); cleared on every way out
   struct SplitCtx {
     explicit SplitCtx(poem_handle_t hh) {
-      if (hh->precision == POEM_PRECISION_SPLIT_F16X3_ALL)
+      if (hh->precision == POEM_PRECISION_SPLIT_F16X3_ALL) {
         poem_gemm_split_context(hh->packed_base, hh->packed_size, hh->gemm_split, hh->gemm_scales);
+        poem_cross_attention_split(1);
+      }
     }
-    ~SplitCtx() { poem_gemm_split_context(nullptr, 0, nullptr, nullptr); }
+    ~SplitCtx() { poem_gemm_split_context(nullptr, 0, nullptr, nullptr); poem_cross_attention_split(0); }
   } split_ctx(h);
   const int B = batch, BN = view_offsets_host[B];
   if (view_offsets_host[0] != 0 || BN < B) return POEM_E_ARG;

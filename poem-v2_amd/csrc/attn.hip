@@ -260,6 +260,141 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
 #endif
 }
 
+// ---- opt-in split precision (POEM_PRECISION_SPLIT_F16X3_ALL; scheme: vecattn_split.hip) --------------------------------
+// Same work decomposition, partials and combine as xattn_kernel; the two contractions run on v_mfma_f32_32x32x16_f16 as
+// hi | lo f16 splits with fp32 accumulation.  It consumes the SAME fp32 fragment images: a 32x32x16 MFMA sums over 16
+// k-slots and does not care which k they hold as long as both operands agree, so slot (half h, t) of chunk c takes
+//   t < 4: element 4h + t of fragment 2c,   t >= 4: element 4h + t - 4 of fragment 2c + 1
+// -- exactly the two float4 a lane already holds of K (channels), of V (keys) and, by the C/D layout, of P (registers
+// 8c .. 8c+7 of the score tile).  Operands are scaled by powers of two (K, Q, V: 16; P: 16) and split in registers; the
+// score scale is folded into the softmax constants, the output scale is undone once per item.
+typedef _Float16 xh8 __attribute__((ext_vector_type(8)));
+#define POEM_XS_SCALE 16.0f
+__device__ __forceinline__ void xsplit8(const float4 a, const float4 b, xh8& hi, xh8& lo) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float x = __builtin_amdgcn_fmed3f(v[t] * POEM_XS_SCALE, -60000.f, 60000.f);
+    hi[t] = (_Float16)x;
+    lo[t] = (_Float16)(x - (float)hi[t]);
+  }
+}
+__device__ __forceinline__ f32x16 xmfma16(xh8 a, xh8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <int DH, int W>
+__global__ __launch_bounds__(256 * W, W) void xattn_split_kernel(const float* __restrict__ q, int ldq,
+                                                                 const float4* __restrict__ kimg,
+                                                                 const float4* __restrict__ vimg,
+                                                                 float4* __restrict__ part_o, float2* __restrict__ part_ml,
+                                                                 int B, int NQ, int NK, int C, int heads, int tpc, float kc2,
+                                                                 float lazy_raw) {
+  constexpr int KC = DH / 8;               // fp32 K fragments (float4) per key tile
+  constexpr int KC16 = DH / 16;            // 16-channel chunks of the score contraction
+  constexpr int DT = (DH + 31) / 32;
+  constexpr float SS = POEM_XS_SCALE * POEM_XS_SCALE;      // scale the raw scores / the outputs carry
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int nqt = (NQ + 31) / 32, nkt = NK / 32, chunks = nkt / tpc;
+  const int items = B * heads * chunks * nqt;
+  const int nb = gridDim.x;
+  const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int ibase = items / nb, irem = items % nb;
+  const int lo_i = ibase * lb + min(lb, irem), hi_i = lo_i + ibase + (lb < irem ? 1 : 0);
+  const __amdgpu_buffer_rsrc_t krs = frag_rsrc(kimg, 0xffffffffu), vrs = frag_rsrc(vimg, 0xffffffffu);
+  const int loff = lane * 16;
+  const float kc2s = kc2 / SS, lazy_s = lazy_raw * SS;      // the softmax macro below works on the scaled scores
+  for (int item = lo_i + wv; item < hi_i; item += 4 * W) {
+    const int qt = item % nqt;
+    int t = item / nqt;
+    const int ch = t % chunks;
+    t /= chunks;
+    const int head = t % heads, b = t / heads;
+    const int qrow = min(qt * 32 + r, NQ - 1);
+    xh8 qh[KC16], ql[KC16];
+    {
+      const float* qp = q + ((size_t)b * NQ + qrow) * ldq + head * DH + 4 * h;
+#pragma unroll
+      for (int c = 0; c < KC16; ++c)
+        xsplit8(*reinterpret_cast<const float4*>(qp + 16 * c), *reinterpret_cast<const float4*>(qp + 16 * c + 8), qh[c], ql[c]);
+    }
+    const int kt0 = ch * tpc;
+    const int ktile_bytes = C * 128;
+    int koff = __builtin_amdgcn_readfirstlane((b * nkt + kt0) * ktile_bytes + head * KC * 1024);
+    int voff = __builtin_amdgcn_readfirstlane((b * nkt + kt0) * ktile_bytes + ((head * DH) / 32) * 4096);
+    float4 kf[KC], vf[DT][4];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) kf[kc] = frag_load(krs, loff, koff + kc * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) vf[d][g] = frag_load(vrs, loff, voff + (d * 4 + g) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[d] = zero16();
+    float m_ref = -INFINITY, nbias = 0.f, l_run = 0.f;
+    {
+    const float kc2 = kc2s, lazy_raw = lazy_s;               // shadow: POEM_SOFTMAX_TILE reads these names
+    for (int kt = 0; kt < tpc; ++kt) {
+      if ((kt & 3) == 0 && kt) __builtin_amdgcn_s_barrier();   // keeps the CU's waves on the same K/V tiles (see above)
+      // ---- S^T = K . Q^T on the scaled splits
+      f32x16 s = zero16();
+#pragma unroll
+      for (int c = 0; c < KC16; ++c) {
+        xh8 kh, kl;
+        xsplit8(kf[2 * c], kf[2 * c + 1], kh, kl);
+        s = xmfma16(kh, ql[c], s);
+        s = xmfma16(kh, qh[c], s);
+        s = xmfma16(kl, qh[c], s);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int adv = (kt + 1 < tpc) ? ktile_bytes : 0;
+      koff += adv;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) kf[kc] = frag_load(krs, loff, koff + kc * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      POEM_SOFTMAX_TILE(DT)
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- O^T += V^T . P^T: registers 8c .. 8c+7 of the numerators are the B operand of key chunk c
+      voff += adv;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        xh8 ph, pl;
+        xsplit8(make_float4(s[8 * c], s[8 * c + 1], s[8 * c + 2], s[8 * c + 3]),
+                make_float4(s[8 * c + 4], s[8 * c + 5], s[8 * c + 6], s[8 * c + 7]), ph, pl);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          xh8 vh, vl;
+          xsplit8(vf[d][2 * c], vf[d][2 * c + 1], vh, vl);
+          o[d] = xmfma16(vh, pl, o[d]);
+          o[d] = xmfma16(vh, ph, o[d]);
+          o[d] = xmfma16(vl, ph, o[d]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          vf[d][2 * c] = frag_load(vrs, loff, voff + (d * 4 + 2 * c) * 1024);
+          vf[d][2 * c + 1] = frag_load(vrs, loff, voff + (d * 4 + 2 * c + 1) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    }
+    // partial (O, m, l) in the exact kernel's units: O / (16 * 16), m in raw-score units
+    l_run = half_sum(l_run);
+    float4* po = part_o + (size_t)item * (DT * 4) * 64 + lane;
+    const float un = 1.0f / SS;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        nt_store4(po + (d * 4 + g) * 64, make_float4(o[d][4 * g] * un, o[d][4 * g + 1] * un, o[d][4 * g + 2] * un, o[d][4 * g + 3] * un));
+    if (h == 0) part_ml[(size_t)item * 32 + r] = make_float2(m_ref * un, l_run);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
+}
+
 // Head dims 128 and 256 (POEM-large / -huge): the K and V fragments of a key tile no longer fit the register file next
 // to Q and O, so they stream through a two-slot ring of 8 fragments (32 registers each): a tile is a fixed sequence of
 // NG = DH/64 + DH/64 operand groups -- K channel groups of 64, then V channel-tile pairs -- and while the 32 MFMAs of
@@ -473,6 +608,11 @@ static int poem_attn_cus() {
   return cus;
 }
 
+// opt-in split precision for the calls enqueued while it is set (api.cpp: around poem_head_forward in SPLIT_F16X3_ALL mode,
+// and by the operator-level entry point); head dims 32 and 64 only, the others keep the exact kernels
+static int g_xattn_split = 0;
+extern "C" void poem_cross_attention_split(int on) { g_xattn_split = on; }
+
 // q (B, NQ, ldq) row-major; kimg / vimg: fragment images of the (B*NK, C) key / value matrices
 extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, const void* kimg, const void* vimg,
                                                       float* ctx, int B, int NQ, int NK, int C, int heads,
@@ -509,6 +649,16 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
   if (const char* e = getenv("POEM_ATTN_W")) wsel = atoi(e);
   if (const char* e = getenv("POEM_ATTN_MAP")) map = atoi(e);
 #endif
+#define POEM_XSPLIT(D, WV)                                                                                         \
+  hipLaunchKernelGGL((xattn_split_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, (const float4*)kimg,    \
+                     (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw);                \
+  hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
+                     heads, chunks, waves, kc2)
+  if (g_xattn_split && (dh == 32 || dh == 64)) {
+    if (dh == 32) { POEM_XSPLIT(32, 3); } else { POEM_XSPLIT(64, 2); }
+    return hipGetLastError();
+  }
+#undef POEM_XSPLIT
   switch (dh) {
     case 8: POEM_XATTN(8, 4); break;
     case 16: POEM_XATTN(16, 4); break;

@@ -98,6 +98,34 @@ def test_cross_attention(C, heads, NQ, NK):
     assert _md(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("C,heads,NQ,NK", [(128, 4, 799, 1024), (256, 4, 799, 4096), (256, 4, 33, 64), (64, 2, 100, 256)])
+def test_cross_attention_split(C, heads, NQ, NK):
+    """Operator level of the opt-in split-precision cross attention (head dims 32 / 64; both contractions as f16 hi/lo
+    splits from the same fp32 fragment images, fp32 accumulation and softmax): the exact kernel's tolerance, incl. a
+    spiked key that forces the rescale branch."""
+    g = torch.Generator().manual_seed(C + NQ + 1)
+    B = 2
+    q, k, v = (torch.randn(B, n, C, generator=g) for n in (NQ, NK, NK))
+    q = q * 2.0
+    k[0, NK - 7] = q[0, 5] * 3
+    dh = C // heads
+    sp = lambda t: t.double().view(B, -1, heads, dh).permute(0, 2, 1, 3)   # noqa: E731
+    s = sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(dh)
+    ref = (torch.softmax(s, -1) @ sp(v)).permute(0, 2, 1, 3).reshape(B, NQ, C)
+    exact = hip.cross_attention(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    out = hip.cross_attention(q.to(DEV), k.to(DEV), v.to(DEV), heads, split=True)
+    assert not torch.equal(out, exact)
+    e_split, e_exact = _md(out, ref), _md(exact, ref)
+    assert e_split < 2e-5 and e_split < 4 * e_exact + 2e-6, (e_split, e_exact)
+
+
+def test_cross_attention_split_needs_head_dim_32_or_64():
+    q = torch.randn(1, 40, 512, device=DEV)
+    k = torch.randn(1, 64, 512, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip.cross_attention(q, k, k, 4, split=True)            # head dim 128: exact kernels only
+
+
 def test_cross_attention_spiked_key_forces_rescale():
     # one key dominates late in the sequence: the running max jumps -> alpha-rescale branch must be right
     g = torch.Generator().manual_seed(9)
