@@ -302,7 +302,8 @@ def main():
                 "value": args.batch * world / adt, "unit": "samples/s", "ms_per_step": adt * 1e3,
                 "mpvpe_vs_fp32_path_mm": float(torch.norm(got_all[-1, :, 21:] - exact[-1, :, 21:], dim=-1).mean()) * 1e3,
                 "note": "opt-in POEM_PRECISION_SPLIT_F16X3_ALL: the same hi/lo f16 scheme also in every panel GEMM (all Linears "
-                        "but the K = 4C one); cross attention, K/V images, softmaxes, LayerNorms, sampling: exact fp32"}
+                        "but the K = 4C one) and in the two contractions of the cross attention (K / V images written as "
+                        "hi | lo f16 by the projection GEMM); softmaxes, LayerNorms, sampling, neighbour searches: fp32"}
             d = float(torch.norm(got[-1, :, 21:] - exact[-1, :, 21:], dim=-1).mean()) * 1e3
             res["split_f16x3_scope"] = {"value": args.batch * world / sdt, "unit": "samples/s", "ms_per_step": sdt * 1e3,
                                         "mpvpe_vs_fp32_path_mm": d,

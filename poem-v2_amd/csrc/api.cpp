@@ -51,6 +51,8 @@ hipError_t poem_launch_pack_split_tiles(const float* w, int N, int K, void* img,
 void poem_gemm_split_context(const void* packed, size_t bytes, const void* split, const float* scales);
 void poem_gemm_split_explicit(const void* img, const float* scales);
 void poem_cross_attention_split(int on);
+int poem_gemm_split_applies(const void* Wp, int M, int ldx, int K);
+void poem_gemm_split_images(int on);
 hipError_t poem_launch_vector_attention_split(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                               const int* idx, int shared_idx, const float* q, const float* k,
                                               const float* v, int nsrc, const float* wd1, const float* bd1,
@@ -207,6 +209,7 @@ struct poem_handle_s {
   int precision = 0;                 // POEM_PRECISION_FP32 | POEM_PRECISION_SPLIT_F16X3 | POEM_PRECISION_SPLIT_F16X3_ALL
   // SPLIT_F16X3_ALL: a byte-for-byte mirror of the packed arena holding the hi | lo f16 image of every packed Linear
   // (gemm.hip: same tile size as the fp32 fragment image) + one scale slot per 256 bytes of image
+  bool kv_presplit[8] = {};
   const char* packed_base = nullptr;
   size_t packed_size = 0;
   char* gemm_split = nullptr;
@@ -372,6 +375,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     const size_t seg = (size_t)BS * C;
     float* outs[6] = {p.y1[i], p.y1[i] + seg, p.y1[i] + 2 * seg, p.y1[i] + 3 * seg, p.y1[i] + 4 * seg, p.y1[i] + 5 * seg};
     const int modes[6] = {1, 2, 1, 2, 0, 0};
+    h->kv_presplit[i] = poem_gemm_split_applies(f.w[0], BS, C, C) != 0;      // split GEMM -> the K / V images are split too
     HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, 6, outs, modes, sb));
     if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));
     return POEM_OK;
@@ -427,6 +431,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
         ldq = C;
       }
       if (ov && a == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
+      if (h->precision == POEM_PRECISION_SPLIT_F16X3_ALL) poem_cross_attention_split(h->kv_presplit[i] ? 2 : 1);
       HIPCHK(poem_launch_cross_attention_img(qptr, ldq, p.y1[i] + (size_t)(2 * a) * BS * C,
                                              p.y1[i] + (size_t)(2 * a + 1) * BS * C, p.ctx, B, Q, S, C, c.heads,
                                              p.attn_scratch, s));
@@ -1080,9 +1085,15 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
       if (hh->precision == POEM_PRECISION_SPLIT_F16X3_ALL) {
         poem_gemm_split_context(hh->packed_base, hh->packed_size, hh->gemm_split, hh->gemm_scales);
         poem_cross_attention_split(1);
+        const int dh = hh->cfg.embed / hh->cfg.heads;
+        poem_gemm_split_images(dh == 32 || dh == 64);          // the head dims the split cross attention takes
       }
     }
-    ~SplitCtx() { poem_gemm_split_context(nullptr, 0, nullptr, nullptr); poem_cross_attention_split(0); }
+    ~SplitCtx() {
+      poem_gemm_split_context(nullptr, 0, nullptr, nullptr);
+      poem_cross_attention_split(0);
+      poem_gemm_split_images(0);
+    }
   } split_ctx(h);
   const int B = batch, BN = view_offsets_host[B];
   if (view_offsets_host[0] != 0 || BN < B) return POEM_E_ARG;

@@ -281,7 +281,9 @@ __device__ __forceinline__ void xsplit8(const float4 a, const float4 b, xh8& hi,
 }
 __device__ __forceinline__ f32x16 xmfma16(xh8 a, xh8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-template <int DH, int W>
+// PRE: the images already hold hi | lo f16 operands (written by the split projection GEMM, gemm.hip output modes 1 / 2 in
+// the split variant): fragment 2c = the hi halfs of chunk c, fragment 2c+1 = the lo halfs -- no conversion of K / V here.
+template <int DH, int W, bool PRE>
 __global__ __launch_bounds__(256 * W, W) void xattn_split_kernel(const float* __restrict__ q, int ldq,
                                                                  const float4* __restrict__ kimg,
                                                                  const float4* __restrict__ vimg,
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(256 * W, W) void xattn_split_kernel(const float* __
 #pragma unroll
       for (int c = 0; c < KC16; ++c) {
         xh8 kh, kl;
-        xsplit8(kf[2 * c], kf[2 * c + 1], kh, kl);
+        if constexpr (PRE) { kh = __builtin_bit_cast(xh8, kf[2 * c]); kl = __builtin_bit_cast(xh8, kf[2 * c + 1]); }
+        else xsplit8(kf[2 * c], kf[2 * c + 1], kh, kl);
         s = xmfma16(kh, ql[c], s);
         s = xmfma16(kh, qh[c], s);
         s = xmfma16(kl, qh[c], s);
@@ -366,7 +369,8 @@ __global__ __launch_bounds__(256 * W, W) void xattn_split_kernel(const float* __
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
           xh8 vh, vl;
-          xsplit8(vf[d][2 * c], vf[d][2 * c + 1], vh, vl);
+          if constexpr (PRE) { vh = __builtin_bit_cast(xh8, vf[d][2 * c]); vl = __builtin_bit_cast(xh8, vf[d][2 * c + 1]); }
+          else xsplit8(vf[d][2 * c], vf[d][2 * c + 1], vh, vl);
           o[d] = xmfma16(vh, pl, o[d]);
           o[d] = xmfma16(vh, ph, o[d]);
           o[d] = xmfma16(vl, ph, o[d]);
@@ -610,7 +614,7 @@ static int poem_attn_cus() {
 
 // opt-in split precision for the calls enqueued while it is set (api.cpp: around poem_head_forward in SPLIT_F16X3_ALL mode,
 // and by the operator-level entry point); head dims 32 and 64 only, the others keep the exact kernels
-static int g_xattn_split = 0;
+static int g_xattn_split = 0;      // 1: split from fp32 images, 2: the images are already split (gemm.hip split output modes)
 extern "C" void poem_cross_attention_split(int on) { g_xattn_split = on; }
 
 // q (B, NQ, ldq) row-major; kimg / vimg: fragment images of the (B*NK, C) key / value matrices
@@ -649,13 +653,14 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
   if (const char* e = getenv("POEM_ATTN_W")) wsel = atoi(e);
   if (const char* e = getenv("POEM_ATTN_MAP")) map = atoi(e);
 #endif
-#define POEM_XSPLIT(D, WV)                                                                                         \
-  hipLaunchKernelGGL((xattn_split_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, (const float4*)kimg,    \
+#define POEM_XSPLIT(D, WV, PREV)                                                                                         \
+  hipLaunchKernelGGL((xattn_split_kernel<D, WV, PREV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, (const float4*)kimg, \
                      (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw);                \
   hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
   if (g_xattn_split && (dh == 32 || dh == 64)) {
-    if (dh == 32) { POEM_XSPLIT(32, 3); } else { POEM_XSPLIT(64, 2); }
+    if (g_xattn_split == 2) { if (dh == 32) { POEM_XSPLIT(32, 3, true); } else { POEM_XSPLIT(64, 2, true); } }
+    else { if (dh == 32) { POEM_XSPLIT(32, 3, false); } else { POEM_XSPLIT(64, 2, false); } }
     return hipGetLastError();
   }
 #undef POEM_XSPLIT

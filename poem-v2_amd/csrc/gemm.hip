@@ -61,6 +61,17 @@ extern "C" hipError_t poem_launch_pack_split_tiles(const float* w, int N, int K,
   return hipGetLastError();
 }
 
+// two fp32 fragments -> the hi | lo f16 operands of one 16-slot chunk (x16, saturating): the K / V images of the split mode
+__device__ __forceinline__ void split_pair(const float4 a, const float4 b, h8& hi, h8& lo) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float x = __builtin_amdgcn_fmed3f(v[t] * POEM_GEMM_SX, -60000.f, 60000.f);
+    hi[t] = (_Float16)x;
+    lo[t] = (_Float16)(x - (float)hi[t]);
+  }
+}
+
 // The split arena of the handle whose forward is being enqueued (api.cpp sets / clears it around poem_head_forward):
 // fp32 image pointers inside [packed, packed + bytes) are redirected to the split image at the same offset; the tile
 // scales sit at one float per 256 bytes of image.  Host-side state, single enqueueing thread (as the reference).
@@ -69,6 +80,17 @@ static struct { const void* img; const float* scales; } g_explicit_split = {null
 extern "C" void poem_gemm_split_explicit(const void* img, const float* scales) { g_explicit_split = {img, scales}; }
 extern "C" void poem_gemm_split_context(const void* packed, size_t bytes, const void* split, const float* scales) {
   g_split_ctx = {(const char*)packed, bytes, (const char*)split, scales};
+}
+
+// Will a panel GEMM with this weight pointer run the split variant (and therefore write SPLIT K / V images)?  Same rule as
+// the dispatch in launch_gemm_split_impl; api.cpp tells the cross attention which image format it gets.
+static int g_split_images = 0;
+extern "C" void poem_gemm_split_images(int on) { g_split_images = on; }
+extern "C" int poem_gemm_split_applies(const void* Wp, int M, int ldx, int K) {
+  const bool in_arena = g_split_ctx.packed && (const char*)Wp >= g_split_ctx.packed &&
+                        (const char*)Wp < g_split_ctx.packed + g_split_ctx.bytes;
+  return g_split_images && (g_explicit_split.img || in_arena) && K % 16 == 0 &&
+         (unsigned long long)M * ldx * 4ull + 64ull < (1ull << 32);
 }
 
 __global__ void pack_linear_kernel(const float* __restrict__ w, int N, int K, float4* __restrict__ out, int total) {
@@ -290,6 +312,7 @@ struct PanelSegs {
   float* ptr[6];
   int mode[6];
   int seg_cols;
+  int split_images;      // split variant only: write the K / V images as hi | lo f16 chunk operands (head dims 32 / 64)
 };
 
 template <int NT, int MT, bool GELU, int OMODE, bool SPLIT = false>
@@ -297,7 +320,7 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
                                            const float* __restrict__ bias, const float* __restrict__ R, int ldr,
                                            float* __restrict__ Y, int ldy, int M, int K, int pact, int col0, int ycol0,
                                            int bip, int blocks_in_panel, const float* __restrict__ tile_scales = nullptr,
-                                           int scale_stride = 0) {
+                                           int scale_stride = 0, int split_images = 0) {
   constexpr int NWV = (SPLIT && !GELU) ? POEM_GS_WAVES : 8;      // split variant: 3 waves per SIMD (<= 170 VGPRs)
   const int KC = K >> 3;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -424,6 +447,8 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
       for (int i = 0; i < MT; ++i) {
         if ((mt0 + i) * 32 >= M) break;
         float4* yp = reinterpret_cast<float4*>(Y) + ((size_t)(mt0 + i) * (ldy >> 3) + (ycol0 >> 3)) * 64 + lane;
+        float4 vprev = make_float4(0.f, 0.f, 0.f, 0.f);
+        (void)vprev;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -435,7 +460,19 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
             }
             if (pact == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (GELU && pact == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-            yp[(size_t)(n * 4 + g) * 64] = v;
+            if (SPLIT && split_images) {
+              // split images for the split cross attention: fragments (2c, 2c+1) of the fp32 image become the hi | lo f16
+              // operands of 16-slot chunk c at the same two addresses (attn.hip, xattn_split_kernel)
+              if (g & 1) {
+                h8 hi, lo;
+                split_pair(vprev, v, hi, lo);
+                yp[(size_t)(n * 4 + g - 1) * 64] = __builtin_bit_cast(float4, hi);
+                yp[(size_t)(n * 4 + g) * 64] = __builtin_bit_cast(float4, lo);
+              }
+              vprev = v;
+            } else {
+              yp[(size_t)(n * 4 + g) * 64] = v;
+            }
           }
       }
       continue;
@@ -473,8 +510,19 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
         if (OMODE == 2) {
           // image float4 index (((mt * ldy/32 + vt) * 4 + g) * 64 + lane), vt = ycol0/32 + n
           float4* yp = reinterpret_cast<float4*>(Y) + ((size_t)(mt0 + i) * (ldy >> 5) + (ycol0 >> 5) + n) * 256 + lane;
+          if (SPLIT && split_images) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              h8 hi, lo;
+              split_pair(make_float4(v[8 * c], v[8 * c + 1], v[8 * c + 2], v[8 * c + 3]),
+                         make_float4(v[8 * c + 4], v[8 * c + 5], v[8 * c + 6], v[8 * c + 7]), hi, lo);
+              yp[(size_t)(2 * c) * 64] = __builtin_bit_cast(float4, hi);
+              yp[(size_t)(2 * c + 1) * 64] = __builtin_bit_cast(float4, lo);
+            }
+          } else {
 #pragma unroll
           for (int g = 0; g < 4; ++g) yp[(size_t)g * 64] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+          }
         } else if (full) {
           if (rl) {
             float rr[16];                                      // 16 residual loads in flight, then 16 stores
@@ -532,10 +580,10 @@ __global__ __launch_bounds__((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512, 2) voi
   // (the image modes exist in the activation-free instantiation only: the launcher sends segmented GEMMs there)
   if (!GELU && mode == 1)
     panel_rows<NT, MT, false, 1, SPLIT>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip,
-                                        blocks_in_panel, tile_scales, scale_stride);
+                                        blocks_in_panel, tile_scales, scale_stride, segs.split_images);
   else if (!GELU && mode == 2)
     panel_rows<NT, MT, false, 2, SPLIT>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip,
-                                        blocks_in_panel, tile_scales, scale_stride);
+                                        blocks_in_panel, tile_scales, scale_stride, segs.split_images);
   else
     panel_rows<NT, MT, GELU, 0, SPLIT>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip,
                                        blocks_in_panel, tile_scales, scale_stride);
@@ -652,6 +700,7 @@ extern "C" hipError_t poem_launch_gemm_segs(const float* X, int ldx, const void*
   if (nsegs < 1 || nsegs > 6 || seg_cols % 32 || M % 32) return hipErrorInvalidValue;
   PanelSegs segs{};
   segs.seg_cols = seg_cols;
+  segs.split_images = g_split_images;
   for (int i = 0; i < nsegs; ++i) { segs.ptr[i] = outs[i]; segs.mode[i] = modes[i]; }
   const int N = seg_cols * nsegs;
   return launch_gemm_split_impl(X, ldx, Wp, bias, nullptr, 0, nullptr, 0, M, N, K, act, N, act, segs, s);
