@@ -341,15 +341,27 @@ __global__ __launch_bounds__(256 * W, W) void xattn_split_kernel(const float* __
     for (int kt = 0; kt < tpc; ++kt) {
       if ((kt & 3) == 0 && kt) __builtin_amdgcn_s_barrier();   // keeps the CU's waves on the same K/V tiles (see above)
       // ---- S^T = K . Q^T on the scaled splits
-      f32x16 s = zero16();
+      // two accumulators (even / odd chunks), part-major: consecutive MFMAs never share an accumulator (a dependent
+      // 32x32x16 pair does not issue back to back)
+      f32x16 s = zero16(), s1 = zero16();
+      xh8 kh[KC16], kl[KC16];
 #pragma unroll
       for (int c = 0; c < KC16; ++c) {
-        xh8 kh, kl;
-        if constexpr (PRE) { kh = __builtin_bit_cast(xh8, kf[2 * c]); kl = __builtin_bit_cast(xh8, kf[2 * c + 1]); }
-        else xsplit8(kf[2 * c], kf[2 * c + 1], kh, kl);
-        s = xmfma16(kh, ql[c], s);
-        s = xmfma16(kh, qh[c], s);
-        s = xmfma16(kl, qh[c], s);
+        if constexpr (PRE) { kh[c] = __builtin_bit_cast(xh8, kf[2 * c]); kl[c] = __builtin_bit_cast(xh8, kf[2 * c + 1]); }
+        else xsplit8(kf[2 * c], kf[2 * c + 1], kh[c], kl[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < KC16; ++c) { if (c & 1) s1 = xmfma16(kh[c], ql[c], s1); else s = xmfma16(kh[c], ql[c], s); }
+#pragma unroll
+      for (int c = 0; c < KC16; ++c) { if (c & 1) s1 = xmfma16(kh[c], qh[c], s1); else s = xmfma16(kh[c], qh[c], s); }
+#pragma unroll
+      for (int c = 0; c < KC16; ++c) { if (c & 1) s1 = xmfma16(kl[c], qh[c], s1); else s = xmfma16(kl[c], qh[c], s); }
+      if (KC16 > 1) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const f32x2 t2 = f32x2{s[i], s[i + 1]} + f32x2{s1[i], s1[i + 1]};
+          s[i] = t2[0]; s[i + 1] = t2[1];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       const int adv = (kt + 1 < tpc) ? ktile_bytes : 0;
@@ -366,15 +378,18 @@ __global__ __launch_bounds__(256 * W, W) void xattn_split_kernel(const float* __
         xh8 ph, pl;
         xsplit8(make_float4(s[8 * c], s[8 * c + 1], s[8 * c + 2], s[8 * c + 3]),
                 make_float4(s[8 * c + 4], s[8 * c + 5], s[8 * c + 6], s[8 * c + 7]), ph, pl);
+        xh8 vh[DT], vl[DT];
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-          xh8 vh, vl;
-          if constexpr (PRE) { vh = __builtin_bit_cast(xh8, vf[d][2 * c]); vl = __builtin_bit_cast(xh8, vf[d][2 * c + 1]); }
-          else xsplit8(vf[d][2 * c], vf[d][2 * c + 1], vh, vl);
-          o[d] = xmfma16(vh, pl, o[d]);
-          o[d] = xmfma16(vh, ph, o[d]);
-          o[d] = xmfma16(vl, ph, o[d]);
+          if constexpr (PRE) { vh[d] = __builtin_bit_cast(xh8, vf[d][2 * c]); vl[d] = __builtin_bit_cast(xh8, vf[d][2 * c + 1]); }
+          else xsplit8(vf[d][2 * c], vf[d][2 * c + 1], vh[d], vl[d]);
         }
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[d] = xmfma16(vh[d], pl, o[d]);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[d] = xmfma16(vh[d], ph, o[d]);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[d] = xmfma16(vl[d], ph, o[d]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
