@@ -674,7 +674,8 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
   hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
   if (g_xattn_split && (dh == 32 || dh == 64)) {
-    if (g_xattn_split == 2) { if (dh == 32) { POEM_XSPLIT(32, 3, true); } else { POEM_XSPLIT(64, 2, true); } }
+    static const int w3 = getenv("POEM_XS_W") ? atoi(getenv("POEM_XS_W")) : 2;      // lab A/B: waves per SIMD, head dim 64
+    if (g_xattn_split == 2) { if (dh == 32) { POEM_XSPLIT(32, 3, true); } else if (w3 == 3) { POEM_XSPLIT(64, 3, true); } else { POEM_XSPLIT(64, 2, true); } }
     else { if (dh == 32) { POEM_XSPLIT(32, 3, false); } else { POEM_XSPLIT(64, 2, false); } }
     return hipGetLastError();
   }
