@@ -153,6 +153,8 @@ def main():
                     help="fp32 (default, exact fp32 matrix-core products) | split_f16x3 (opt-in hi/lo f16 split of the vector "
                          "attention's C x C GEMMs; include/poem_hip.h)")
     ap.add_argument("--overlap", type=int, default=1, help="0: issue every kernel on one stream (A/B of the side streams)")
+    ap.add_argument("--anchor-tables", type=int, default=1,
+                    help="0: block 0's vector attentions in the per-sample form (A/B of poem_set_anchor_tables)")
     args = ap.parse_args()
 
     # POEM_DIST_BACKEND=gloo + POEM_SINGLE_DEVICE=1: rehearse the N-rank code path on a 1-GPU box (all ranks share cuda:0;
@@ -209,6 +211,10 @@ def main():
             head.set_precision(args.precision)
             for _ in range(args.warmup):
                 step()
+        if not args.anchor_tables:
+            head.set_anchor_tables(False)
+            for _ in range(args.warmup):
+                step()
         if not args.overlap:
             eng.set_overlap(False)
             for _ in range(args.warmup):
@@ -226,7 +232,8 @@ def main():
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     pdist.all_reduce_max_(tmax)
     dt = float(tmax.item())
-    n_launch, va_ms = eng.profile_read()
+    n_anch, anch_ms = eng.profile_read_anchored()      # block 0's table form (one C x C GEMM per neighbour column)
+    n_launch, va_ms = eng.profile_read()               # the full fused kernel (blocks 1, 2)
     eng.profile_enable(0)
 
     total_samples = args.batch * world * args.steps
@@ -263,6 +270,13 @@ def main():
                            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
                            "traffic": traffic, "launches_timed": n_launch, "avg_launch_ms": va_ms / n_launch,
                            "share_of_step": va_ms / (dt * 1e3)}
+        if n_anch > 0:
+            res["roofline"]["anchored_block0"] = {
+                "kernel": "vecattn_kernel MODE 2 (block 0: positional products from the per-forward anchor tables)",
+                "launches_timed": n_anch, "avg_launch_ms": anch_ms / n_anch, "share_of_step": anch_ms / (dt * 1e3),
+                "as_written_TFLOPs": vecattn_flops_per_launch(args.batch, C) / (anch_ms / n_anch * 1e-3) / 1e12,
+                "executed_TFLOPs": vecattn_flops_per_launch(args.batch, C) / 3.0 / (anch_ms / n_anch * 1e-3) / 1e12,
+                "note": "not part of `achieved`: a third of the as-written products are executed per sample"}
     res["mpvpe_synthetic_gt_mm"] = meter.result() * 1e3
     if args.precision != "fp32":
         res["dtype"] = "f32 (vector-attention C x C products as hi/lo f16 splits on the f16 matrix cores, fp32 accumulation)"

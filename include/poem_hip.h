@@ -121,6 +121,15 @@ int poem_decoder_forward(poem_handle_t h, const float* query_xyz, const float* q
  * internal side streams ordered against `stream` by events; everything is joined back before the call returns its
  * last launch, so the caller only ever synchronises its own stream.  0 = issue everything on `stream` in order. */
 int poem_set_overlap(poem_handle_t h, int enable);
+/* Block-0 anchor tables of poem_head_forward (default on, fp32 mode).  In the first decoder block every query's
+ * neighbours are the 32 fixed anchors (anchor_points, lib/models/bricks/point_transformers.py:10-32) and every sample's
+ * query coordinates are the hand template (lib/models/heads/ptEmb_head.py:886-894,935: ((c + t) - c) / r, i.e. t / r up
+ * to the rounding of c + t), so fc_delta's output and fc_gamma.0's positional term of both vector attentions
+ * (point_transformers.py:88-91,144-147) are computed once per forward from t / r for the Q x 32 (query, anchor) pairs
+ * and shared by all samples; the per-sample kernel runs one C x C GEMM per neighbour column instead of three.  Results
+ * differ from the per-sample form by fp32 round-off of the inputs only and do not depend on the batch.  0 = per-sample
+ * form everywhere (the exact arithmetic of the reference).  poem_decoder_forward never uses the tables. */
+int poem_set_anchor_tables(poem_handle_t h, int enable);
 /* Arithmetic of the three C x C per-neighbour GEMMs inside the fused vector attention (everything else is fp32 always):
  *   POEM_PRECISION_FP32 (default): v_mfma_f32_32x32x2_f32, exact fp32 products, k-ordered fma chains;
  *   POEM_PRECISION_SPLIT_F16X3 (opt-in, embed >= 128): hi/lo f16 splits of both operands on the f16 matrix cores
@@ -154,6 +163,9 @@ int poem_finalize_parametric(poem_handle_t h, const float* mano_verts, const flo
  * (0 disables); read() synchronises the recorded pairs and returns their count and summed duration. */
 int poem_profile_enable(poem_handle_t h, int max_launches);
 int poem_profile_read(poem_handle_t h, int* launches, float* total_ms, int reset);
+/* The same for the anchored (table) launches of block 0 (poem_set_anchor_tables), which poem_profile_read leaves out:
+ * call it before a resetting poem_profile_read. */
+int poem_profile_read_anchored(poem_handle_t h, int* launches, float* total_ms);
 /* Debug taps: copies of intermediate tensors of the LAST poem_head_forward on this handle (device->device).
  * name: "x","g","bps_feat","pt_xyz","query_xyz","b<i>.h_cross","b<i>.f_self","b<i>.f_cross","b<i>.xyz",
  * "b<i>.feats","b<i>.idx_self","b<i>.idx_cross".  Returns number of elements or <0. */

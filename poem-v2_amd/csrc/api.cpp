@@ -46,6 +46,14 @@ hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src
                                         int nsrc, const float* wd1, const float* bd1, const void* wd2, const float* bd2,
                                         const void* wg1, const float* bg1, const void* wg2, const float* bg2, float* out,
                                         int B, int Q, int C, int ldq, int ldk, int ldv, int composed, hipStream_t s);
+size_t poem_vector_attention_table_floats(int Q, int C);
+hipError_t poem_launch_vector_attention_tables(const float* query_xyz, const float* anchor_xyz, const int* idx,
+                                               const float* wd1, const float* bd1, const void* wd2, const float* bd2,
+                                               const void* wg1d2, float* tab_g, float* tab_p, int Q, int C, hipStream_t s);
+hipError_t poem_launch_vector_attention_anchored(const int* idx, const float* qg, const float* kg, const float* v, int nsrc,
+                                                 const void* wg2, const float* tab_g, const float* tab_p, float* out, int B,
+                                                 int Q, int C, int ldq, int ldk, int ldv, hipStream_t s);
+hipError_t poem_launch_canon_xyz(const float* tmpl, float* out, int n, float radius, hipStream_t s);
 hipError_t poem_launch_pack_split(const float* w, int C, void* img, float* scale_out, hipStream_t s);
 hipError_t poem_launch_pack_split_tiles(const float* w, int N, int K, void* img, float* scales, int scale_stride, hipStream_t s);
 void poem_gemm_split_context(const void* packed, size_t bytes, const void* split, const float* scales);
@@ -220,11 +228,19 @@ struct poem_handle_s {
   // optional HIP-event timing of the dominant kernel (vector attention) on the launch stream
   std::vector<hipEvent_t> prof_ev;   // pairs (start, stop)
   int prof_used = 0;
+  std::vector<char> prof_kind;       // per pair: 0 = the full fused kernel, 1 = the anchored (table) form of block 0
   bool prof_on = false;
   // Side streams: the basis-point-side projections of every block (they depend only on bps_feat and the weights) and
   // the neighbour searches run beside the query-side chain; events order them against the caller's stream.
   hipStream_t bps_stream = nullptr, knn_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join_bps = nullptr, ev_join_knn = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join_bps = nullptr, ev_join_knn = nullptr, ev_tab = nullptr;
+  // Block 0 of the head path: every sample's query coordinates are the hand template ((c + t) - c)/r -- t/r up to the
+  // rounding of c + t -- and the neighbours are the 32 fixed anchors (Q2), so the positional products of both vector
+  // attentions are computed ONCE per forward from t/r (vecattn.hip MODE 1) and the per-sample kernels run one C x C GEMM
+  // per neighbour column instead of three (MODE 2).  Not bit-identical to the per-sample form (inputs differ by <= 1 ulp
+  // of the coordinate); same distance from the reference (tools/lab/hoist_probe.py).  poem_decoder_forward, whose
+  // query coordinates are the caller's, never uses it.
+  bool anchor_tables = true;
   hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {};
   bool overlap = true;
   // Per-view index arrays (view_offsets | view_sample | pe_index) live in handle-owned device memory and are re-uploaded
@@ -284,6 +300,7 @@ struct Plan {
   // per block kept tensors (taps)
   float *h_cross[8], *f_self[8], *f_cross[8], *feats[8];
   float *q3t, *par, *attn_scratch;
+  float *canon_xyz, *tab_g[2], *tab_p[2];   // block-0 anchor tables (self, cross) of the head path
   size_t bytes;
 };
 
@@ -333,6 +350,11 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   p.q3t = a.take<float>((size_t)B * C);
   p.par = a.take<float>((size_t)B * 106);
   p.attn_scratch = a.take<float>(poem_cross_attention_scratch_floats(B, (int)Q, (int)S, (int)C, c.heads, 0) + 4);
+  p.canon_xyz = a.take<float>(Q * 3);
+  for (int k = 0; k < 2; ++k) {
+    p.tab_g[k] = a.take<float>(poem_vector_attention_table_floats((int)Q, (int)C));
+    p.tab_p[k] = a.take<float>(poem_vector_attention_table_floats((int)Q, (int)C));
+  }
   p.bytes = align_up(a.off, 256);
   return p;
 }
@@ -346,7 +368,7 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
 // neighbour searches of block i (they need only xyz_i) go to `knn_stream`.  The small, latency-bound query-side
 // kernels thereby share the chip with the large basis-point GEMMs instead of leaving it half empty.
 static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const float* pt_xyz, const float* pt_feats, int B,
-                       float* pose_aa, float* betas, hipStream_t s) {
+                       float* pose_aa, float* betas, hipStream_t s, bool template_queries = false) {
   const poem_config_t& c = h->cfg;
   const int C = c.embed, S = c.nsample, Q = c.nquery;
   const int BS = B * S, BQ = B * Q;
@@ -359,8 +381,8 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
 #define PROF_START()                                                                              \
   const bool prof_ = h->prof_on && (size_t)(2 * h->prof_used + 1) < h->prof_ev.size();           \
   if (prof_) HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_used], s))
-#define PROF_STOP()                                                                               \
-  if (prof_) { HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_used + 1], s)); ++h->prof_used; }
+#define PROF_STOP(KIND)                                                                           \
+  if (prof_) { HIPCHK(hipEventRecord(h->prof_ev[2 * h->prof_used + 1], s)); h->prof_kind[h->prof_used++] = (KIND); }
 
   // ---- basis-point side of every block (side stream) -------------------------------------------------------------
   if (ov) {
@@ -385,6 +407,19 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       const int rc = bps_side(i);
       if (rc != POEM_OK) return rc;
     }
+  }
+  // block-0 anchor tables (once per forward, on the neighbour-search stream, which has nothing to do before block 1)
+  const bool tables = template_queries && h->anchor_tables && h->precision == POEM_PRECISION_FP32;
+  if (tables) {
+    const int bb0 = h->block_base(0);
+    HIPCHK(poem_launch_canon_xyz(h->tmpl, p.canon_xyz, Q * 3, c.radius, sk));
+    for (int k = 0; k < 2; ++k) {
+      const int vb = bb0 + (k == 0 ? B_VS : B_VC);
+      HIPCHK(poem_launch_vector_attention_tables(p.canon_xyz, h->anchor, h->anchor_idx, h->R(vb + 4), h->R(vb + 5),
+                                                 h->P(vb + 6), h->R(vb + 7), h->fused[0].w[5 + k], p.tab_g[k], p.tab_p[k],
+                                                 Q, C, sk));
+    }
+    if (ov) HIPCHK(hipEventRecord(h->ev_tab, sk));
   }
 
   const float* feats = feats_in;
@@ -453,11 +488,15 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       HIPCHK(poem_launch_vector_attention_split(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q,
                                                 h->R(vsb + 4), h->R(vsb + 5), sw.w[0], h->R(vsb + 7), sw.w[1], sw.w[2],
                                                 sw.scales, p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, s));
+    } else if (tables && i == 0) {
+      if (ov) HIPCHK(hipStreamWaitEvent(s, h->ev_tab, 0));
+      HIPCHK(poem_launch_vector_attention_anchored(idx_s, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->P(vsb + 10), p.tab_g[0],
+                                                   p.tab_p[0], p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, s));
     } else
     HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
                                         h->R(vsb + 5), h->P(vsb + 6), h->R(vsb + 7), h->fused[i].w[5], h->R(vsb + 9),
                                         h->P(vsb + 10), h->R(vsb + 11), p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, 1, s));
-    PROF_STOP();
+    PROF_STOP(tables && i == 0 ? 1 : 0);
     }
     GEMM(p.rs, C, vsb + 2, vsb + 3, hidden, C, p.f_self[i], C, BQ, C, C, POEM_ACT_NONE);
     // vector cross-attention over the basis points
@@ -470,12 +509,15 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       HIPCHK(poem_launch_vector_attention_split(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
                                                 p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4), h->R(vcb + 5), sw.w[0],
                                                 h->R(vcb + 7), sw.w[1], sw.w[2], sw.scales, p.rc, B, Q, C, C, C, C, s));
+    } else if (tables && i == 0) {
+      HIPCHK(poem_launch_vector_attention_anchored(idx_c, p.qc, p.y1[i] + 4 * (size_t)BS * C, p.y1[i] + 5 * (size_t)BS * C,
+                                                   S, h->P(vcb + 10), p.tab_g[1], p.tab_p[1], p.rc, B, Q, C, C, C, C, s));
     } else
     HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
                                         p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4),
                                         h->R(vcb + 5), h->P(vcb + 6), h->R(vcb + 7), h->fused[i].w[6], h->R(vcb + 9),
                                         h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, C, C, C, 1, s));
-    PROF_STOP();
+    PROF_STOP(tables && i == 0 ? 1 : 0);
     }
     GEMM(p.rc, C, vcb + 2, vcb + 3, p.f_self[i], C, p.f_cross[i], C, BQ, C, C, POEM_ACT_NONE);
     // xyz update
@@ -754,7 +796,7 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
     bool ok = hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess;
     auto mk = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
-    mk(&h->ev_fork); mk(&h->ev_join_bps); mk(&h->ev_join_knn);
+    mk(&h->ev_fork); mk(&h->ev_join_bps); mk(&h->ev_join_knn); mk(&h->ev_tab);
     for (int i = 0; i < 8; ++i) { mk(&h->ev_bps[i]); mk(&h->ev_xyz[i]); mk(&h->ev_knn[i]); }
     if (!ok) { poem_destroy(h); return POEM_E_LAUNCH; }
   }
@@ -766,7 +808,7 @@ void poem_destroy(poem_handle_t h) {
   if (!h) return;
   for (auto e : h->prof_ev) (void)hipEventDestroy(e);
   auto de = [](hipEvent_t e) { if (e) (void)hipEventDestroy(e); };
-  de(h->ev_fork); de(h->ev_join_bps); de(h->ev_join_knn);
+  de(h->ev_fork); de(h->ev_join_bps); de(h->ev_join_knn); de(h->ev_tab);
   for (int i = 0; i < 8; ++i) { de(h->ev_bps[i]); de(h->ev_xyz[i]); de(h->ev_knn[i]); }
   if (h->split_mem) (void)hipFree(h->split_mem);
   if (h->gemm_split) (void)hipFree(h->gemm_split);
@@ -779,6 +821,12 @@ void poem_destroy(poem_handle_t h) {
 int poem_set_overlap(poem_handle_t h, int enable) {
   if (!h) return POEM_E_ARG;
   h->overlap = enable != 0;
+  return POEM_OK;
+}
+
+int poem_set_anchor_tables(poem_handle_t h, int enable) {
+  if (!h) return POEM_E_ARG;
+  h->anchor_tables = enable != 0;
   return POEM_OK;
 }
 
@@ -1155,7 +1203,7 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   HIPCHK(poem_launch_broadcast(h->R(T_QEMB), p.feats0, (long)Q * C, B, s));
 #undef GEMM
   {
-    const int rc = run_decoder(h, p, p.feats0, p.pt_xyz, p.bps_feat, B, pose_aa, betas, s);
+    const int rc = run_decoder(h, p, p.feats0, p.pt_xyz, p.bps_feat, B, pose_aa, betas, s, true);
     if (rc != POEM_OK) return rc;
   }
   HIPCHK(poem_launch_finalize(p.xyz[1], p.centre, out_xyz, c.nblocks, B, Q, c.radius, s));
@@ -1190,6 +1238,7 @@ int poem_profile_enable(poem_handle_t h, int max_launches) {
   h->prof_ev.clear();
   h->prof_used = 0;
   h->prof_on = max_launches > 0;
+  h->prof_kind.assign((size_t)max_launches, 0);
   for (int i = 0; i < 2 * max_launches; ++i) {
     hipEvent_t e;
     HIPCHK(hipEventCreate(&e));
@@ -1198,19 +1247,32 @@ int poem_profile_enable(poem_handle_t h, int max_launches) {
   return POEM_OK;
 }
 
-int poem_profile_read(poem_handle_t h, int* launches, float* total_ms, int reset) {
-  if (!h || !launches || !total_ms) return POEM_E_ARG;
+static int profile_sum(poem_handle_t h, int kind, int* launches, float* total_ms) {
   float tot = 0.f;
+  int n = 0;
   for (int i = 0; i < h->prof_used; ++i) {
+    if (h->prof_kind[i] != kind) continue;
     HIPCHK(hipEventSynchronize(h->prof_ev[2 * i + 1]));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
     tot += ms;
+    ++n;
   }
-  *launches = h->prof_used;
+  *launches = n;
   *total_ms = tot;
-  if (reset) h->prof_used = 0;
   return POEM_OK;
+}
+
+int poem_profile_read(poem_handle_t h, int* launches, float* total_ms, int reset) {
+  if (!h || !launches || !total_ms) return POEM_E_ARG;
+  const int rc = profile_sum(h, 0, launches, total_ms);
+  if (rc == POEM_OK && reset) h->prof_used = 0;
+  return rc;
+}
+
+int poem_profile_read_anchored(poem_handle_t h, int* launches, float* total_ms) {
+  if (!h || !launches || !total_ms) return POEM_E_ARG;
+  return profile_sum(h, 1, launches, total_ms);
 }
 
 int poem_finalize_parametric(poem_handle_t h, const float* mano_verts, const float* mano_joints,

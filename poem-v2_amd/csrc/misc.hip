@@ -36,6 +36,17 @@ extern "C" hipError_t poem_launch_prep_xyz(const float* ref_joints, const float*
   return hipGetLastError();
 }
 
+// t / radius: what ((c + t) - c) / radius is for every sample up to the rounding of c + t (block-0 anchor tables, api.cpp)
+__global__ void canon_xyz_kernel(const float* __restrict__ tmpl, float* __restrict__ out, int n, float radius) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = __fdiv_rn(tmpl[i], radius);
+}
+
+extern "C" hipError_t poem_launch_canon_xyz(const float* tmpl, float* out, int n, float radius, hipStream_t s) {
+  hipLaunchKernelGGL(canon_xyz_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tmpl, out, n, radius);
+  return hipGetLastError();
+}
+
 __global__ void broadcast_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long per, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) dst[i] = src[i % per];

@@ -45,6 +45,8 @@ struct VecAttnArgs {
   int ldq, ldk, ldv;        // row strides (floats) of q, k, v: they may be column blocks of a fused projection
   int stagger;              // > 0: persistent launch, second block of each CU starts `stagger` cycles late
   int composed;             // 1: q, k are W_g1 q + (W_g1 b_d2 + b_g1) and W_g1 k, `wg1` is W_g1 W_d2 (see vecattn_kernel)
+  float4* tab_g;            // MODE 1 writes / MODE 2 reads: (W_g1 W_d2) h_ij per (query, anchor), C/D fragment images
+  float4* tab_p;            // MODE 1 writes / MODE 2 reads: pos_ij = W_d2 h_ij + b_d2, transposed (lane = channel) images
 };
 
 // arrival parity per CU (key: XCC id, HW_ID[15:8]); atomicInc wraps 0 -> 1 -> 0, so the table resets itself when
@@ -118,8 +120,20 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
 // (api.cpp), W_g1 W_d2 composed once at handle creation.  GEMM 2 then reads the SAME activations h as GEMM 1: the two
 // run back to back with no LDS round trip and no barrier between them, and the gathered kg_j rows simply wait in GEMM 2's
 // accumulator registers (acc = qg_i - kg_j before its first k-step).
-template <int C, int P, int NW, int MINW, bool COMP>
+//
+// MODE (composed form only) -- the first decoder block's neighbours are the 32 fixed anchors for every query of every
+// sample (quirk Q2, point_transformers.py:10-32 upstream) and its query coordinates are the hand template, so h_ij,
+// pos_ij and (W_g1 W_d2) h_ij do not depend on the sample:
+//   MODE 1  one pass over the Q queries (B = 1) that stops after GEMM 2 and writes both products as register-fragment
+//           images (1 KiB coalesced stores): tab_g = (W_g1 W_d2) h in the C/D layout GEMM 2 leaves it in, tab_p = pos
+//           already transposed to the softmax epilogue's layout (lane = channel, registers = neighbours);
+//   MODE 2  per sample: g = relu(qg_i - kg_j + tab_g) -> X, GEMM 3, softmax-sum with pos from tab_p -- one C x C GEMM per
+//           neighbour column instead of three, no coordinate stage, no transpose scratch.  Items are dealt so that the
+//           blocks an XCD runs back to back share a query group (its table tiles stay in that XCD's L2).
+template <int C, int P, int NW, int MINW, bool COMP, int MODE = 0>
 __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
+  static_assert(MODE == 0 || COMP, "table modes exist for the composed form only");
+  constexpr int NTILE = C / 32;
   constexpr int TPW = C / 32 / NW;
   constexpr int XS = 32 * P;
   constexpr int NT = NW * 64;
@@ -153,8 +167,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   }
 
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
-  const int b = item / groups;
-  const int i0 = (item % groups) * P;
+  int b = item / groups, ig = item % groups;
+  if (MODE == 2) {
+    if (groups % 8 == 0) {   // block ids go round-robin over the 8 XCDs: XCD x walks groups x, x + 8, ... sample by sample
+      const int r = item >> 3;
+      ig = (r / A.B) * 8 + (item & 7);
+      b = r % A.B;
+    } else {
+      ig = item / A.B;
+      b = item % A.B;
+    }
+  }
+  const int i0 = ig * P;
   __syncthreads();   // previous item's epilogue still reads sidx / the scratch inside X
 
   VA_STAMP(0);
@@ -168,15 +192,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
     (void)0;
 #else
     const int id = A.shared_idx ? A.idx[jj] : A.idx[((size_t)b * A.Q + qi) * 32 + jj];
-    const float* qx = A.query_xyz + ((size_t)b * A.Q + qi) * 3;
-    const float* nx = A.anchor_xyz ? A.anchor_xyz + jj * 3 : A.src_xyz + ((size_t)b * A.NS + id) * 3;
-    dl[tid * 3 + 0] = qx[0] - nx[0];
-    dl[tid * 3 + 1] = qx[1] - nx[1];
-    dl[tid * 3 + 2] = qx[2] - nx[2];
+    if (MODE != 2) {
+      const float* qx = A.query_xyz + ((size_t)b * A.Q + qi) * 3;
+      const float* nx = A.anchor_xyz ? A.anchor_xyz + jj * 3 : A.src_xyz + ((size_t)b * A.NS + id) * 3;
+      dl[tid * 3 + 0] = qx[0] - nx[0];
+      dl[tid * 3 + 1] = qx[1] - nx[1];
+      dl[tid * 3 + 2] = qx[2] - nx[2];
+    }
 #endif
     sidx[tid] = id;
     voffs[tid] = (int)(((unsigned)b * (unsigned)A.NS + (unsigned)id) * (unsigned)(A.ldv * 4));
   }
+  if (MODE != 1)
   for (int f = tid; f < P * C / 4; f += NT) {           // query rows -> LDS (read back as broadcasts in epilogue 1)
     const int p = f / (C / 4), c4 = f % (C / 4);
     const int qi = min(i0 + p, A.Q - 1);
@@ -186,7 +213,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   // h = relu(W_d1 delta + b_d1) as two MFMA k-steps per tile (K = 3 zero-padded to 4): the same k-ordered fma chain
   // fma(dz, w2, fma(dy, w1, dx * w0)) as a scalar loop, with the result already in the layout X wants
   // (lane = column, registers = channels; conflict-free stores).
-  {
+  if (MODE != 2) {
     float db0[P], db1[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -217,14 +244,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
         }
       }
     }
+    __syncthreads();
   }
-  __syncthreads();
 
   f32x16 acc[TPW][P], pos[TPW][P];   // initialised by the first k-step of a GEMM (chain_gemm, INIT0) unless stated
 
   // k_j (COMP: kg_j) for this lane's (channel tile, neighbour) cells: 16-byte row gathers issued BEFORE the first GEMM
   // so their L2/HBM latency hides under its MFMAs.  They wait in registers the first GEMM does not touch: `pos` in the
   // plain form (GEMM 1 accumulates into acc), `acc` in the composed form (GEMM 1 accumulates into pos).
+  if (MODE != 1)
 #pragma unroll
   for (int tp = 0; tp < TPW; ++tp) {
     const int cbase = (wv * TPW + tp) * 32 + 4 * h;
@@ -242,7 +270,47 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   __builtin_amdgcn_sched_barrier(0);
 
   VA_STAMP(1);
-  if (COMP) {
+  if (MODE == 2) {
+    // ---- table mode: g = relu((qg_i - kg_j) + tab_g) -> X ; pos fragments (already in the epilogue's layout) -> `pos`
+    const float4* tg = A.tab_g + ((size_t)ig * NTILE + wv * TPW) * (P * 4 * 64) + lane;
+    const float4* tq = A.tab_p + ((size_t)ig * NTILE + wv * TPW) * (P * 4 * 64) + lane;
+    float4 gf[TPW][P][4];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gf[tp][p][g] = tg[((tp * P + p) * 4 + g) * 64];
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 t = tq[((tp * P + p) * 4 + g) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pos[tp][p][4 * g + e] = (&t.x)[e];
+        }
+#pragma unroll
+    for (int tp = 0; tp < TPW; ++tp) {
+      const int cbase = (wv * TPW + tp) * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const float4 qq = *reinterpret_cast<const float4*>(qs + p * C + cbase + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const int i = 4 * g + e;
+            const f32x2 tv = (f32x2{(&qq.x)[e], (&qq.x)[e + 1]} - f32x2{acc[tp][p][i], acc[tp][p][i + 1]}) +
+                             f32x2{(&gf[tp][p][g].x)[e], (&gf[tp][p][g].x)[e + 1]};
+            X[((wv * TPW + tp) * 32 + mfma_row(i, h)) * XS + 32 * p + j] = fmaxf(tv[0], 0.f);
+            X[((wv * TPW + tp) * 32 + mfma_row(i + 1, h)) * XS + 32 * p + j] = fmaxf(tv[1], 0.f);
+          }
+        }
+    }
+    __syncthreads();
+  } else if (COMP) {
     // ---- GEMM 1: pos = W_d2 h (+ b_d2 below)
     chain_gemm<C, P, NW, TPW, false>(A.wd2, X, pos, wv, lane);
     VA_STAMP(2);
@@ -254,23 +322,49 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
         const float4 bb = *reinterpret_cast<const float4*>(A.bd2 + cbase + 8 * g);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-          const float4 qq = *reinterpret_cast<const float4*>(qs + p * C + cbase + 8 * g);
+          const float4 qq = MODE == 1 ? float4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const float4*>(qs + p * C + cbase + 8 * g);
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {      // register pairs -> v_pk_add_f32
             const int i = 4 * g + e;
             const f32x2 pv = f32x2{pos[tp][p][i], pos[tp][p][i + 1]} + f32x2{(&bb.x)[e], (&bb.x)[e + 1]};
-            const f32x2 tv = f32x2{(&qq.x)[e], (&qq.x)[e + 1]} - f32x2{acc[tp][p][i], acc[tp][p][i + 1]};
             pos[tp][p][i] = pv[0]; pos[tp][p][i + 1] = pv[1];
-            acc[tp][p][i] = tv[0]; acc[tp][p][i + 1] = tv[1];
+            if (MODE != 1) {
+              const f32x2 tv = f32x2{(&qq.x)[e], (&qq.x)[e + 1]} - f32x2{acc[tp][p][i], acc[tp][p][i + 1]};
+              acc[tp][p][i] = tv[0]; acc[tp][p][i + 1] = tv[1];
+            }
           }
         }
       }
     }
     VA_STAMP(3);
     // ---- GEMM 2 on the same activations: acc (= qg_i - kg_j) += (W_g1 W_d2) h ;  g = relu(acc)
-    chain_gemm<C, P, NW, TPW, false, false>(A.wg1, X, acc, wv, lane);
+    chain_gemm<C, P, NW, TPW, false, MODE == 1>(A.wg1, X, acc, wv, lane);   // MODE 1: from zero (no q, k)
     VA_STAMP(4);
     __syncthreads();   // every wave is done reading h
+    if (MODE == 1) {
+      // both products leave as fragment images: 16 registers per lane = four 1 KiB wave stores per (tile, query)
+      float4* tg = A.tab_g + ((size_t)ig * NTILE + wv * TPW) * (P * 4 * 64) + lane;
+      float4* tq = A.tab_p + ((size_t)ig * NTILE + wv * TPW) * (P * 4 * 64) + lane;
+      float* scr1 = X + wv * (32 * 33);
+#pragma unroll
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) scr1[j * 33 + mfma_row(i, h)] = pos[tp][p][i];   // [c'][j] -> [j][c']
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          float pt[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) pt[i] = scr1[mfma_row(i, h) * 33 + j];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            tg[((tp * P + p) * 4 + g) * 64] = float4{acc[tp][p][4 * g], acc[tp][p][4 * g + 1], acc[tp][p][4 * g + 2], acc[tp][p][4 * g + 3]};
+            tq[((tp * P + p) * 4 + g) * 64] = float4{pt[4 * g], pt[4 * g + 1], pt[4 * g + 2], pt[4 * g + 3]};
+          }
+        }
+      continue;
+    }
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
@@ -343,7 +437,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   VA_STAMP(5);
   chain_gemm<C, P, NW, TPW, true>(A.wg2, X, acc, wv, lane);
   VA_STAMP(6);
-  __syncthreads();   // X is dead from here on: reuse it as per-wave transpose scratch
+  if (MODE != 2) __syncthreads();   // X is dead from here on: reuse it as per-wave transpose scratch
 
   // Softmax over the 32 neighbours (registers x 2 half-waves) and the weighted sum, written for instruction count --
   // every VALU instruction here comes out of the matrix pipe's time (tools/lab/phase_lab):
@@ -362,8 +456,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       // pos tile [c'][j] (lane = neighbour) -> [j][c'] (lane = channel) through the wave-private scratch
+      if (MODE != 2) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) scr[j * 33 + mfma_row(i, h)] = pos[tp][p][i];
+        for (int i = 0; i < 16; ++i) scr[j * 33 + mfma_row(i, h)] = pos[tp][p][i];
+      }
       float vg[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i)
@@ -371,7 +467,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       float pt[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pt[i] = scr[mfma_row(i, h) * 33 + j];
+      for (int i = 0; i < 16; ++i) pt[i] = MODE == 2 ? pos[tp][p][i] : scr[mfma_row(i, h) * 33 + j];
       f32x16& a = acc[tp][p];
       float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
 #pragma unroll
@@ -399,14 +495,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   }   // item loop
 }
 
-template <int C, int P, int NW, int MINW, bool COMP>
+template <int C, int P, int NW, int MINW, bool COMP, int MODE = 0>
 static hipError_t launch_va_t(const VecAttnArgs& a, hipStream_t s) {
   const int groups = (a.Q + P - 1) / P;
   size_t lds = (size_t)C * 32 * P * 4 + P * 32 * 3 * 4 + 2 * P * 32 * 4 + (size_t)P * C * 4;
 #ifdef POEM_VA_DBG
   if (const char* e = getenv("POEM_VA_LDSPAD")) lds += atoi(e);
 #endif
-  auto kern = vecattn_kernel<C, P, NW, MINW, COMP>;
+  auto kern = vecattn_kernel<C, P, NW, MINW, COMP, MODE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -429,8 +525,51 @@ static hipError_t launch_va_t(const VecAttnArgs& a, hipStream_t s) {
 }
 
 template <int C, int P, int NW, int MINW>
-static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s) {
+static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s, int mode = 0) {
+  if (mode == 1) return launch_va_t<C, P, NW, MINW, true, 1>(a, s);
+  if (mode == 2) return launch_va_t<C, P, NW, MINW, true, 2>(a, s);
   return a.composed ? launch_va_t<C, P, NW, MINW, true>(a, s) : launch_va_t<C, P, NW, MINW, false>(a, s);
+}
+
+// queries per block of the instantiation that serves embed width C (the table images are laid out per query group)
+static int va_group_size(int C) { return C == 128 ? 4 : (C >= 512 ? 1 : 2); }
+
+static hipError_t dispatch_va(const VecAttnArgs& a, int C, hipStream_t s, int mode) {
+  switch (C) {
+    case 32: return launch_va<32, 2, 1, 1>(a, s, mode);
+    case 64: return launch_va<64, 2, 2, 1>(a, s, mode);
+    case 128: return launch_va<128, 4, 4, 2>(a, s, mode);
+    case 256: return launch_va<256, 2, 4, 2>(a, s, mode);
+    case 512: return launch_va<512, 1, 4, 2>(a, s, mode);
+    case 1024: return launch_va<1024, 1, 8, 2>(a, s, mode);   // 8 waves x 4 channel tiles: 2 waves per SIMD, no spills (4 x 8 tiles spilled 158 VGPRs)
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// Floats per table (tab_g or tab_p) for Q queries of width C: whole query groups x 32 anchors x C.
+extern "C" size_t poem_vector_attention_table_floats(int Q, int C) {
+  const int P = va_group_size(C);
+  return (size_t)((Q + P - 1) / P) * P * 32 * C;
+}
+
+// MODE 1: the sample-independent products of an anchored (first-block) vector attention, from the Q query coordinates.
+extern "C" hipError_t poem_launch_vector_attention_tables(const float* query_xyz, const float* anchor_xyz, const int* idx,
+                                                          const float* wd1, const float* bd1, const void* wd2,
+                                                          const float* bd2, const void* wg1d2, float* tab_g,
+                                                          float* tab_p, int Q, int C, hipStream_t s) {
+  VecAttnArgs a{query_xyz, nullptr, anchor_xyz, idx, 1, nullptr, nullptr, nullptr, 1, wd1, bd1, (const float4*)wd2, bd2,
+                (const float4*)wg1d2, nullptr, nullptr, nullptr, nullptr, 1, Q, 0, 0, 0, 0, 1, (float4*)tab_g, (float4*)tab_p};
+  return dispatch_va(a, C, s, 1);
+}
+
+// MODE 2: the per-sample remainder on top of the tables (q, k are the composed qg, kg).
+extern "C" hipError_t poem_launch_vector_attention_anchored(const int* idx, const float* qg, const float* kg,
+                                                            const float* v, int nsrc, const void* wg2,
+                                                            const float* tab_g, const float* tab_p, float* out, int B,
+                                                            int Q, int C, int ldq, int ldk, int ldv, hipStream_t s) {
+  VecAttnArgs a{nullptr, nullptr, nullptr, idx, 1, qg, kg, v, nsrc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                (const float4*)wg2, nullptr, out, B, Q, ldq, ldk, ldv, 0, 1, (float4*)tab_g, (float4*)tab_p};
+  return dispatch_va(a, C, s, 2);
 }
 
 extern "C" hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
@@ -440,28 +579,20 @@ extern "C" hipError_t poem_launch_vector_attention(const float* query_xyz, const
                                                    const void* wg2, const float* bg2, float* out, int B, int Q, int C,
                                                    int ldq, int ldk, int ldv, int composed, hipStream_t s) {
   VecAttnArgs a{query_xyz, src_xyz, anchor_xyz, idx, shared_idx, q, k, v, nsrc, wd1, bd1, (const float4*)wd2, bd2,
-                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q, ldq, ldk, ldv, 0, composed};
+                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q, ldq, ldk, ldv, 0, composed, nullptr, nullptr};
   if (const char* e = getenv("POEM_VA_STAGGER")) a.stagger = atoi(e);
-  switch (C) {
-    case 32: return launch_va<32, 2, 1, 1>(a, s);
-    case 64: return launch_va<64, 2, 2, 1>(a, s);
-    case 128: return launch_va<128, 4, 4, 2>(a, s);
-    case 256:
 #ifdef POEM_VA_DBG
-      if (const char* e = getenv("POEM_VA_CFG")) {
-        switch (atoi(e)) {
-          case 1: return launch_va<256, 1, 4, 4>(a, s);
-          case 2: return launch_va<256, 1, 4, 3>(a, s);
-          case 3: return launch_va<256, 2, 8, 4>(a, s);
-          case 4: return launch_va<256, 1, 8, 4>(a, s);
-          case 5: return launch_va<256, 1, 2, 2>(a, s);
-          default: break;
-        }
+  if (C == 256)
+    if (const char* e = getenv("POEM_VA_CFG")) {
+      switch (atoi(e)) {
+        case 1: return launch_va<256, 1, 4, 4>(a, s);
+        case 2: return launch_va<256, 1, 4, 3>(a, s);
+        case 3: return launch_va<256, 2, 8, 4>(a, s);
+        case 4: return launch_va<256, 1, 8, 4>(a, s);
+        case 5: return launch_va<256, 1, 2, 2>(a, s);
+        default: break;
       }
+    }
 #endif
-      return launch_va<256, 2, 4, 2>(a, s);
-    case 512: return launch_va<512, 1, 4, 2>(a, s);
-    case 1024: return launch_va<1024, 1, 8, 2>(a, s);   // 8 waves x 4 channel tiles: 2 waves per SIMD, no spills (4 x 8 tiles spilled 158 VGPRs)
-    default: return hipErrorInvalidValue;
-  }
+  return dispatch_va(a, C, s, 0);
 }

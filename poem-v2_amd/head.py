@@ -102,7 +102,20 @@ class POEM_Generalized_Head(nn.Module):
             self._engine_sig = sig
             if self._precision != "fp32":
                 self._engine.set_precision(self._precision)
+            if not self._anchor_tables:
+                self._engine.set_anchor_tables(False)
         return self._engine
+
+    _anchor_tables = True
+
+    def set_anchor_tables(self, flag=True):
+        """Block 0 (fixed anchors, template queries: ptEmb_head.py:886-894, point_transformers.py:10-32): positional products
+        of both vector attentions once per forward (default) or, ``False``, per sample exactly as the reference evaluates
+        them (include/poem_hip.h poem_set_anchor_tables)."""
+        self._anchor_tables = bool(flag)
+        if self._engine is not None:
+            self._engine.set_anchor_tables(flag)
+        return self
 
     _precision = "fp32"
 

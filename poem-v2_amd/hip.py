@@ -47,9 +47,11 @@ SIGNATURES = {
     "poem_enable_taps": (_i, [_vp, _i]),
     "poem_profile_enable": (_i, [_vp, _i]),
     "poem_profile_read": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_f), _i]),
+    "poem_profile_read_anchored": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_f)]),
     "poem_packed_linear_bytes": (_sz, [_i, _i]),
     "poem_pack_linear": (_i, [_vp, _i, _i, _vp, _vp]),
     "poem_set_overlap": (_i, [_vp, _i]),
+    "poem_set_anchor_tables": (_i, [_vp, _i]),
     "poem_set_precision": (_i, [_vp, _i]),
     "poem_pack_split_linear": (_i, [_vp, _i, _vp, _vp, _vp]),
     "poem_pack_split_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
@@ -220,6 +222,10 @@ class Engine:
     def set_overlap(self, flag=True):
         check(lib().poem_set_overlap(self.handle, int(flag)), "poem_set_overlap")
 
+    def set_anchor_tables(self, flag=True):
+        """Block-0 positional products once per forward instead of per sample (include/poem_hip.h)."""
+        check(lib().poem_set_anchor_tables(self.handle, int(flag)), "poem_set_anchor_tables")
+
     def set_precision(self, mode):
         check(lib().poem_set_precision(self.handle, PRECISIONS[mode] if isinstance(mode, str) else int(mode)),
               "poem_set_precision")
@@ -230,6 +236,11 @@ class Engine:
     def profile_read(self, reset=True):
         n, ms = _i(0), _f(0.0)
         check(lib().poem_profile_read(self.handle, ctypes.byref(n), ctypes.byref(ms), int(reset)), "poem_profile_read")
+        return n.value, ms.value
+
+    def profile_read_anchored(self):
+        n, ms = _i(0), _f(0.0)
+        check(lib().poem_profile_read_anchored(self.handle, ctypes.byref(n), ctypes.byref(ms)), "poem_profile_read_anchored")
         return n.value, ms.value
 
     def head_forward(self, mlvl_feat, cam_intr, cam_extr, cam_view_num, reference_joints, inp_img_shape):

@@ -301,6 +301,35 @@ def test_head_release_shapes_vs_golden_and_oracle(name):
     assert _md(got, ref) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano"])
+def test_anchor_tables_vs_per_sample_form(name):
+    """Block 0 (Q2: fixed anchors; query coordinates = the template for every sample): the default path computes the
+    positional products of both vector attentions once per forward from t/r (csrc/vecattn.hip MODE 1/2); with
+    set_anchor_tables(False) they are evaluated per sample from ((c + t) - c)/r as the reference does.  The two agree to
+    round-off (the inputs differ by the rounding of c + t), both meet the 1e-3 mm bar against the reference fixture, and
+    the table form stays at the per-sample form's own distance from it."""
+    z, meta = load_golden(name)
+    spec = meta["spec"]
+    cfg, w, consts, batch = case_setup(spec)
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    ref = torch.from_numpy(z["all_coords_preds"])
+    with torch.no_grad():
+        tab = head(feat, metas, rj)["all_coords_preds"].cpu()
+        head.set_anchor_tables(False)
+        per = head(feat, metas, rj)["all_coords_preds"].cpu()
+        head.set_anchor_tables(True)
+        again = head(feat, metas, rj)["all_coords_preds"].cpu()
+    assert torch.equal(tab, again)
+    assert not torch.equal(tab, per)                                   # the table kernels really ran
+    mp = lambda a, b: float(torch.norm(a[-1, :, 21:] - b[-1, :, 21:], dim=-1).mean(dim=1).max())
+    d_tab, d_per, d_between = mp(tab, ref), mp(per, ref), mp(tab, per)
+    assert d_per < 1e-6 and d_tab < 1e-6, (d_tab, d_per)               # metres: the 1e-3 mm bar, both forms
+    assert d_tab < 2 * d_per + 2e-8, (d_tab, d_per)
+    assert d_between < 2e-7, d_between
+    assert _md(tab, per) < 2e-5
+
+
 @pytest.mark.parametrize("mode", ["split_f16x3", "split_f16x3_all"])
 @pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged"])
 def test_split_precision_mode_vs_golden(name, mode):
