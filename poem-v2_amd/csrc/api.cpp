@@ -53,6 +53,8 @@ hipError_t poem_launch_vector_attention_tables(const float* query_xyz, const flo
 hipError_t poem_launch_vector_attention_anchored(const int* idx, const float* qg, const float* kg, const float* v, int nsrc,
                                                  const void* wg2, const float* tab_g, const float* tab_p, float* out, int B,
                                                  int Q, int C, int ldq, int ldk, int ldv, hipStream_t s);
+hipError_t poem_launch_gather_anchor_rows(const float* src, int ld, const int* idx, int NS, float* dst, int B, int C,
+                                          int* ident, hipStream_t s);
 hipError_t poem_launch_canon_xyz(const float* tmpl, float* out, int n, float radius, hipStream_t s);
 hipError_t poem_launch_pack_split(const float* w, int C, void* img, float* scale_out, hipStream_t s);
 hipError_t poem_launch_pack_split_tiles(const float* w, int N, int K, void* img, float* scales, int scale_stride, hipStream_t s);
@@ -301,6 +303,8 @@ struct Plan {
   float *h_cross[8], *f_self[8], *f_cross[8], *feats[8];
   float *q3t, *par, *attn_scratch;
   float *canon_xyz, *tab_g[2], *tab_p[2];   // block-0 anchor tables (self, cross) of the head path
+  float *anch_x[2], *anch_kv[2], *qeqp0;    // block 0: anchor rows of the key/value sources, their (k | v) rows; F2 on Q rows
+  int32_t* ident;
   size_t bytes;
 };
 
@@ -352,6 +356,12 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   p.attn_scratch = a.take<float>(poem_cross_attention_scratch_floats(B, (int)Q, (int)S, (int)C, c.heads, 0) + 4);
   p.canon_xyz = a.take<float>(Q * 3);
   for (int k = 0; k < 2; ++k) {
+    p.anch_x[k] = a.take<float>((size_t)B * 32 * C);
+    p.anch_kv[k] = a.take<float>((size_t)B * 32 * C * 2);
+  }
+  p.qeqp0 = a.take<float>(Q * C * 2);
+  p.ident = a.take<int32_t>(32);
+  for (int k = 0; k < 2; ++k) {
     p.tab_g[k] = a.take<float>(poem_vector_attention_table_floats((int)Q, (int)C));
     p.tab_p[k] = a.take<float>(poem_vector_attention_table_floats((int)Q, (int)C));
   }
@@ -390,6 +400,8 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     HIPCHK(hipStreamWaitEvent(sb, h->ev_fork, 0));
     HIPCHK(hipStreamWaitEvent(sk, h->ev_fork, 0));
   }
+  // block 0 of the head path (template queries, fixed anchors): see poem_handle_s::anchor_tables
+  const bool tables = template_queries && h->anchor_tables && h->precision == POEM_PRECISION_FP32;
   auto bps_side = [&](int i) -> int {
     const auto& f = h->fused[i];
     // F1: keys / values of both BERT cross attentions and of the vector cross attention, straight from the basis-point
@@ -398,7 +410,15 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     float* outs[6] = {p.y1[i], p.y1[i] + seg, p.y1[i] + 2 * seg, p.y1[i] + 3 * seg, p.y1[i] + 4 * seg, p.y1[i] + 5 * seg};
     const int modes[6] = {1, 2, 1, 2, 0, 0};
     h->kv_presplit[i] = poem_gemm_split_applies(f.w[0], BS, C, C) != 0;      // split GEMM -> the K / V images are split too
-    HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, 6, outs, modes, sb));
+    const bool anchored = tables && i == 0;
+    HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, anchored ? 4 : 6, outs, modes, sb));
+    if (anchored) {
+      // the vector cross attention of block 0 reads only the 32 anchor rows of (kc | vc): project just those (the same
+      // fma chain per element as the full GEMM's rows)
+      HIPCHK(poem_launch_gather_anchor_rows(pt_feats, C, h->anchor_idx, S, p.anch_x[1], B, C, p.ident, sb));
+      HIPCHK(poem_launch_gemm(p.anch_x[1], C, (const float*)f.w[0] + (size_t)4 * C * C, f.b[0] + 4 * C, nullptr, 0,
+                              p.anch_kv[1], 2 * C, B * 32, 2 * C, C, POEM_ACT_NONE, sb));
+    }
     if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));
     return POEM_OK;
   };
@@ -409,7 +429,6 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     }
   }
   // block-0 anchor tables (once per forward, on the neighbour-search stream, which has nothing to do before block 1)
-  const bool tables = template_queries && h->anchor_tables && h->precision == POEM_PRECISION_FP32;
   if (tables) {
     const int bb0 = h->block_base(0);
     HIPCHK(poem_launch_canon_xyz(h->tmpl, p.canon_xyz, Q * 3, c.radius, sk));
@@ -451,6 +470,12 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       if (rc != POEM_OK) return rc;
     }
     // F2: qe = embedding(feats) | query projection of the first attention (composed with the embedding)
+    if (tables && i == 0) {
+      // every sample's block-0 query features are the learned embedding table: F2 on its Q rows, then one copy per sample
+      HIPCHK(poem_launch_gemm_split(h->R(T_QEMB), C, h->fused[i].w[1], h->fused[i].b[1], nullptr, 0, p.qeqp0, 2 * C, Q,
+                                    2 * C, C, POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, s));
+      HIPCHK(poem_launch_broadcast(p.qeqp0, p.qeqp, (long)Q * 2 * C, B, s));
+    } else
     HIPCHK(poem_launch_gemm_split(feats, C, h->fused[i].w[1], h->fused[i].b[1], nullptr, 0, p.qeqp, 2 * C, BQ, 2 * C, C,
                                   POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, s));
     const float* hidden = p.qeqp;
@@ -478,6 +503,14 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     // vector self-attention over the queries
     const int vsb = bb + B_VS;
     // F3: (w_qs | w_ks | w_vs) o fc1 on h_cross
+    if (tables && i == 0) {
+      // block 0 gathers keys / values from the 32 anchor rows only: qg for every row, (kg | v) for the anchor rows
+      HIPCHK(poem_launch_gemm(hidden, C, h->fused[i].w[2], h->fused[i].b[2], nullptr, 0, p.y3, 3 * C, BQ, C, C,
+                              POEM_ACT_NONE, s));
+      HIPCHK(poem_launch_gather_anchor_rows(hidden, C, h->anchor_idx, Q, p.anch_x[0], B, C, nullptr, s));
+      HIPCHK(poem_launch_gemm(p.anch_x[0], C, (const float*)h->fused[i].w[2] + (size_t)C * C, h->fused[i].b[2] + C,
+                              nullptr, 0, p.anch_kv[0], 2 * C, B * 32, 2 * C, C, POEM_ACT_NONE, s));
+    } else
     HIPCHK(poem_launch_gemm_split(hidden, C, h->fused[i].w[2], h->fused[i].b[2], nullptr, 0, p.y3, 3 * C, BQ, 3 * C, C,
                                   POEM_ACT_NONE, 3 * C, POEM_ACT_NONE, s));
     if (ov && i > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
@@ -490,8 +523,8 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
                                                 sw.scales, p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, s));
     } else if (tables && i == 0) {
       if (ov) HIPCHK(hipStreamWaitEvent(s, h->ev_tab, 0));
-      HIPCHK(poem_launch_vector_attention_anchored(idx_s, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->P(vsb + 10), p.tab_g[0],
-                                                   p.tab_p[0], p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, s));
+      HIPCHK(poem_launch_vector_attention_anchored(p.ident, p.y3, p.anch_kv[0], p.anch_kv[0] + C, 32, h->P(vsb + 10),
+                                                   p.tab_g[0], p.tab_p[0], p.rs, B, Q, C, 3 * C, 2 * C, 2 * C, s));
     } else
     HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
                                         h->R(vsb + 5), h->P(vsb + 6), h->R(vsb + 7), h->fused[i].w[5], h->R(vsb + 9),
@@ -510,8 +543,8 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
                                                 p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4), h->R(vcb + 5), sw.w[0],
                                                 h->R(vcb + 7), sw.w[1], sw.w[2], sw.scales, p.rc, B, Q, C, C, C, C, s));
     } else if (tables && i == 0) {
-      HIPCHK(poem_launch_vector_attention_anchored(idx_c, p.qc, p.y1[i] + 4 * (size_t)BS * C, p.y1[i] + 5 * (size_t)BS * C,
-                                                   S, h->P(vcb + 10), p.tab_g[1], p.tab_p[1], p.rc, B, Q, C, C, C, C, s));
+      HIPCHK(poem_launch_vector_attention_anchored(p.ident, p.qc, p.anch_kv[1], p.anch_kv[1] + C, 32, h->P(vcb + 10),
+                                                   p.tab_g[1], p.tab_p[1], p.rc, B, Q, C, C, 2 * C, 2 * C, s));
     } else
     HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
                                         p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4),

@@ -47,6 +47,27 @@ extern "C" hipError_t poem_launch_canon_xyz(const float* tmpl, float* out, int n
   return hipGetLastError();
 }
 
+// Block 0 touches only the 32 anchor rows of each sample's key / value sources (Q2): dst (B*32, C) <- src rows
+// b*NS + idx[j]; `ident` (32 ints, optional) <- 0..31, the neighbour ids into the compacted rows.
+__global__ void gather_anchor_rows_kernel(const float* __restrict__ src, int ld, const int* __restrict__ idx, int NS,
+                                          float* __restrict__ dst, int B, int C, int* __restrict__ ident) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C / 4;
+  if (i < (long)B * 32 * c4) {
+    const int c = (int)(i % c4), r = (int)(i / c4), b = r >> 5, j = r & 31;
+    reinterpret_cast<float4*>(dst)[i] = *reinterpret_cast<const float4*>(src + ((size_t)b * NS + idx[j]) * ld + 4 * c);
+  }
+  if (ident && i < 32) ident[i] = (int)i;
+}
+
+extern "C" hipError_t poem_launch_gather_anchor_rows(const float* src, int ld, const int* idx, int NS, float* dst, int B,
+                                                     int C, int* ident, hipStream_t s) {
+  const long total = (long)B * 32 * (C / 4);
+  hipLaunchKernelGGL(gather_anchor_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, ld, idx, NS,
+                     dst, B, C, ident);
+  return hipGetLastError();
+}
+
 __global__ void broadcast_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long per, long total) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < total) dst[i] = src[i % per];
