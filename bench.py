@@ -260,7 +260,9 @@ def main():
         for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
             try:
                 ks = json.load(open(pmc))["kernels"]
-                va = [v for k, v in ks.items() if k.startswith("vecattn_kernel") and "hbm_bytes_per_launch" in v]
+                # the full fused kernel (MODE 0), not the table builder / anchored form of block 0 (MODE 1 / 2)
+                va = [v for k, v in ks.items() if k.startswith("vecattn_kernel") and "hbm_bytes_per_launch" in v
+                      and not k.rstrip().endswith((", 1>", ", 2>"))]
                 if va:
                     traffic = va[0]["hbm_bytes_per_launch"]
                     break

@@ -11,24 +11,28 @@ from . import dist as pdist
 class MeanEPE:
     def __init__(self, name="", device="cpu"):
         self.name = f"{name}_mepe"
-        self.acc = torch.zeros(2, dtype=torch.float64, device=device)   # [sum of per-sample means, n samples]
+        self.acc = torch.zeros(2, dtype=torch.float64, device=device)   # this rank's [sum of per-sample means, n samples]
+        self._global = None                                               # the all-reduced pair of the last reduce()
 
     def reset(self):
         self.acc.zero_()
+        self._global = None
 
     def feed(self, pred_kp, gt_kp):
         assert pred_kp.dim() == 3, "pred shape should be (BATCH, NPOINTS, 1|2|3)"
         d = torch.norm(pred_kp - gt_kp, p="fro", dim=2).mean(dim=1)
         self.acc[0] += d.sum().double()
         self.acc[1] += d.shape[0]
+        self._global = None
 
     def reduce(self):
-        """all-reduce(sum) of [sum, count] over the process group (16 bytes: the path's only collective)."""
-        pdist.all_reduce_sum_(self.acc)
+        """all-reduce(sum) of [sum, count] over the process group (16 bytes: the path's only collective).  The local
+        sums are left alone, so reducing after every step does not count earlier steps once per rank."""
+        self._global = pdist.all_reduce_sum_(self.acc.clone())
         return self
 
     def result(self):
-        s, n = self.acc.tolist()
+        s, n = (self.acc if self._global is None else self._global).tolist()
         return s / max(n, 1.0)
 
     def __str__(self):
