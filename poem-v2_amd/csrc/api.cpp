@@ -235,7 +235,7 @@ struct poem_handle_s {
   // Side streams: the basis-point-side projections of every block (they depend only on bps_feat and the weights) and
   // the neighbour searches run beside the query-side chain; events order them against the caller's stream.
   hipStream_t bps_stream = nullptr, knn_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join_bps = nullptr, ev_join_knn = nullptr, ev_tab = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join_bps = nullptr, ev_join_knn = nullptr, ev_tab = nullptr, ev_fork0 = nullptr;
   // Block 0 of the head path: every sample's query coordinates are the hand template ((c + t) - c)/r -- t/r up to the
   // rounding of c + t -- and the neighbours are the 32 fixed anchors (Q2), so the positional products of both vector
   // attentions are computed ONCE per forward from t/r (vecattn.hip MODE 1) and the per-sample kernels run one C x C GEMM
@@ -370,6 +370,31 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
 }
 }  // namespace
 
+// Block-0 anchor tables (poem_handle_s::anchor_tables): built once per forward on the neighbour-search stream, forked at
+// the very top of poem_head_forward -- they depend on the handle's constants only, so they overlap the HBM-bound sampling
+// front end instead of competing with the first basis-point GEMM the query side waits for (0.07 ms each when they get
+// the chip; 0.7 ms and a later start of block 0 when issued next to that GEMM).
+static int build_anchor_tables(poem_handle_t h, Plan& p, hipStream_t s) {
+  const poem_config_t& c = h->cfg;
+  const int C = c.embed, Q = c.nquery;
+  const bool ov = h->overlap && h->bps_stream && h->knn_stream;
+  hipStream_t sk = ov ? h->knn_stream : s;
+  if (ov) {
+    HIPCHK(hipEventRecord(h->ev_fork0, s));      // the previous forward's readers of the tables are behind this point
+    HIPCHK(hipStreamWaitEvent(sk, h->ev_fork0, 0));
+  }
+  const int bb0 = h->block_base(0);
+  HIPCHK(poem_launch_canon_xyz(h->tmpl, p.canon_xyz, Q * 3, c.radius, sk));
+  for (int k = 0; k < 2; ++k) {
+    const int vb = bb0 + (k == 0 ? B_VS : B_VC);
+    HIPCHK(poem_launch_vector_attention_tables(p.canon_xyz, h->anchor, h->anchor_idx, h->R(vb + 4), h->R(vb + 5),
+                                               h->P(vb + 6), h->R(vb + 7), h->fused[0].w[5 + k], p.tab_g[k], p.tab_p[k],
+                                               Q, C, sk));
+  }
+  if (ov) HIPCHK(hipEventRecord(h->ev_tab, sk));
+  return POEM_OK;
+}
+
 // Decoder (PtEmbedTRv4.forward): p.xyz[0] holds the initial normalised query coordinates; writes p.xyz[1..nblocks].
 //
 // Three HIP streams.  The caller's stream `s` carries the query-side chain (the critical path).  Everything that
@@ -428,19 +453,6 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       if (rc != POEM_OK) return rc;
     }
   }
-  // block-0 anchor tables (once per forward, on the neighbour-search stream, which has nothing to do before block 1)
-  if (tables) {
-    const int bb0 = h->block_base(0);
-    HIPCHK(poem_launch_canon_xyz(h->tmpl, p.canon_xyz, Q * 3, c.radius, sk));
-    for (int k = 0; k < 2; ++k) {
-      const int vb = bb0 + (k == 0 ? B_VS : B_VC);
-      HIPCHK(poem_launch_vector_attention_tables(p.canon_xyz, h->anchor, h->anchor_idx, h->R(vb + 4), h->R(vb + 5),
-                                                 h->P(vb + 6), h->R(vb + 7), h->fused[0].w[5 + k], p.tab_g[k], p.tab_p[k],
-                                                 Q, C, sk));
-    }
-    if (ov) HIPCHK(hipEventRecord(h->ev_tab, sk));
-  }
-
   const float* feats = feats_in;
   for (int i = 0; i < c.nblocks; ++i) {
     const int bb = h->block_base(i);
@@ -555,6 +567,16 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     GEMM(p.rc, C, vcb + 2, vcb + 3, p.f_self[i], C, p.f_cross[i], C, BQ, C, C, POEM_ACT_NONE);
     // xyz update
     // F4: reg_branch.0 (relu) | intermediate.dense (gelu) share f_cross
+    // The last block's feed-forward output (intermediate -> output -> LayerNorm) feeds nothing: PtEmbedTRv4.forward returns
+    // the coordinate stack only (ptEmb_transformer.py:115-121,371-376 upstream; the reference evaluates it and drops it).  It
+    // is computed only when something reads it: the parametric tail (medium_MANO) or the debug taps.
+    const bool feats_dead = i == c.nblocks - 1 && !c.parametric && !h->taps;
+    if (feats_dead) {
+      HIPCHK(poem_launch_gemm(p.f_cross[i], C, h->fused[i].w[3], h->fused[i].b[3], nullptr, 0, p.y4, 5 * C, BQ, C, C,
+                              POEM_ACT_RELU, s));
+      HIPCHK(poem_launch_narrow_linear(p.y4, 5 * C, h->R(bb + B_REG2_W), h->R(bb + B_REG2_B), xyz, p.xyz[i + 1], BQ, C, 3, s));
+      break;
+    }
     HIPCHK(poem_launch_gemm_split(p.f_cross[i], C, h->fused[i].w[3], h->fused[i].b[3], nullptr, 0, p.y4, 5 * C, BQ, 5 * C, C,
                                   POEM_ACT_RELU, C, POEM_ACT_GELU, s));
     HIPCHK(poem_launch_narrow_linear(p.y4, 5 * C, h->R(bb + B_REG2_W), h->R(bb + B_REG2_B), xyz, p.xyz[i + 1], BQ, C, 3, s));
@@ -829,7 +851,7 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
     bool ok = hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess;
     auto mk = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
-    mk(&h->ev_fork); mk(&h->ev_join_bps); mk(&h->ev_join_knn); mk(&h->ev_tab);
+    mk(&h->ev_fork); mk(&h->ev_join_bps); mk(&h->ev_join_knn); mk(&h->ev_tab); mk(&h->ev_fork0);
     for (int i = 0; i < 8; ++i) { mk(&h->ev_bps[i]); mk(&h->ev_xyz[i]); mk(&h->ev_knn[i]); }
     if (!ok) { poem_destroy(h); return POEM_E_LAUNCH; }
   }
@@ -841,7 +863,7 @@ void poem_destroy(poem_handle_t h) {
   if (!h) return;
   for (auto e : h->prof_ev) (void)hipEventDestroy(e);
   auto de = [](hipEvent_t e) { if (e) (void)hipEventDestroy(e); };
-  de(h->ev_fork); de(h->ev_join_bps); de(h->ev_join_knn); de(h->ev_tab);
+  de(h->ev_fork); de(h->ev_join_bps); de(h->ev_join_knn); de(h->ev_tab); de(h->ev_fork0);
   for (int i = 0; i < 8; ++i) { de(h->ev_bps[i]); de(h->ev_xyz[i]); de(h->ev_knn[i]); }
   if (h->split_mem) (void)hipFree(h->split_mem);
   if (h->gemm_split) (void)hipFree(h->gemm_split);
@@ -1218,6 +1240,10 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
 #define GEMM(X, LDX, WI, BI, RES, LDR, Y, LDY, M, N, K, ACT) \
   HIPCHK(poem_launch_gemm(X, LDX, h->P(WI), (BI) >= 0 ? h->R(BI) : nullptr, RES, LDR, Y, LDY, M, N, K, ACT, s))
 
+  if (h->anchor_tables && h->precision == POEM_PRECISION_FP32) {
+    const int rc = build_anchor_tables(h, p, s);
+    if (rc != POEM_OK) return rc;
+  }
   // ---- sampling stage ------------------------------------------------------------------------------------------
   HIPCHK(poem_launch_conv1x1(mlvl_feat, h->P(T_INPROJ_W), h->R(T_INPROJ_B), h->pe_table, p.pe_index, p.x, BN,
                              c.in_channels, C, HW, s));

@@ -330,6 +330,24 @@ def test_anchor_tables_vs_per_sample_form(name):
     assert _md(tab, per) < 2e-5
 
 
+def test_last_block_feed_forward_is_computed_only_when_read():
+    """PtEmbedTRv4.forward returns the coordinate stack only (ptEmb_transformer.py:115-121,371-376): the last block's
+    feed-forward output feeds nothing unless the parametric tail or a debug tap reads it, and the path does not compute
+    it then.  The coordinates must not notice: bit-equal with the taps (which force it) on and off."""
+    z, meta = load_golden("medium")
+    spec = meta["spec"]
+    cfg, w, consts, batch = case_setup(spec)
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    with torch.no_grad():
+        lean = head(feat, metas, rj)["all_coords_preds"].clone()
+        eng = head._engine_for(torch.device(DEV))
+        eng.enable_taps(True)
+        full = head(feat, metas, rj)["all_coords_preds"].clone()
+        eng.enable_taps(False)
+    assert torch.equal(lean, full)
+
+
 @pytest.mark.parametrize("mode", ["split_f16x3", "split_f16x3_all"])
 @pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged"])
 def test_split_precision_mode_vs_golden(name, mode):
