@@ -329,6 +329,30 @@ def main():
                                                 "everything else fp32; the headline `value` is the exact-fp32 default"}
         except Exception as e:
             res["split_f16x3_scope"] = {"error": repr(e)[:200]}
+    if world == 1 and args.precision == "fp32" and args.anchor_tables:
+        # the same step with block 0's positional products evaluated per sample, term by term as the reference does
+        # (poem_set_anchor_tables(0)): what the anchor tables buy, and how far the two forms are apart on this batch
+        try:
+            with torch.no_grad():
+                tab = step()["all_coords_preds"].clone()
+                head.set_anchor_tables(False)
+                for _ in range(2):
+                    per = step()["all_coords_preds"]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                pdt = (time.perf_counter() - t0) / args.steps
+                head.set_anchor_tables(True)
+            res["per_sample_block0_scope"] = {
+                "value": args.batch * world / pdt, "unit": "samples/s", "ms_per_step": pdt * 1e3,
+                "mpvpe_vs_headline_path_mm": float(torch.norm(per[-1, :, 21:] - tab[-1, :, 21:], dim=-1).mean()) * 1e3,
+                "note": "poem_set_anchor_tables(0): the first block's vector attentions evaluate fc_delta / fc_gamma.0's "
+                        "positional term per (sample, query, anchor) from ((c + t) - c)/r like the reference; the headline "
+                        "computes them once per forward from t/r (fixed anchors, template queries: DESIGN.md section 3)"}
+        except Exception as e:
+            res["per_sample_block0_scope"] = {"error": repr(e)[:200]}
     if world == 1 and not args.views_range and not parametric:
         # one stage earlier (SURVEY 8f rows N1 + N2): backbone pyramid -> feat_decode / heatmap_stage -> DLT -> head.  The
         # HRNet backbone itself is out of scope; its output pyramid is synthetic.  Reported beside the headline, never as it.
