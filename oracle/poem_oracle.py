@@ -294,8 +294,13 @@ def parametric_tail(w, pre, feats, xyz, mano_fn, C):
     return xyz, pose_aa, betas
 
 
-def decoder_block(w, cfg, i, query_xyz, query_feats, pt_xyz, pt_feats, consts, hoist=False, taps=None, mano_fn=None):
-    """point_METRO_block.forward (pt_metro_transformer.py:153-200) for block i."""
+def decoder_block(w, cfg, i, query_xyz, query_feats, pt_xyz, pt_feats, consts, hoist=False, taps=None, mano_fn=None,
+                  anchor_xyz=None):
+    """point_METRO_block.forward (pt_metro_transformer.py:153-200) for block i.
+
+    anchor_xyz (Q,3), block 0 only: restates the HIP path's anchor-table form -- the coordinate differences of both vector
+    attentions are taken from these sample-independent query coordinates (t/r) instead of each sample's ((c + t) - c)/r;
+    the xyz residual keeps the per-sample coordinates.  None = the reference's arithmetic."""
     p = f"transformer.pt_metro_encoder.{i}."
     C = cfg.embed
     B, Q = query_feats.shape[:2]
@@ -314,8 +319,9 @@ def decoder_block(w, cfg, i, query_xyz, query_feats, pt_xyz, pt_feats, consts, h
         idx_c = knn_indices(query_xyz, pt_xyz, cfg.knn)
         nxyz_c = gather_xyz(pt_xyz, idx_c)
     vp = p + "encoder.vec_attn."
-    f_self = vec_attn_self(w, vp + "query_self_attn.", query_xyz, h, idx_s, nxyz_s)
-    f_cross = vec_attn_cross(w, vp + "query_cross_attn.", query_xyz, f_self, ke, idx_c, nxyz_c, hoist=hoist)
+    va_xyz = query_xyz if (anchor_xyz is None or i != 0) else anchor_xyz[None].expand_as(query_xyz)
+    f_self = vec_attn_self(w, vp + "query_self_attn.", va_xyz, h, idx_s, nxyz_s)
+    f_cross = vec_attn_cross(w, vp + "query_cross_attn.", va_xyz, f_self, ke, idx_c, nxyz_c, hoist=hoist)
     r = F.relu(linear(f_cross, w[vp + "reg_branch.0.weight"], w[vp + "reg_branch.0.bias"]))
     new_xyz = linear(r, w[vp + "reg_branch.2.weight"], w[vp + "reg_branch.2.bias"]) + query_xyz
     inter = F.gelu(linear(f_cross, w[p + "encoder.intermediate.dense.weight"], w[p + "encoder.intermediate.dense.bias"]))
@@ -338,10 +344,12 @@ def decoder_block(w, cfg, i, query_xyz, query_feats, pt_xyz, pt_feats, consts, h
 
 
 def head_forward(w, cfg, consts, mlvl_feat, cam_intr, cam_extr, cam_view_num, reference_joints,
-                 inp_img_shape=(256, 256), hoist=False, taps=None, mano_fn=None):
+                 inp_img_shape=(256, 256), hoist=False, taps=None, mano_fn=None, anchor_tables=False):
     """POEM_Generalized_Head.forward (ptEmb_head.py:825-964).
 
     consts: dict(bps (S,3), anchor (32,3), anchor_idx (32,) int64, template (799,3) metres).
+    anchor_tables=True restates the HIP path's default (block 0's positional terms from template / radius, see
+    decoder_block); False is the reference's arithmetic term by term.
     Returns all_coords_preds (nblocks,B,799,3) [, pred_pose (B,16,3), pred_shape (B,10)]."""
     C, S = cfg.embed, cfg.nsample
     views = [int(v) for v in cam_view_num]
@@ -372,7 +380,8 @@ def head_forward(w, cfg, consts, mlvl_feat, cam_intr, cam_extr, cam_view_num, re
     stack = []
     pose = shape = None
     for i in range(cfg.nblocks):                                                                 # ptEmb_transformer.py:115-121
-        feats, xyz, pose, shape = decoder_block(w, cfg, i, xyz, feats, pt_xyz, bps_feat, consts, hoist, taps, mano_fn)
+        feats, xyz, pose, shape = decoder_block(w, cfg, i, xyz, feats, pt_xyz, bps_feat, consts, hoist, taps, mano_fn,
+                                                anchor_xyz=consts["template"] / cfg.radius if anchor_tables else None)
         stack.append(xyz)
     out = torch.nan_to_num(torch.stack(stack))                                                   # :944
     c = centre[None, :, None, :]

@@ -328,6 +328,10 @@ def test_anchor_tables_vs_per_sample_form(name):
     assert d_tab < 2 * d_per + 2e-8, (d_tab, d_per)
     assert d_between < 2e-7, d_between
     assert _md(tab, per) < 2e-5
+    # each form against the oracle's restatement of the SAME arithmetic
+    o_tab = run_oracle(cfg, w, consts, batch, anchor_tables=True)["all_coords_preds"]
+    o_per = run_oracle(cfg, w, consts, batch)["all_coords_preds"]
+    assert mp(tab, o_tab) < 1e-6 and mp(per, o_per) < 1e-6, (mp(tab, o_tab), mp(per, o_per))
 
 
 def test_last_block_feed_forward_is_computed_only_when_read():

@@ -51,6 +51,23 @@ def test_release_shapes(name):
         assert _maxdiff(out["pred_shape"], z["pred_shape"]) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["tiny", "medium", "ragged"])
+def test_anchor_table_form_is_equivalent(name):
+    """The HIP path's default evaluates block 0's positional terms once per forward from template / radius (every sample's
+    query coordinates are ((c + t) - c) / r, the anchors are fixed -- quirk Q2).  Restated in the oracle
+    (head_forward(anchor_tables=True)) it must stay at the reference fixture's round-off distance: the MPVPE bar, and no
+    further from the fixture than twice the plain oracle (+ 2e-5 mm)."""
+    z, meta = load_golden(name)
+    cfg, w, consts, batch = case_setup(meta["spec"])
+    ref = z["all_coords_preds"]
+    mp = lambda o: float(np.linalg.norm(o["all_coords_preds"].numpy()[-1, :, 21:] - ref[-1, :, 21:], axis=-1).mean())
+    plain = mp(run_oracle(cfg, w, consts, batch))
+    tab = run_oracle(cfg, w, consts, batch, anchor_tables=True)
+    assert mp(tab) < 1e-6, mp(tab)
+    assert mp(tab) < 2 * plain + 2e-8, (mp(tab), plain)
+    assert _maxdiff(tab["all_coords_preds"], ref) < 5e-5
+
+
 def test_hoisted_cross_attention_is_equivalent():
     z, meta = load_golden("tiny")
     cfg, w, consts, batch = case_setup(meta["spec"])

@@ -36,13 +36,13 @@ def case_setup(spec):
     return cfg, w, consts, batch
 
 
-def run_oracle(cfg, w, consts, batch, taps=None, hoist=False):
+def run_oracle(cfg, w, consts, batch, taps=None, hoist=False, anchor_tables=False):
     m = batch["img_metas"]
     mano_fn = po.toy_mano(consts["template"], cfg.center_idx) if cfg.parametric else None
     with torch.no_grad():
         return po.head_forward(w, cfg, consts, batch["mlvl_feat"], m["cam_intr"], m["cam_extr"], m["cam_view_num"],
                                batch["reference_joints"], inp_img_shape=m["inp_img_shape"], taps=taps, hoist=hoist,
-                               mano_fn=mano_fn)
+                               mano_fn=mano_fn, anchor_tables=anchor_tables)
 
 
 from poem_v2_amd.configs import head_cfg  # noqa: E402,F401
