@@ -72,3 +72,43 @@ def synthetic_images(views, seed=0, img=256):
     """(BN,3,img,img) seeded N(0, 0.3^2) "images" for the end-to-end timing scope."""
     g = torch.Generator().manual_seed(3000 + seed)
     return 0.3 * torch.randn(views, 3, img, img, generator=g)
+
+
+def synthetic_frame(seed, n_cams=4, raw=(640, 480), ext="png", dtype=np.float32):
+    """A decoded multi-view record of the layout the dataset tars hold (``image_<i>.<ext>`` per camera + ``label.pyd`` =
+    dict of per-camera lists; lib/data_wds/multiview_wds.py:63-75 upstream), seeded: cameras on a ring around a hand at
+    0.6 m, jittered intrinsics, Gaussian joints / vertices, a gradient + noise image per camera.  The dataset tars are not
+    available offline; ``scripts/eval_single.py --shards`` and the tests write shards of these records instead.
+    (tests/test_transform.py checks that the test infrastructure's own generator produces the identical records.)"""
+    g = np.random.default_rng(seed)
+    W, H = raw
+    names = ("cam_intr", "cam_extr", "cam_serial", "joints_3d", "verts_3d", "joints_2d", "joints_vis", "bbox_center",
+             "bbox_scale", "image_path", "raw_size", "mano_pose", "mano_shape", "idx")
+    lab = {k: [] for k in names}
+    item = {"__key__": f"frame{seed:06d}"}
+    hand = np.array([0.0, 0.0, 0.6])
+    yy, xx = np.mgrid[0:H, 0:W]
+    ramp = np.stack([xx * 255 // max(W - 1, 1), yy * 255 // max(H - 1, 1), (xx + yy) % 256], -1).astype(np.int64)
+    for i in range(n_cams):
+        K = np.array([[580 + 20 * g.random(), 0, W / 2 + 10 * g.normal()], [0, 580 + 20 * g.random(), H / 2 + 10 * g.normal()],
+                      [0, 0, 1]], dtype)
+        ang = 2 * np.pi * i / max(n_cams, 1) + 0.1 * g.normal()
+        T = np.eye(4)
+        T[:3, :3] = [[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]]
+        T[:3, 3] = hand - T[:3, :3] @ hand + 0.01 * g.normal(size=3)
+        j3d = (hand + 0.04 * g.normal(size=(21, 3))).astype(dtype)
+        v3d = (hand + 0.04 * g.normal(size=(778, 3))).astype(dtype)
+        uvw = (K.astype(np.float64) @ j3d.T.astype(np.float64)).T
+        j2d = (uvw[:, :2] / uvw[:, 2:]).astype(dtype)
+        span = j2d.max(0) - j2d.min(0)
+        per_cam = {"cam_intr": K, "cam_extr": T.astype(dtype), "cam_serial": f"cam{i}", "joints_3d": j3d, "verts_3d": v3d,
+                   "joints_2d": j2d, "joints_vis": np.ones(21, dtype), "bbox_center": (0.5 * (j2d.min(0) + j2d.max(0))).astype(dtype),
+                   "bbox_scale": dtype(float(1.7 * span.max())), "image_path": f"seq/{seed}/{i}.{ext}", "raw_size": (W, H)}
+        per_cam["mano_pose"] = (0.1 * g.normal(size=48)).astype(dtype)
+        per_cam["mano_shape"] = (0.1 * g.normal(size=10)).astype(dtype)
+        per_cam["idx"] = seed * 16 + i
+        for k in names:
+            lab[k].append(per_cam[k])
+        item[f"image_{i}.{ext}"] = np.clip(ramp + g.integers(-40, 40, size=(H, W, 3)), 0, 255).astype(np.uint8)
+    item["label.pyd"] = lab
+    return item

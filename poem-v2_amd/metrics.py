@@ -54,11 +54,13 @@ class PAEval:
     def __init__(self, cfg=None, mesh_score=False, device="cuda"):
         self.mesh_score = mesh_score
         self.device = torch.device(device)
-        self.acc = torch.zeros(5, dtype=torch.float64, device=self.device)   # pa_j, j, pa_v, v, count
+        self.acc = torch.zeros(5, dtype=torch.float64, device=self.device)   # this rank's pa_j, j, pa_v, v, count
+        self._global = None                                                   # the all-reduced sums of the last reduce()
         self.count = 0
 
     def reset(self):
         self.acc.zero_()
+        self._global = None
         self.count = 0
 
     def _pair(self, pred, gt):
@@ -78,13 +80,16 @@ class PAEval:
             self.acc[2:4] += self._pair(pred_verts_3d_abs, verts_3d_abs)
         self.acc[4] += b
         self.count += b
+        self._global = None
 
     def reduce(self):
-        pdist.all_reduce_sum_(self.acc)
+        """all-reduce(sum) of a copy: the rank-local sums stay what this rank fed, so a second ``reduce()`` or a ``feed``
+        after it never counts anything once per rank (same contract as ``MeanEPE.reduce``)."""
+        self._global = pdist.all_reduce_sum_(self.acc.clone())
         return self
 
     def get_measures(self, **kwargs):
-        a = self.acc.tolist()
+        a = (self.acc if self._global is None else self._global).tolist()
         n = max(a[4], 1.0)
         m = {"pa_mpjpe": a[0] / n, "mpjpe": a[1] / n}
         if self.mesh_score:
@@ -119,6 +124,7 @@ class _PCKMetric:
         self.n = torch.zeros(self.num_kp, dtype=torch.int32, device=self.device)
         self.dists = []          # per-batch (B, num_kp) distance tensors on the device (arbitrary-threshold queries)
         self.count = 0
+        self._global = None      # (counts int64, n int64, sum fp64) over all ranks, set by reduce()
 
     def _get_predictions(self, preds, targs):
         pk_, tk_ = self._keys[self.eval_type]
@@ -136,27 +142,46 @@ class _PCKMetric:
                                                 hip.ptr(d), hip.stream()), "poem_pck_accumulate")
         self.dists.append(d)
         self.count += p.shape[0]
+        self._global = None
 
     def reduce(self):
-        """Sum the accumulators over ranks (counts as int64 to stay exact)."""
-        c = self.counts.long()
-        n = self.n.long()
-        pdist.all_reduce_sum_(c), pdist.all_reduce_sum_(n), pdist.all_reduce_sum_(self.sum)
-        self.counts, self.n = c.int(), n.int()
+        """Sum the accumulators over ranks into a separate global copy (counts as int64 to stay exact); the rank-local
+        accumulators are untouched, so reducing twice or feeding afterwards never double counts."""
+        g = (self.counts.long(), self.n.long(), self.sum.clone())
+        for t in g:
+            pdist.all_reduce_sum_(t)
+        self._global = g
         return self
 
     def get_pck_all(self, threshold):
-        d = torch.cat(self.dists, 0).double()
-        return float((d <= threshold).double().mean(0).mean())
+        """Fraction of key points within ``threshold`` (every sample carries all key points, so the mean of per-key-point
+        means is hits / total).  Before ``reduce()``: this rank's samples.  After it: all ranks' -- read from the reduced
+        threshold histogram when ``threshold`` is one of its steps (the usual 0.02 = VAL_MAX is; no communication, so rank 0
+        alone may print the metric); for any other threshold this rank's [hits, total] pair is all-reduced here and every
+        rank must make the call."""
+        import numpy as np
+        if self._global is not None:
+            steps = np.linspace(self.val_min, self.val_max, self.steps)
+            hit = np.nonzero(np.isclose(steps, threshold, rtol=0, atol=1e-12))[0]
+            if hit.size:
+                counts, n, _ = self._global
+                return float(counts[:, int(hit[0])].sum()) / max(float(n.sum()), 1.0)
+        d = torch.cat(self.dists, 0) if self.dists else torch.zeros(0, self.num_kp, device=self.device)
+        pair = torch.stack([(d.double() <= threshold).sum().double(), torch.tensor(float(d.numel()), dtype=torch.float64, device=d.device)])
+        if self._global is not None:
+            pdist.all_reduce_sum_(pair)
+        hits, total = pair.tolist()
+        return hits / max(total, 1.0)
 
     def get_measures(self):
         import numpy as np
         thresholds = np.linspace(self.val_min, self.val_max, self.steps)
         area_under_one = getattr(np, "trapezoid", getattr(np, "trapz", None))(np.ones_like(thresholds), thresholds)
-        n = self.n.cpu().numpy().astype(np.float64)
+        counts, n, dsum = (self.counts, self.n, self.sum) if self._global is None else self._global
+        n = n.cpu().numpy().astype(np.float64)
         valid = n > 0
-        curve = self.counts.cpu().numpy().astype(np.float64)[valid] / n[valid][:, None]
-        epe = self.sum.cpu().numpy()[valid] / n[valid]
+        curve = counts.cpu().numpy().astype(np.float64)[valid] / n[valid][:, None]
+        epe = dsum.cpu().numpy()[valid] / n[valid]
         auc = getattr(np, "trapezoid", getattr(np, "trapz", None))(curve, thresholds, axis=1) / area_under_one
         return {"epe_mean_per_kp": epe, "pck_curve_per_kp": curve, "auc_per_kp": auc, "epe_mean_all": float(np.mean(epe)),
                 "auc_all": float(np.mean(auc)), "thresholds": thresholds}

@@ -2,16 +2,15 @@
 work (crop / warp / colour jitter / to-tensor / normalise) on the MI355X and the label arithmetic on the host.
 
 Mirrors ``lib/utils/transform.py`` upstream: ``SimpleTransform2D.__call__`` (:105-196), ``SimpleTransform3DMultiView``
-(:240-281), the affine helpers (:618-705) and ``RandomOcclusion`` (:21-67); same config keys, same result keys, the same
-draws from ``np.random`` / ``random`` in the same order (so a seeded upstream run and a seeded run here pick the same
-augmentation).  The image chain of the reference is ``cv2.warpAffine`` -> colour jitter -> ``tvF.to_tensor`` ->
+(:240-281) and the affine helpers (:618-705); same config keys, same result keys and dtypes, the same consumption of
+``np.random`` / ``random`` (so a seeded upstream run and a seeded run here pick the same augmentation) -- but formulated per
+frame: closed-form crop matrices for all views at once (:func:`crop_geometry`) instead of per-view 3x3 product chains.  The image chain of the reference is ``cv2.warpAffine`` -> colour jitter -> ``tvF.to_tensor`` ->
 ``tvF.normalize`` per view on the host; here every view handed to :func:`warp_views` is processed by ONE launch of
 ``poem_warp_affine`` (csrc/warp.hip) from one pinned upload, and ``results["image"]`` is a device tensor.
 
 No CPU fallback: without the HIP library / a GPU the image side raises (``hip.lib()``); the label side
 (:meth:`SimpleTransform3DMultiView.labels`) is pure numpy and runs anywhere.
 """
-import math
 import random
 
 import numpy as np
@@ -28,56 +27,69 @@ def build_transform(cfg, **kwargs):                   # lib/utils/builder.py:335
     return build_from_cfg(cfg, TRANSFORM, **kwargs)
 
 
-# ---- affine helpers (transform.py:618-705) --------------------------------------------------------------------------
-def _construct_rotation_matrix(rot, size=3):
-    m = np.eye(size, dtype=np.float32)
-    if rot != 0:
-        sn, cs = np.sin(rot), np.cos(rot)
-        m[0, :2] = [cs, -sn]
-        m[1, :2] = [sn, cs]
-    return m
+# ---- crop geometry of all views of a frame at once ------------------------------------------------------------------
+# What the reference builds per view through chains of 3x3 products (lib/utils/transform.py:618-705: the in-plane
+# rotation, the crop about the rotated bbox centre, the "post-rotation" crop about the centre rotated around the
+# principal point) is written here in closed form over a leading view axis.  The 3x3 products upstream only ever add
+# exact zeros to a single product per entry, so the closed form below is the same fp64 number, entry by entry; the
+# association order of the two-term sums is kept ((a*x + b*y) + t) because the fixtures compare with ``==``.
+def inplane_rotations(rot):
+    """rot (V,) radians -> (V,3,3) fp32 rotations about the optical axis (identity where rot == 0)."""
+    rot = np.asarray(rot, dtype=np.float64).reshape(-1)
+    out = np.zeros((rot.size, 3, 3), dtype=np.float32)
+    cs, sn = np.cos(rot), np.sin(rot)
+    out[:, 0, 0] = out[:, 1, 1] = cs
+    out[:, 0, 1], out[:, 1, 0] = -sn, sn
+    out[:, 2, 2] = 1
+    return out
 
 
-def _get_affine_trans_no_rot(center, scale, res):
-    a = np.zeros((3, 3))
-    ratio = float(res[0]) / float(res[1])
-    a[0, 0] = float(res[0]) / scale
-    a[1, 1] = float(res[1]) / scale * ratio
-    a[0, 2] = res[0] * (-float(center[0]) / scale + 0.5)
-    a[1, 2] = res[1] * (-float(center[1]) / scale * ratio + 0.5)
-    a[2, 2] = 1
-    return a
+def _crop_about(cx, cy, scale, out_size):
+    """Scale + shift that maps the ``scale``-sized square centred at (cx, cy) onto the output window -> (sx, sy, tx, ty).
+    Evaluated in the dtype of ``scale``: the records store the bbox scale as a numpy scalar and the reference divides plain
+    Python floats by it, which (numpy >= 2 promotion) keeps fp32 labels in fp32 -- the fixtures pin that."""
+    dt = scale.dtype
+    w, h = dt.type(out_size[0]), dt.type(out_size[1])
+    aspect = dt.type(float(out_size[0]) / float(out_size[1]))
+    half = dt.type(0.5)
+    cx, cy = cx.astype(dt), cy.astype(dt)
+    return w / scale, h / scale * aspect, w * (-cx / scale + half), h * (-cy / scale * aspect + half)
 
 
-def _affine_transform(center, scale, out_res, rot=0):
-    rotmat = _construct_rotation_matrix(rot=rot, size=3)
-    origin_rot_center = (rotmat.dot(np.concatenate([center, np.ones(1)])))[:2]
-    return _get_affine_trans_no_rot(origin_rot_center, scale, out_res).dot(rotmat).astype(np.float32)
+def crop_geometry(center, scale, rot, principal, out_size):
+    """center (V,2), scale (V,), rot (V,), principal point (V,2), all fp64 -> three (V,3,3) fp32 stacks:
+    rotation R, the image warp  A = Crop(R c) . R  (source pixel -> output pixel, what ``cv2.warpAffine`` receives) and the
+    intrinsics update  P = Crop(o + R (c - o))  (no rotation part: the rotation moves to the extrinsics)."""
+    center = np.asarray(center, dtype=np.float64).reshape(-1, 2)
+    scale = np.asarray(scale).reshape(-1)
+    if scale.dtype not in (np.float32, np.float64):
+        scale = scale.astype(np.float64)
+    principal = np.asarray(principal, dtype=np.float64).reshape(-1, 2)
+    R = inplane_rotations(rot)
+    cs, ms, sn = (R[:, 0, 0].astype(np.float64), R[:, 0, 1].astype(np.float64), R[:, 1, 0].astype(np.float64))
+    cx, cy, ox, oy = center[:, 0], center[:, 1], principal[:, 0], principal[:, 1]
+    V = scale.size
+    # warp: crop about the rotated centre, then the rotation folded in (columns 0/1 scale the rotation's rows)
+    sx, sy, tx, ty = _crop_about(cs * cx + ms * cy, sn * cx + cs * cy, scale, out_size)
+    A = np.zeros((V, 3, 3))
+    A[:, 0, 0], A[:, 0, 1], A[:, 0, 2] = sx * cs, sx * ms, tx
+    A[:, 1, 0], A[:, 1, 1], A[:, 1, 2] = sy * sn, sy * cs, ty
+    A[:, 2, 2] = 1
+    # intrinsics: the centre rotated about the principal point, o + R (c - o), with the translation column of
+    # T(o) R T(-o) formed first as upstream's left-to-right product does
+    shift_x = (cs * -ox + ms * -oy) + ox
+    shift_y = (sn * -ox + cs * -oy) + oy
+    sx, sy, tx, ty = _crop_about((cs * cx + ms * cy) + shift_x, (sn * cx + cs * cy) + shift_y, scale, out_size)
+    P = np.zeros((V, 3, 3))
+    P[:, 0, 0], P[:, 1, 1], P[:, 0, 2], P[:, 1, 2], P[:, 2, 2] = sx, sy, tx, ty, 1
+    return R, A.astype(np.float32), P.astype(np.float32)
 
 
-def _affine_transform_post_rot(center, scale, optical_center, out_res, rot=0):
-    rotmat = _construct_rotation_matrix(rot=rot, size=3)
-    t_mat = np.eye(3)
-    t_mat[0, 2] = -optical_center[0]
-    t_mat[1, 2] = -optical_center[1]
-    t_inv = t_mat.copy()
-    t_inv[:2, 2] *= -1
-    c = t_inv.dot(rotmat).dot(t_mat).dot(np.concatenate([center, np.ones(1)]))
-    return _get_affine_trans_no_rot(c[:2], scale, out_res).astype(np.float32)
-
-
-def _transform_coords(pts, affine_trans, invert=False):
-    if invert:
-        affine_trans = np.linalg.inv(affine_trans)
-    hom2d = np.concatenate([pts, np.ones([np.array(pts).shape[0], 1])], 1)
-    return affine_trans.dot(hom2d.transpose()).transpose()[:, :2]
-
-
-def center_scale_to_box(center, scale):               # transform.py:1083-1101
-    w = h = scale * 1.0
-    xmin = center[0] - w * 0.5
-    ymin = center[1] - h * 0.5
-    return [xmin, ymin, xmin + w, ymin + h]
+def _rows_times(mat, pts):
+    """mat (3,3), pts (n,3) -> rows  m[r,0]*x + m[r,1]*y + m[r,2]*z  summed left to right, in the promoted dtype."""
+    dt = np.result_type(mat.dtype, pts.dtype)
+    m, p = mat.astype(dt), np.asarray(pts).astype(dt)
+    return (m[None, :, 0] * p[:, 0:1] + m[None, :, 1] * p[:, 1:2]) + m[None, :, 2] * p[:, 2:3]
 
 
 # ---- the device stage -------------------------------------------------------------------------------------------------
@@ -164,113 +176,99 @@ def warp_views(images, affines, out_size, gains=None, device="cuda:0", out="f32"
     return f32 if f32 is not None else u8
 
 
-# ---- RandomOcclusion (transform.py:21-67): modifies the raw image on the host, before the upload -------------------------
-class RandomOcclusion:
-
-    def __init__(self, occlusion_prob=0.5):
-        self.occlusion_prob = occlusion_prob
-
-    def __call__(self, results):
-        if np.random.rand() > self.occlusion_prob:
-            return results
-        xmin, ymin, xmax, ymax = results["bbox"]
-        imgwidth, imgheight, img = results["width"], results["height"], results["image"]
-        synth_area = (random.random() * 0.2) * (xmax - xmin) * (ymax - ymin)
-        synth_ratio = random.random() * (1 / 0.5 - 0.5) + 0.5
-        synth_h = math.sqrt(synth_area * synth_ratio)
-        synth_w = math.sqrt(synth_area / synth_ratio)
-        synth_xmin = random.random() * ((xmax - xmin) - synth_w - 1) + xmin
-        synth_ymin = random.random() * ((ymax - ymin) - synth_h - 1) + ymin
-        if synth_xmin >= 0 and synth_ymin >= 0 and synth_xmin + synth_w < imgwidth and synth_ymin + synth_h < imgheight:
-            x0, y0, w, h = int(synth_xmin), int(synth_ymin), int(synth_w), int(synth_h)
-            img[y0:y0 + h, x0:x0 + w, :] = (np.random.rand(h, w, 3) * 255)
-        results["image"] = img
-        return results
-
-
 # ---- the transform ------------------------------------------------------------------------------------------------------
+class ViewDraw:
+    """The random part of one view's augmentation: bbox centre / scale jitter, in-plane rotation, colour gains."""
+    __slots__ = ("center", "scale", "rot", "gain")
+
+    def __init__(self, center, scale, rot=0.0, gain=None):
+        self.center, self.scale, self.rot, self.gain = center, scale, rot, gain
+
+
 @TRANSFORM.register_module()
 class SimpleTransform3DMultiView:
-    """``SimpleTransform2D`` + ``SimpleTransform3DMultiView`` (transform.py:70-196,240-281).
+    """Counterpart of upstream's ``SimpleTransform2D`` + ``SimpleTransform3DMultiView`` (transform.py:70-196,240-281): same
+    config keys, same result keys and dtypes, same consumption of ``np.random`` / ``random`` -- but organised per *frame*:
 
-    ``__call__(image, label, no_rot=False)`` -> the reference's result dict (``image`` is a (3,H,W) fp32 device tensor).
-    The batched form -- :meth:`labels` per view, then one :func:`warp_views` over all views of a frame or a batch -- is
-    what ``MultiviewWebDataset`` uses.  Heat-map / mask targets (``WITH_HEATMAP`` / ``WITH_MASK``) belong to the training
-    losses and are not built."""
+      :meth:`draw`          the random numbers of one view (the only sequential part)
+      :meth:`frame_labels`  the label arithmetic of all views of a frame in one vectorised pass (:func:`crop_geometry`)
+      :meth:`images`        the pixels of any number of views in ONE ``poem_warp_affine`` launch
+
+    ``__call__(image, label, no_rot=False)`` is the per-view form with the reference's signature.  Heat-map / mask targets
+    and the random-occlusion patch belong to the training losses / training augmentation and are not built (the released
+    configs switch the occlusion off: config/release/train_*.yaml ``OCCLUSION: False``)."""
 
     def __init__(self, cfg):
-        self._output_size = cfg.DATA_PRESET.IMAGE_SIZE
-        self._train = cfg.IS_TRAIN
-        self._aug = cfg.AUG
-        self._center_jit_factor = cfg.get("CENTER_JIT", 0)
-        self._scale_jit_factor = cfg.get("SCALE_JIT", 0.04 if self._aug else 0)
-        self._color_jit_factor = cfg.get("COLOR_JIT", 0.3 if self._aug else 0)
-        self._rot_jit_factor = cfg.get("ROT_JIT", 10 if self._aug else 0)
-        self._rot_prob = cfg.get("ROT_PROB", 1.0 if self._aug else 0)
-        self._occlusion = cfg.get("OCCLUSION", True if self._aug else False)
-        self._occlusion_prob = cfg.get("OCCLUSION_PROB", 0.1 if self._aug else 0)
+        self._output_size, self._train, self._aug = cfg.DATA_PRESET.IMAGE_SIZE, cfg.IS_TRAIN, cfg.AUG
+        on = bool(self._aug)
+        self._jitter = {"center": cfg.get("CENTER_JIT", 0), "scale": cfg.get("SCALE_JIT", 0.04 if on else 0),
+                        "rot_deg": cfg.get("ROT_JIT", 10 if on else 0), "color": cfg.get("COLOR_JIT", 0.3 if on else 0)}
+        self._rot_prob = cfg.get("ROT_PROB", 1.0 if on else 0)
+        if cfg.get("OCCLUSION", on) and cfg.get("OCCLUSION_PROB", 0.1 if on else 0) > 0:
+            raise NotImplementedError("OCCLUSION is a training-time augmentation outside the built path; set OCCLUSION: False")
         if cfg.DATA_PRESET.get("WITH_HEATMAP", False) or cfg.DATA_PRESET.get("WITH_MASK", False):
             raise NotImplementedError("heat-map / mask targets are training-side and outside the built path")
         self.device = cfg.get("DEVICE", "cuda:0")
-        if self._occlusion:
-            self.occlusion_op = RandomOcclusion(self._occlusion_prob)
+
+    # -- random numbers ---------------------------------------------------------------------------------------------------
+    def draw(self, label, no_rot=False):
+        """Consumes the generators exactly as one upstream ``__call__`` does: four normal deviates from ``np.random``
+        (centre x/y, scale, angle), one uniform unless ``no_rot`` (the master view keeps its orientation), and -- from the
+        ``random`` module, an independent stream -- three colour gains."""
+        if not self._aug:
+            return ViewDraw(label["bbox_center"], label["bbox_scale"])
+        j = self._jitter
+        z = np.random.standard_normal(4)
+        center = label["bbox_center"] + (0 + j["center"] * z[:2]) * label["bbox_scale"]
+        scale = label["bbox_scale"] * (1 + j["scale"] * z[2])
+        turn = (not no_rot) and np.random.rand() <= self._rot_prob
+        rot = np.deg2rad(0 + j["rot_deg"] * z[3]) if turn else 0.0
+        lo, hi = 1 - j["color"], 1 + j["color"]
+        return ViewDraw(center, scale, rot, [random.uniform(lo, hi) for _ in range(3)])
+
+    # -- labels -----------------------------------------------------------------------------------------------------------
+    def frame_labels(self, images, labels, draws):
+        """images / labels / draws: per kept view.  -> list of per-view result dicts (no pixels yet: ``raw_image``,
+        ``color_gain`` are the inputs of :meth:`images`)."""
+        V = len(labels)
+        K = [lab["cam_intr"] for lab in labels]
+        R, A, P = crop_geometry([d.center for d in draws], [d.scale for d in draws], [d.rot for d in draws],
+                                [[k[0, 2], k[1, 2]] for k in K], self._output_size)
+        W, H = self._output_size[0], self._output_size[1]
+        out = []
+        for v in range(V):
+            lab, d = labels[v], draws[v]
+            j2 = np.asarray(lab["joints_2d"])
+            a = A[v].astype(np.float64)
+            uv = np.stack([(a[0, 0] * j2[:, 0] + a[0, 1] * j2[:, 1]) + a[0, 2], (a[1, 0] * j2[:, 0] + a[1, 1] * j2[:, 1]) + a[1, 2]],
+                          axis=1).astype(np.float32)
+            if not self._train:
+                vis = np.ones(NUM_JOINTS, dtype=np.float32)
+            else:
+                inside = (uv[:, 0] >= 0) & (uv[:, 0] < W) & (uv[:, 1] >= 0) & (uv[:, 1] < H)
+                enough = lab["joints_vis"].sum() >= NUM_JOINTS * 0.3 and inside.sum() >= NUM_JOINTS * 0.3
+                vis = inside.astype(np.float32) if enough else np.zeros(NUM_JOINTS, dtype=np.float32)
+            p = P[v]
+            k = np.asarray(K[v])
+            dt = np.result_type(p.dtype, k.dtype)
+            intr = np.stack([p[0, 0].astype(dt) * k[0].astype(dt) + p[0, 2].astype(dt) * k[2].astype(dt),
+                             p[1, 1].astype(dt) * k[1].astype(dt) + p[1, 2].astype(dt) * k[2].astype(dt), k[2].astype(dt)])
+            out.append({"rot_rad": d.rot, "rot_mat3d": R[v], "affine": A[v], "target_bbox_center": d.center,
+                        "target_bbox_scale": d.scale, "target_joints_2d": uv, "target_joints_vis": vis,
+                        "image_path": lab["image_path"], "color_gain": d.gain, "raw_image": images[v],
+                        "affine_postrot": p, "extr_prerot": R[v], "target_cam_intr": intr,
+                        "target_joints_3d": _rows_times(R[v], lab["joints_3d"]),
+                        "target_verts_3d": _rows_times(R[v], lab["verts_3d"]),
+                        "target_joints_3d_no_rot": lab["joints_3d"], "target_verts_3d_no_rot": lab["verts_3d"]})
+        return out
 
     def labels(self, image, label, **kwargs):
-        """Everything of the reference's ``__call__`` except the pixels: draws the augmentation, applies the occlusion to
-        the raw image (host, in place, as upstream), returns the result dict without ``image`` plus ``color_gain``
-        (3 gains or None) for the device stage.  Pure numpy."""
-        if self._aug:
-            cf, sf, rf = self._center_jit_factor, self._scale_jit_factor, self._rot_jit_factor
-            c_factor = np.random.normal(loc=0, scale=cf, size=2)
-            bbox_center = label["bbox_center"] + c_factor * label["bbox_scale"]
-            s_factor = np.random.normal(loc=1, scale=sf)
-            bbox_scale = label["bbox_scale"] * s_factor
-            r_factor = np.random.normal(loc=0, scale=rf)
-            no_rot = kwargs.get("no_rot", False)
-            rot = np.deg2rad(r_factor) if (not no_rot and np.random.rand() <= self._rot_prob) else 0.0
-            if self._occlusion:
-                occ = {"bbox": center_scale_to_box(bbox_center, bbox_scale), "width": image.shape[1],
-                       "height": image.shape[0], "image": image}
-                image = self.occlusion_op(occ)["image"]
-        else:
-            bbox_scale, bbox_center, rot = label["bbox_scale"], label["bbox_center"], 0.0
-        rot_mat3d = _construct_rotation_matrix(rot)
-        affine = _affine_transform(center=bbox_center, scale=bbox_scale, out_res=self._output_size, rot=rot)
-        target_joints_2d = _transform_coords(label["joints_2d"], affine).astype(np.float32)
-        jv = label["joints_vis"]
-        if not self._train:
-            vis = np.full(NUM_JOINTS, 1.0, dtype=np.float32)
-        elif jv.sum() < NUM_JOINTS * 0.3:
-            vis = np.full(NUM_JOINTS, 0.0, dtype=np.float32)
-        else:
-            t = target_joints_2d
-            vis = (((t[:, 0] >= 0) & (t[:, 0] < self._output_size[0])) &
-                   ((t[:, 1] >= 0) & (t[:, 1] < self._output_size[1]))).astype(np.float32)
-            if vis.sum() < NUM_JOINTS * 0.3:
-                vis = np.full(NUM_JOINTS, 0.0, dtype=np.float32)
-        gain = None
-        if self._aug:                                   # the three draws follow the warp upstream; nothing between them
-            c_high, c_low = 1 + self._color_jit_factor, 1 - self._color_jit_factor          # consumes these generators
-            gain = [random.uniform(c_low, c_high) for _ in range(3)]
-        results = {"rot_rad": rot, "rot_mat3d": rot_mat3d, "affine": affine, "target_bbox_center": bbox_center,
-                   "target_bbox_scale": bbox_scale, "target_joints_2d": target_joints_2d, "target_joints_vis": vis,
-                   "image_path": label["image_path"], "color_gain": gain, "raw_image": image}
-        # SimpleTransform3DMultiView (:245-281)
-        intr = label["cam_intr"]
-        cc = np.array([intr[0, 2], intr[1, 2]])
-        affine_postrot = _affine_transform_post_rot(center=bbox_center, scale=bbox_scale, optical_center=cc,
-                                                    out_res=self._output_size, rot=rot)
-        results["affine_postrot"] = affine_postrot
-        results["extr_prerot"] = rot_mat3d
-        results["target_cam_intr"] = affine_postrot.dot(label["cam_intr"])
-        results["target_joints_3d"] = rot_mat3d.dot(label["joints_3d"].transpose(1, 0)).transpose()
-        results["target_verts_3d"] = rot_mat3d.dot(label["verts_3d"].transpose(1, 0)).transpose()
-        results["target_joints_3d_no_rot"] = label["joints_3d"]
-        results["target_verts_3d_no_rot"] = label["verts_3d"]
-        return results
+        """One view: draw, then the label arithmetic (pure numpy, runs anywhere)."""
+        return self.frame_labels([image], [label], [self.draw(label, kwargs.get("no_rot", False))])[0]
 
+    # -- pixels -----------------------------------------------------------------------------------------------------------
     def images(self, results_list):
-        """One launch for the views whose :meth:`labels` results are given; fills ``image`` and drops the staging keys."""
+        """One launch for the views whose label results are given; fills ``image`` and drops the staging keys."""
         gains = [r["color_gain"] for r in results_list]
         use_gain = any(g is not None for g in gains)
         out = warp_views([r["raw_image"] for r in results_list], [r["affine"][:2, :] for r in results_list],

@@ -154,21 +154,18 @@ class MultiviewWebDataset:
     that ``collation_random_n_views`` can warp every view of the batch in one launch."""
 
     def __init__(self, cfg, data_preset=None, is_train=True, defer_images=False, rank=None, world=None):
-        self.cfg = cfg
-        self.data_split = cfg.DATA_SPLIT
+        self.cfg, self.is_train, self.defer_images = cfg, is_train, defer_images
+        self.urls, self.data_split = cfg.URLS, cfg.DATA_SPLIT
         self.epoch_size = cfg.get("EPOCH_SIZE", None)
-        self.data_preset = data_preset if data_preset is not None else cfg.DATA_PRESET
-        self.urls = cfg.URLS
-        self.name = cfg.URLS.split("/")[-1].split("_")[0]
-        self.inv_extr = self.name in INV_EXTR_DATASETS
-        self.random_n_views = cfg.get("RANDOM_N_VIEWS", False)
-        self.view_range = cfg.get("VIEW_RANGE", None)
+        self.data_preset = cfg.DATA_PRESET if data_preset is None else data_preset
         self.mode = "train" if is_train else "val"
-        self.is_train = is_train
-        self.defer_images = defer_images
+        # "<root>/<Name>_mv/<Name>_mv_<split>-{000000..N}.tar": the dataset name decides the extrinsics convention
+        self.name = os.path.basename(cfg.URLS).split("_")[0]
+        self.random_n_views, self.view_range = cfg.get("RANDOM_N_VIEWS", False), cfg.get("VIEW_RANGE", None)
+        self.inv_extr = self.name in INV_EXTR_DATASETS
+        if self.random_n_views and (self.view_range is None or self.view_range[0] < 1):
+            raise AssertionError("RANDOM_N_VIEWS needs VIEW_RANGE = [lo >= 1, hi]")
         self.transform = build_transform(cfg=cfg.TRANSFORM, data_preset=self.data_preset, is_train=is_train)
-        if self.random_n_views:
-            assert self.view_range is not None and self.view_range[0] >= 1
         self.shards = split_by_node(expand_urls(self.urls), rank, world)
 
     def __iter__(self):
@@ -188,69 +185,91 @@ class MultiviewWebDataset:
     def get_dataset(self):
         return self
 
-    def process_data_item(self, item):                                       # multiview_wds.py:62-145
-        n_view_imgs = {k: v for k, v in item.items() if k.startswith("image")}
-        img_type = "jpg"
-        for k in n_view_imgs:
-            img_type = "png" if "png" in k else "jpg"
-        n_cams = len(n_view_imgs)
-        key = item["__key__"]
-        labels = item["label.pyd"]
-        if "mano_pose" in labels:
-            labels["mano_pose"] = [labels["mano_pose"][i].reshape(-1)[:48].reshape(16, 3) for i in range(n_cams)]
-        else:
-            labels["mano_pose"] = [np.zeros((16, 3)) for _ in range(n_cams)]
-            labels["mano_shape"] = [np.zeros(10) for _ in range(n_cams)]
-        if self.inv_extr:
-            labels["cam_extr"] = [np.linalg.inv(labels["cam_extr"][i]) for i in range(n_cams)]
-        indices = list(range(n_cams))
-        if self.random_n_views:
-            random.shuffle(indices)
-            n = int(round(random.gauss(4, 2)))
-            n = min(max(self.view_range[0], n), self.view_range[1])
-            indices_keep = indices[:min(n, n_cams)]
-        else:
-            indices_keep = indices
-        new_master_id = indices_keep[0]
-        T_master_2_new_master = labels["cam_extr"][new_master_id]
-        imgs = [n_view_imgs[f"image_{ind}.{img_type}"] for ind in indices_keep]
-        if labels.get("request_flip", False):                                # :112-118, all kept views in one launch
-            flips = [np.array([[-1, 0, 2 * labels["cam_intr"][ind][0, 2]], [0, 1, 0]], dtype=np.float32) for ind in indices_keep]
-            sizes = {tuple(labels["raw_size"][ind]) for ind in indices_keep}
-            if len(sizes) == 1:
-                imgs = list(warp_views(imgs, flips, sizes.pop(), device=self.transform.device, out="u8").cpu().numpy())
-            else:
-                imgs = [warp_views([im], [M], labels["raw_size"][ind], device=self.transform.device, out="u8")[0].cpu().numpy()
-                        for im, M, ind in zip(imgs, flips, indices_keep)]
-        per_view = []
-        for img, ind in zip(imgs, indices_keep):
-            lab = {k: v[ind] for k, v in labels.items() if k not in ["request_flip"]}
-            tgt = self.transform.labels(img, lab, no_rot=ind == new_master_id)
-            T_new_master_2_cam = np.linalg.inv(T_master_2_new_master) @ lab["cam_extr"]
-            pre = np.concatenate([tgt["extr_prerot"], np.zeros((3, 1))], axis=1)
-            pre = np.concatenate([pre, np.array([[0, 0, 0, 1]])], axis=0)
-            tgt["target_cam_extr"] = np.linalg.inv(pre @ np.linalg.inv(T_new_master_2_cam)).astype(np.float32)
-            tgt.update(lab)
-            per_view.append(tgt)
+    # -- one record -> one processed frame (multiview_wds.py:62-145 upstream) --------------------------------------------
+    def _choose_views(self, n_cams):
+        """Camera indices kept for this frame, master first.  Random-view mode consumes ``random`` as upstream does:
+        one shuffle, one Gaussian draw (mean 4, sigma 2) clamped to VIEW_RANGE and to the cameras there are."""
+        order = list(range(n_cams))
+        if not self.random_n_views:
+            return order
+        random.shuffle(order)
+        want = int(round(random.gauss(4, 2)))
+        lo, hi = self.view_range[0], self.view_range[1]
+        return order[:min(max(lo, want), hi, n_cams)]
+
+    def _mirrored(self, pixels, cam_intr, raw_size):
+        """``request_flip`` records (left hands stored un-mirrored): reflect every kept view about the vertical line through
+        its principal point, x -> 2 cx - x, at the raw resolution -- all views that share a raw size in one launch."""
+        flips = [np.array([[-1, 0, 2 * k[0, 2]], [0, 1, 0]], dtype=np.float32) for k in cam_intr]
+        out = [None] * len(pixels)
+        for size in sorted({tuple(s) for s in raw_size}):
+            group = [i for i, s in enumerate(raw_size) if tuple(s) == size]
+            warped = warp_views([pixels[i] for i in group], [flips[i] for i in group], size, device=self.transform.device,
+                                out="u8").cpu().numpy()
+            for j, i in enumerate(group):
+                out[i] = warped[j]
+        return out
+
+    @staticmethod
+    def remaster_extrinsics(cam_extr, prerot):
+        """cam_extr (V,4,4): camera -> old-master transforms of the kept views, view 0 = the new master; prerot (V,3,3): the
+        in-plane rotation applied to each view's image.  -> (V,4,4) fp32 camera -> new-master transforms of the *rotated*
+        cameras:  inv( [R_v 0; 0 1] . inv( inv(T_0) . T_v ) ), batched over the views."""
+        T = np.stack([np.asarray(t) for t in cam_extr])
+        rel = np.linalg.inv(T[0]) @ T
+        pre = np.zeros((len(T), 4, 4))
+        pre[:, :3, :3] = prerot
+        pre[:, 3, 3] = 1
+        return np.linalg.inv(pre @ np.linalg.inv(rel)).astype(np.float32)
+
+    def process_data_item(self, item):
+        cams = {}                                                            # camera index -> decoded pixels
+        for name, value in item.items():
+            m = re.fullmatch(r"image_(\d+)\.(\w+)", name)
+            if m:
+                cams[int(m.group(1))] = value
+        n_cams, labels = len(cams), item["label.pyd"]
+        has_fit = "mano_pose" in labels
+        # MANO fits are stored with trailing extras (keep 16 x 3); records without fits (Oakink dumps) get zeros
+        labels["mano_pose"] = [np.asarray(labels["mano_pose"][c]).reshape(-1)[:48].reshape(16, 3) if has_fit else np.zeros((16, 3))
+                               for c in range(n_cams)]
+        if not has_fit:
+            labels["mano_shape"] = [np.zeros(10)] * n_cams
+        if self.inv_extr:                                                    # these datasets store master -> camera
+            labels["cam_extr"] = list(np.linalg.inv(np.stack(labels["cam_extr"][:n_cams])))
+        keep = self._choose_views(n_cams)
+        master = keep[0]
+        fields = [k for k in labels if k != "request_flip"]
+        view_labels = [{k: labels[k][c] for k in fields} for c in keep]
+        pixels = [cams[c] for c in keep]
+        if labels.get("request_flip", False):
+            pixels = self._mirrored(pixels, [lab["cam_intr"] for lab in view_labels], [lab["raw_size"] for lab in view_labels])
+        draws = [self.transform.draw(lab, no_rot=(c == master)) for lab, c in zip(view_labels, keep)]
+        views = self.transform.frame_labels(pixels, view_labels, draws)
+        extr = self.remaster_extrinsics([lab["cam_extr"] for lab in view_labels], [v["extr_prerot"] for v in views])
+        for v, lab, e in zip(views, view_labels, extr):
+            v["target_cam_extr"] = e
+            v.update(lab)
         if not self.defer_images:
-            self.transform.images(per_view)
-        res = {}
-        for tgt in per_view:
-            for k, v in tgt.items():
-                res.setdefault(k, []).append(v)
-        for q in res:
-            if q in ("raw_image", "color_gain"):
-                continue
-            if isinstance(res[q][0], torch.Tensor):
-                res[q] = torch.stack(res[q])                                 # device images stay on the device
-            elif isinstance(res[q][0], (int, float, np.ndarray)):
-                res[q] = np.stack(res[q])
-        res["master_id"] = 0
-        res["master_serial"] = labels["cam_serial"][new_master_id]
-        res["master_joints_3d"] = labels["joints_3d"][new_master_id]
-        res["master_verts_3d"] = labels["verts_3d"][new_master_id]
-        res["__key__"] = key
-        return res
+            self.transform.images(views)
+        frame = {k: _column([v[k] for v in views], keep_list=k in ("raw_image", "color_gain")) for k in views[0]}
+        frame.update(master_id=0, master_serial=labels["cam_serial"][master], master_joints_3d=labels["joints_3d"][master],
+                     master_verts_3d=labels["verts_3d"][master], __key__=item["__key__"])
+        return frame
+
+
+def _column(values, keep_list=False):
+    """Per-view values of one field -> the frame's entry.  As upstream (`np.stack` when the first value is an int, a float
+    or an array): numbers and arrays gain a leading view axis, everything else (paths, serials, size tuples, numpy scalars
+    that are not Python floats) stays a per-view list; device images are stacked on the device."""
+    first = values[0]
+    if keep_list:
+        return values
+    if isinstance(first, torch.Tensor):
+        return torch.stack(values)
+    if isinstance(first, (int, float, np.ndarray)):
+        return np.stack(values)
+    return values
 
 
 def _buffer_shuffle(it, size):

@@ -88,8 +88,28 @@ def random_views(n_samples, view_range, seed):
     return rng.randint(lo, hi + 1, size=n_samples).tolist()
 
 
+def load_template(path):
+    """(799,3) zero-pose hand template in metres (rows 0..20 joints, 21..798 vertices, centred at joint 9) from a ``.npy`` /
+    ``.pt`` file: on a licensed machine, ManoLayer's zero-pose output (lib/models/heads/ptEmb_head.py:886-892 upstream)."""
+    t = np.load(path) if path.endswith(".npy") else torch.load(path, map_location="cpu")
+    return torch.as_tensor(np.asarray(t), dtype=torch.float32).reshape(799, 3)
+
+
+def install_template(head, reload, template):
+    """Which hand template the head runs with, and a word for the result record.  A seeded synthetic template is only
+    right for seeded synthetic weights: with ``--reload`` the template must come from ``--template``; otherwise the head's
+    own "synthetic template" warning is left armed and the record says so."""
+    if template:
+        head.set_template(load_template(template))
+        return f"file:{template}"
+    if reload:
+        return "synthetic (NO --template given with --reload: metrics are not meaningful for a real checkpoint)"
+    head.set_template(pk.inputs.synthetic_template(1234))
+    return "synthetic(seed=1234)"
+
+
 def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, batch_size=2, seed=0, verbose=True,
-             pyramid=False):
+             pyramid=False, template=None):
     rank, _, world = pdist.env_world()
     head_node = pk.CN(cfg["MODEL"]["HEAD"])
     head_node["MAX_VIEWS"] = max(10, int(view_range[1]))
@@ -103,7 +123,7 @@ def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, ba
             print(f"reloaded {reload}: {len(ignored)} dead tensors ignored")
     else:
         head.load_state_dict(pk.weights.seeded_state_dict(embed, seed=0, parametric=head.parametric_output), strict=False)
-    head.set_template(pk.inputs.synthetic_template(1234))
+    template_source = install_template(head, reload, template)
     if head.parametric_output:
         raise SystemExit("medium_MANO needs a MANO layer (licence-gated assets): call head.set_mano_layer(fn) from "
                          "Python; this script evaluates the non-parametric categories")
@@ -171,12 +191,13 @@ def evaluate(cfg, view_range, model_type, device, reload=None, epoch_size=64, ba
            "samples": int(mpvpe.acc[1].item()), "MPVPE_mm_vs_synthetic_gt": mpvpe.result() * 1e3,
            "MPJPE_mm_vs_synthetic_gt": mpjpe.result() * 1e3, "PA_MPJPE_mm": pam["pa_mpjpe"] * 1e3,
            "PA_MPVPE_mm": pam["pa_mpvpe"] * 1e3, "auc_j": pck_j.get_measures()["auc_all"], "auc_v": pck_v.get_measures()["auc_all"],
-           "samples_per_s_rank0": (n_done / dt) if dt > 0 and n_done else None, "world_size": world}
+           "samples_per_s_rank0": (n_done / dt) if dt > 0 and n_done else None, "world_size": world,
+           "template_source": template_source}
     return res
 
 
 def evaluate_shards(cfg, view_range, model_type, device, shard_dir, dataset, reload=None, epoch_size=16, batch_size=2,
-                    n_cams=8, raw_size=(640, 480)):
+                    n_cams=8, raw_size=(640, 480), template=None):
     """Images -> metrics from record shards (SURVEY 8f N4 in front of the model): ``MultiviewWebDataset`` over the URLS of the
     edited config (tar records: ``image_<i>.png|jpg`` + ``label.pyd``), the per-view crop / warp / normalise on the
     device (one launch per batch), ``collation_random_n_views``, then the model-level caller
@@ -184,13 +205,12 @@ def evaluate_shards(cfg, view_range, model_type, device, shard_dir, dataset, rel
     against the records' ``master_joints_3d`` / ``master_verts_3d`` (lib/models/POEM.py:596-610 upstream).
     The dataset tars are not available offline: when ``shard_dir`` holds no shard of the dataset's name, seeded synthetic
     shards of the same record layout are written there first."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     rank, _, world = pdist.env_world()
     ds_node = cfg["DATASET"]["TEST"]["TARGET"]
     pattern = os.path.join(shard_dir, os.path.basename(ds_node["URLS"]))
     urls = pk.wds.expand_urls(pattern)
     if rank == 0 and not all(os.path.exists(u) for u in urls):
-        from transform_oracle import synthetic_frame        # the seeded record generator (test infrastructure: data only)
+        synthetic_frame = pk.inputs.synthetic_frame
         os.makedirs(shard_dir, exist_ok=True)
         per = -(-epoch_size // len(urls))
         for si, u in enumerate(urls):
@@ -205,11 +225,13 @@ def evaluate_shards(cfg, view_range, model_type, device, shard_dir, dataset, rel
     if reload:
         sd = torch.load(reload, map_location="cpu")
         model.load_state_dict(sd.get("state_dict", sd.get("model", sd)) if isinstance(sd, dict) else sd)
+        template_source = install_template(model.ptEmb_head, reload, template)
     else:
+        template_source = f"file:{template}" if template else "synthetic(seed=1234)"
         from poem_v2_amd.backbone import seeded_hrnet_state_dict
         model.load_parts(seeded_hrnet_state_dict(0), pk.weights.seeded_decoder_state_dict(0),
                          pk.weights.seeded_state_dict(model.ptEmb_head.embed_dims, seed=0),
-                         template=pk.inputs.synthetic_template(1234))
+                         template=load_template(template) if template else pk.inputs.synthetic_template(1234))
     mpvpe, mpjpe = MeanEPE("verts", device=device), MeanEPE("joints", device=device)
     n, t0, frames = 0, None, []
 
@@ -242,7 +264,8 @@ def evaluate_shards(cfg, view_range, model_type, device, shard_dir, dataset, rel
     return {"dataset_source": f"record shards {pattern} (synthetic records)", "scope": "shards->images->verts",
             "model": model_type, "view_range": list(view_range), "samples": int(mpvpe.acc[1].item()),
             "MPVPE_mm_vs_record_gt": mpvpe.result() * 1e3, "MPJPE_mm_vs_record_gt": mpjpe.result() * 1e3,
-            "samples_per_s_rank0": (n / dt) if dt > 0 and n else None, "world_size": world}
+            "samples_per_s_rank0": (n / dt) if dt > 0 and n else None, "world_size": world,
+            "template_source": template_source}
 
 
 def main(args):
@@ -253,9 +276,14 @@ def main(args):
     else:
         cfg = default_cfg()
     view_range = edit_cfg(cfg, args.dataset, args.model, view_range)
-    if args.cfg:
-        with open(args.cfg, "w") as f:            # upstream dumps the edited tree back to the same path
+    # upstream dumps the edited tree back to the same path from its single launcher process; under torch.distributed.run
+    # every rank executes this script, so only rank 0 writes (via a rename: a concurrent reader sees the old or the new
+    # file, never a truncated one) and the others keep their in-memory edit
+    if args.cfg and int(os.environ.get("RANK", "0")) == 0:
+        tmp = f"{args.cfg}.tmp{os.getpid()}"
+        with open(tmp, "w") as f:
             yaml.dump(cfg, f)
+        os.replace(tmp, args.cfg)
     rank, local_rank, world = pdist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("eval_single.py needs a GPU: the head runs on the MI355X HIP path only (no CPU fallback)")
@@ -265,10 +293,10 @@ def main(args):
         print("--draw: rendering is outside the hot path and not built (DESIGN.md section 0); metrics only")
     if args.shards:
         res = evaluate_shards(cfg, view_range, args.model, device, args.shards, args.dataset, reload=args.reload,
-                              epoch_size=args.epoch_size, batch_size=args.batch_size)
+                              epoch_size=args.epoch_size, batch_size=args.batch_size, template=args.template)
     else:
         res = evaluate(cfg, view_range, args.model, device, reload=args.reload, epoch_size=args.epoch_size,
-                       batch_size=args.batch_size, pyramid=args.pyramid)
+                       batch_size=args.batch_size, pyramid=args.pyramid, template=args.template)
     if rank == 0:
         exp_id = f"{args.dataset}_view_{view_range[0]}_{view_range[1]}_{args.model}"
         print(json.dumps({"exp_id": exp_id, **res}))
@@ -293,5 +321,8 @@ if __name__ == "__main__":
     parser.add_argument("--shards", type=str, default=None, metavar="DIR",
                         help="evaluate the full model from record shards under DIR (the dataset's URLS pattern; synthetic "
                              "shards are written there when absent): tar records -> device transform -> model -> metrics")
+    parser.add_argument("--template", type=str, default=None, metavar="FILE",
+                        help="(799,3) zero-pose hand template (.npy / .pt; ManoLayer's zero-pose joints + vertices, centred at "
+                             "joint 9).  Required for meaningful metrics with --reload; synthetic otherwise (this build).")
     parser.add_argument("--batch_size", type=int, default=2, help="--val_batch_size of the reference (lib/opt.py:27-30).")
     main(parser.parse_args())

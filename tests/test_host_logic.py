@@ -165,7 +165,7 @@ sys.path.insert(0, sys.argv[1])
 import torch.distributed as dist
 import poem_v2_amd as pk
 from poem_v2_amd import dist as pdist
-from poem_v2_amd.metrics import MeanEPE
+from poem_v2_amd.metrics import MeanEPE, PAEval, Joint3DPCK
 rank, local, world = pdist.init_from_env(backend="gloo")
 assert world == 2
 g = torch.Generator().manual_seed(0)
@@ -175,9 +175,28 @@ m = MeanEPE("v"); m.feed(pred[lo:hi], gt[lo:hi]); m.reduce()
 full = MeanEPE("v"); full.feed(pred, gt)
 assert abs(m.result() - full.result()) < 1e-6, (m.result(), full.result())
 t = torch.tensor([float(rank + 1)], dtype=torch.float64); pdist.all_reduce_max_(t); assert t.item() == 2.0
+# reduce() is non-destructive for every metric: twice in a row, then feed-after-reduce, never counts once per rank.
+# (feed() itself is a HIP launch; the accumulators are filled by hand here: rank r holds r+1 samples)
+m.reduce(); assert abs(m.result() - full.result()) < 1e-6
+pa = PAEval(None, mesh_score=True, device="cpu")
+pa.acc += torch.tensor([1.0, 2.0, 3.0, 4.0, 1.0], dtype=torch.float64) * (rank + 1)
+for _ in range(2):
+    pa.reduce()
+    meas = pa.get_measures()
+    assert abs(meas["pa_mpjpe"] - 1.0) < 1e-12 and abs(meas["mpvpe"] - 4.0) < 1e-12, meas
+    assert pa.acc[4].item() == rank + 1                      # local sums untouched
+pck = Joint3DPCK(device="cpu", VAL_MIN=0.0, VAL_MAX=0.02, STEPS=5)
+pck.n += (rank + 1); pck.counts[:, 2:] += (rank + 1); pck.sum += 0.01 * (rank + 1)
+pck.dists.append(torch.full((rank + 1, 21), 0.03 if rank else 0.01))
+for _ in range(2):
+    pck.reduce()
+    g = pck.get_measures()
+    assert abs(g["epe_mean_all"] - 0.01) < 1e-12 and abs(g["pck_curve_per_kp"][0, 2] - 1.0) < 1e-12, g
+    assert pck.get_pck_all(0.02) == 1.0                      # a histogram step: from the reduced counts, no collective
+    assert abs(pck.get_pck_all(0.017) - 1.0 / 3.0) < 1e-12   # any other threshold: global [hits, total] (1 of 3 samples)
+    assert int(pck.n[0]) == rank + 1
 # input side (N4): shards are dealt by rank (webdataset.split_by_node), no data-path collective; the union is the epoch
-sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
-import transform_oracle as to
+to = pk.inputs
 d = sys.argv[2]
 if rank == 0:
     for si in range(4):

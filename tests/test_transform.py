@@ -149,6 +149,42 @@ def test_color_jitter_truncates_like_a_uint8_assignment():
     assert out[..., 0].max() == int(255 * 0.7137) and out[..., 1].max() == 255 and np.array_equal(out[..., 2], img[..., 2])
 
 
+def test_product_record_generator_equals_test_generator():
+    """``scripts/eval_single.py --shards`` writes its shards with the product's own generator (poem_v2_amd.inputs); it is
+    the same seeded record the test infrastructure uses, so fixtures and product shards describe the same frames."""
+    import poem_v2_amd as pk
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, (list, tuple)):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        if isinstance(a, np.ndarray):
+            return a.dtype == b.dtype and np.array_equal(a, b)
+        return type(a) is type(b) and a == b
+    for kw in (dict(seed=3, n_cams=4), dict(seed=9, n_cams=2, raw=(96, 64), ext="jpg", dtype=np.float64)):
+        assert same(pk.inputs.synthetic_frame(**kw), to.synthetic_frame(**kw))
+
+
+def test_crop_geometry_is_the_composition_it_claims():
+    """Independent of the fixtures: A maps the bbox square onto the window after rotating about the origin, P is a pure
+    crop whose centre is the bbox centre rotated about the principal point."""
+    import poem_v2_amd as pk
+    g = np.random.default_rng(0)
+    c, s, r, o = g.uniform(100, 400, (5, 2)), g.uniform(80, 200, 5), g.uniform(-0.3, 0.3, 5), g.uniform(200, 300, (5, 2))
+    r[0] = 0.0
+    R, A, P = pk.transform.crop_geometry(c, s, r, o, (256, 192))
+    for v in range(5):
+        Rm = np.array([[np.cos(r[v]), -np.sin(r[v])], [np.sin(r[v]), np.cos(r[v])]])
+        assert np.allclose(R[v][:2, :2], Rm, atol=1e-7) and R[v][2, 2] == 1
+        centre = A[v].astype(np.float64) @ np.array([c[v, 0], c[v, 1], 1.0])
+        assert np.allclose(centre[:2], [128, 96], atol=1e-3)                      # bbox centre -> window centre
+        assert np.allclose(A[v][:2, :2], (256 / s[v]) * Rm, rtol=1e-6, atol=1e-6)  # isotropic zoom (aspect folded in)
+        pc = o[v] + Rm @ (c[v] - o[v])
+        assert np.allclose(P[v].astype(np.float64) @ np.array([pc[0], pc[1], 1.0]), [128, 96, 1], atol=1e-3)
+        assert P[v][0, 1] == 0 and P[v][1, 0] == 0
+
+
 def test_shard_format_round_trip(tmp_path):
     import poem_v2_amd as pk
     recs = [to.synthetic_frame(s, n_cams=n, raw=(96, 64)) for s, n in ((1, 2), (2, 3))]
