@@ -166,6 +166,12 @@ int poem_profile_read(poem_handle_t h, int* launches, float* total_ms, int reset
 /* The same for the anchored (table) launches of block 0 (poem_set_anchor_tables), which poem_profile_read leaves out:
  * call it before a resetting poem_profile_read. */
 int poem_profile_read_anchored(poem_handle_t h, int* launches, float* total_ms);
+/* Generic form: the spans poem_head_forward times between HIP events on the caller's stream, by kind.  (Read before a
+ * resetting poem_profile_read.) */
+#define POEM_PROF_VECATTN 0        /* the full fused vector attention (what poem_profile_read sums) */
+#define POEM_PROF_VECATTN_ANCHORED 1
+#define POEM_PROF_SAMPLING 2       /* input_proj .. merge finalize: the sampling front end of one forward */
+int poem_profile_read_stage(poem_handle_t h, int stage, int* launches, float* total_ms);
 /* Debug taps: copies of intermediate tensors of the LAST poem_head_forward on this handle (device->device).
  * name: "x","g","bps_feat","pt_xyz","query_xyz","b<i>.h_cross","b<i>.f_self","b<i>.f_cross","b<i>.xyz",
  * "b<i>.feats","b<i>.idx_self","b<i>.idx_cross".  Returns number of elements or <0. */
@@ -264,6 +270,21 @@ int poem_pck_accumulate(const float* pred, const float* gt, int batch, int npoin
  * lib/models/POEM.py:602-603): j_regressor (16,nverts) MANO's th_J_regressor, verts (B,nverts,3) -> joints (B,21,3) in
  * OpenPose order (16 regressed joints + the 5 finger-tip vertices, re-ordered).  nverts must be 778. */
 int poem_mano_to_openpose(const float* j_regressor, const float* verts, float* joints, int batch, int nverts, void* stream);
+/* MANO linear blend skinning: the `ManoLayer(pose_aa, betas)` call of the medium_MANO tail
+ * (lib/models/bricks/pt_metro_transformer.py:120-124,147-148: manotorch ManoLayer(joint_rot_mode="axisang", use_pca=False,
+ * flat_hand_mean=True, center_idx=9)) and the head's zero-pose template (lib/models/heads/ptEmb_head.py:732-736,886-892).
+ * pose_aa (B,48) axis-angle of the 16 joints, betas (B,10); assets as device buffers: v_template (778,3),
+ * shapedirs (778,3,10), posedirs (778,3,135), j_regressor (16,778), weights (778,16)  [MANO_RIGHT.pkl fields; licence-gated,
+ * never read from disk here].  -> verts (B,778,3), joints (B,21,3) in the 21-joint hand order (16 skeleton joints + the
+ * finger-tip vertices 745,317,444,556,673), both minus joint center_idx (-1: not centred).  manotorch is absent from the
+ * reference tree: restated from the published model in manopth / manotorch's evaluation order -- parity unpinned. */
+/* The rotation half of get_parametric_output (pt_metro_transformer.py:144-146 -> rot6d_to_aa, lib/utils/transform.py:448-466:
+ * pytorch3d rotation_6d_to_matrix -> matrix_to_quaternion -> quaternion_to_axis_angle): params (B,106) = 16 six-dimensional
+ * rotations then 10 betas -> pose_aa (B,48), betas (B,10). */
+int poem_rot6d_to_axis_angle(const float* params, float* pose_aa, float* betas, int batch, void* stream);
+int poem_mano_lbs(const float* pose_aa, const float* betas, const float* v_template, const float* shapedirs,
+                  const float* posedirs, const float* j_regressor, const float* weights, int batch, int center_idx,
+                  float* verts, float* joints, void* stream);
 /* Crop / warp / normalise every view of a batch in one launch (replaces the per-view host chain of
  * lib/utils/transform.py:153-170: cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT 0) -> colour jitter -> to_tensor ->
  * normalize(0.5, 1)).  src: the raw uint8 HxWx3 images back to back in one device blob; src_offsets (views) byte offset

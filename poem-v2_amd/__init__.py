@@ -6,10 +6,11 @@ registers them, as ``import lib.models`` does upstream)."""
 from .config import CN  # noqa: F401
 from .builder import (HEAD, TRANSFORMER, BACKBONE, MODEL, Registry, build_from_cfg, build_head, build_transformer,  # noqa: F401
                       build_backbone, build_model)
-from . import builder, weights, inputs, hip, configs, triangulation, decode, backbone, transform, wds  # noqa: F401
+from . import builder, weights, inputs, hip, configs, triangulation, decode, backbone, transform, wds, mano  # noqa: F401
 from .transformer import PtEmbedTRv4  # noqa: F401
 from .head import POEM_Generalized_Head  # noqa: F401
 from .backbone import HRNet  # noqa: F401
 from .model import PtEmbedMultiviewStereoV2  # noqa: F401
 from .transform import TRANSFORM, SimpleTransform3DMultiView, build_transform  # noqa: F401
 from .wds import MultiviewWebDataset, MixWebDataset, collation_random_n_views  # noqa: F401
+from .mano import ManoLayer  # noqa: F401

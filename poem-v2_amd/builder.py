@@ -68,7 +68,12 @@ class Registry:
 
 
 def build_from_cfg(cfg, registry, **kwargs):
-    assert isinstance(cfg, CN) and cfg.get("TYPE") is not None, "cfg must be a CN with a TYPE"
+    # a node of the reference's own config class (yacs ``CfgNode``, a dict subclass) arrives here when this package's
+    # classes are registered in the reference's registries: the head then builds its
+    # transformer from ``cfg.TRANSFORMER`` through this function -- adopt the node instead of refusing it
+    if isinstance(cfg, dict) and not isinstance(cfg, CN):
+        cfg = CN(dict(cfg))
+    assert isinstance(cfg, CN) and cfg.get("TYPE") is not None, "cfg must be a config node with a TYPE"
     if kwargs:
         merged = cfg.clone()
         merged.defrost()

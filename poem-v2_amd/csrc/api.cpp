@@ -102,6 +102,9 @@ hipError_t poem_launch_finalize_param(const float* verts, const float* joints, c
 hipError_t poem_launch_q3_flatten(const float* feats, const float* fw, const float* fb, float* t, int B, int Q, int C,
                                   hipStream_t s);
 hipError_t poem_launch_rot6d_to_aa(const float* par, float* pose_aa, float* betas, int B, hipStream_t s);
+hipError_t poem_launch_mano_lbs(const float* pose, const float* betas, const float* v_template, const float* shapedirs,
+                                const float* posedirs, const float* j_regressor, const float* weights, float* verts,
+                                float* joints, int B, int center_idx, hipStream_t s);
 hipError_t poem_launch_compose_weight(const float* A, const float* Bm, float* out, int N, int Cm, int K, hipStream_t s);
 hipError_t poem_launch_compose_bias(const float* A, const float* b1, const float* b2, float* out, int N, int Cm,
                                     hipStream_t s);
@@ -1154,6 +1157,23 @@ int poem_mano_to_openpose(const float* j_regressor, const float* verts, float* j
   return POEM_OK;
 }
 
+int poem_rot6d_to_axis_angle(const float* params, float* pose_aa, float* betas, int batch, void* stream) {
+  if (!params || !pose_aa || !betas || batch <= 0) return POEM_E_ARG;
+  HIPCHK(poem_launch_rot6d_to_aa(params, pose_aa, betas, batch, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_mano_lbs(const float* pose_aa, const float* betas, const float* v_template, const float* shapedirs,
+                  const float* posedirs, const float* j_regressor, const float* weights, int batch, int center_idx,
+                  float* verts, float* joints, void* stream) {
+  if (!pose_aa || !betas || !v_template || !shapedirs || !posedirs || !j_regressor || !weights || !verts || !joints ||
+      batch <= 0 || center_idx < -1 || center_idx > 20)
+    return POEM_E_ARG;
+  HIPCHK(poem_launch_mano_lbs(pose_aa, betas, v_template, shapedirs, posedirs, j_regressor, weights, verts, joints, batch,
+                              center_idx, (hipStream_t)stream));
+  return POEM_OK;
+}
+
 int poem_warp_affine(const uint8_t* src, const int64_t* src_offsets, const int32_t* src_hw, const double* m_inv,
                      const double* gain, float* out_f32, uint8_t* out_u8, int views, int out_h, int out_w, void* stream) {
   if (!src || !src_offsets || !src_hw || !m_inv || (!out_f32 && !out_u8) || views <= 0 || out_h <= 0 || out_w <= 0)
@@ -1245,6 +1265,9 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
     if (rc != POEM_OK) return rc;
   }
   // ---- sampling stage ------------------------------------------------------------------------------------------
+  const bool prof_fe = h->prof_on && (size_t)(2 * h->prof_used + 1) < h->prof_ev.size();
+  const int prof_fe_slot = h->prof_used;
+  if (prof_fe) { HIPCHK(hipEventRecord(h->prof_ev[2 * prof_fe_slot], s)); h->prof_kind[h->prof_used++] = POEM_PROF_SAMPLING; }
   HIPCHK(poem_launch_conv1x1(mlvl_feat, h->P(T_INPROJ_W), h->R(T_INPROJ_B), h->pe_table, p.pe_index, p.x, BN,
                              c.in_channels, C, HW, s));
   HIPCHK(poem_launch_prep_xyz(reference_joints, h->bps, h->tmpl, p.centre, p.pt_xyz, p.xyz[0], B, S, Q, c.radius, s));
@@ -1257,6 +1280,7 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   GEMM(p.mm, C / 2, T_M10_W, T_M10_B, nullptr, 0, p.mh, C / 2, BS, C / 2, C / 2, POEM_ACT_RELU);
   GEMM(p.mh, C / 2, T_M12_W, T_M12_B, nullptr, 0, p.y, C, BS, C, C / 2, POEM_ACT_NONE);
   HIPCHK(poem_launch_merge_finalize(p.g, p.y, p.offs, p.bps_feat, B, S, C, s));
+  if (prof_fe) HIPCHK(hipEventRecord(h->prof_ev[2 * prof_fe_slot + 1], s));
 
   // ---- decoder ---------------------------------------------------------------------------------------------------
   HIPCHK(poem_launch_broadcast(h->R(T_QEMB), p.feats0, (long)Q * C, B, s));
@@ -1332,6 +1356,11 @@ int poem_profile_read(poem_handle_t h, int* launches, float* total_ms, int reset
 int poem_profile_read_anchored(poem_handle_t h, int* launches, float* total_ms) {
   if (!h || !launches || !total_ms) return POEM_E_ARG;
   return profile_sum(h, 1, launches, total_ms);
+}
+
+int poem_profile_read_stage(poem_handle_t h, int stage, int* launches, float* total_ms) {
+  if (!h || !launches || !total_ms || stage < 0 || stage > 7) return POEM_E_ARG;
+  return profile_sum(h, stage, launches, total_ms);
 }
 
 int poem_finalize_parametric(poem_handle_t h, const float* mano_verts, const float* mano_joints,

@@ -39,6 +39,9 @@ class POEM_Generalized_Head(nn.Module):
         assert self.query_type == "KPT"                                  # ptEmb_head.py:721
         if self.PETR_embedding:
             raise NotImplementedError("PETR_EMBEDDING=True is not used by any release config and is not built")
+        if not self.cfg_position_encoding.get("NORMALIZE", True):
+            raise NotImplementedError("POSITIONAL_ENCODING.NORMALIZE=False is not used by any release config and is not built "
+                                      "(the positional table is folded with normalize=True, scale 2*pi, temperature 1e4)")
         if self.cfg_position_encoding.NUM_FEATS * 2 != self.embed_dims:
             raise ValueError("POSITIONAL_ENCODING.NUM_FEATS must be EMBED_DIMS / 2")
         C = self.embed_dims

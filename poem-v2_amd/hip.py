@@ -80,6 +80,9 @@ SIGNATURES = {
     "poem_pool_conv1x1_sigmoid": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_pa_epe": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "poem_mano_to_openpose": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "poem_rot6d_to_axis_angle": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "poem_mano_lbs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "poem_profile_read_stage": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_f)]),
     "poem_warp_affine": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "poem_pck_accumulate": (_i, [_vp, _vp, _i, _i, ctypes.c_double, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp]),
     "poem_knn": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -184,6 +187,10 @@ class Engine:
         self.anchor_idx = anchor_idx.to(self.device, torch.int32).contiguous()
         self.template = template.to(self.device, torch.float32).contiguous()
         assert self.bps.shape == (cfg.nsample, 3) and self.anchor.shape == (32, 3) and self.template.shape == (cfg.nquery, 3)
+        # quirk Q2: the anchor ids index the query rows (vector self attention) AND the basis-point rows (cross attention)
+        if anchor_idx.numel() != 32 or int(anchor_idx.min()) < 0 or int(anchor_idx.max()) >= min(cfg.nquery, cfg.nsample):
+            raise RuntimeError(f"anchor_idx must hold 32 ids in [0, {min(cfg.nquery, cfg.nsample)}) "
+                               f"(got {anchor_idx.numel()} ids, range [{int(anchor_idx.min())}, {int(anchor_idx.max())}])")
         nbytes = L.poem_packed_bytes(ctypes.byref(cfg))
         if nbytes == 0:
             raise RuntimeError("unsupported configuration for libpoem_hip")
@@ -238,6 +245,13 @@ class Engine:
         check(lib().poem_profile_read(self.handle, ctypes.byref(n), ctypes.byref(ms), int(reset)), "poem_profile_read")
         return n.value, ms.value
 
+    def profile_read_stage(self, stage):
+        """(launches, total ms) of one timed span kind: 0 full vector attention, 1 anchored block-0 form, 2 sampling front
+        end (input_proj .. merge finalize), 3 query-side Linear / LayerNorm chain  (include/poem_hip.h POEM_PROF_*)."""
+        n, ms = _i(0), _f(0.0)
+        check(lib().poem_profile_read_stage(self.handle, int(stage), ctypes.byref(n), ctypes.byref(ms)), "poem_profile_read_stage")
+        return n.value, ms.value
+
     def profile_read_anchored(self):
         n, ms = _i(0), _f(0.0)
         check(lib().poem_profile_read_anchored(self.handle, ctypes.byref(n), ctypes.byref(ms)), "poem_profile_read_anchored")
@@ -249,6 +263,12 @@ class Engine:
         B, BN = len(views), int(sum(views))
         if tuple(mlvl_feat.shape) != (BN, c.in_channels, c.feat_h, c.feat_w):
             raise RuntimeError(f"mlvl_feat shape {tuple(mlvl_feat.shape)} != {(BN, c.in_channels, c.feat_h, c.feat_w)}")
+        # the C ABI takes raw pointers: a wrong-shaped camera / joint tensor would be an out-of-bounds device read where the
+        # reference raises a shape error
+        for what, t, shape in (("cam_intr", cam_intr, (BN, 3, 3)), ("cam_extr", cam_extr, (BN, 4, 4)),
+                               ("reference_joints", reference_joints, (B, 21, 3))):
+            if tuple(t.shape) != shape:
+                raise RuntimeError(f"{what} shape {tuple(t.shape)} != {shape} (cam_view_num sums to {BN} views, {B} samples)")
         offs = (ctypes.c_int32 * (B + 1))(*np.concatenate([[0], np.cumsum(views)]).astype(np.int32).tolist())
         ws, need = self._ws(B, BN)
         out = torch.empty(c.nblocks, B, c.nquery, 3, dtype=torch.float32, device=self.device)
@@ -401,6 +421,15 @@ def vector_attention_split(query_xyz, src_xyz, anchor_xyz, idx, qg, kg, v, wd1, 
                                             wg1d2_img.data_ptr(), wg2_img.data_ptr(), ptr(scales), ptr(out), B, NQ, C,
                                             stream()), "poem_vector_attention_split")
     return out
+
+def rot6d_to_axis_angle(params):
+    """params (B,106) device fp32 -> (pose_aa (B,48), betas (B,10))."""
+    B = params.shape[0]
+    pose = torch.empty(B, 48, dtype=torch.float32, device=params.device)
+    betas = torch.empty(B, 10, dtype=torch.float32, device=params.device)
+    check(lib().poem_rot6d_to_axis_angle(ptr(params), ptr(pose), ptr(betas), B, stream()), "poem_rot6d_to_axis_angle")
+    return pose, betas
+
 
 def project_sample(x, bps, centre, view_sample, cam_intr, cam_extr, img_shape):
     BN, C, fh, fw = x.shape

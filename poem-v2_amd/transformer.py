@@ -139,5 +139,21 @@ class PtEmbedTRv4(nn.Module):
         out, pose, shape = eng.decoder_forward(query_xyz.float().contiguous(), query_feat.float().contiguous(),
                                                pt_xyz.float().contiguous(), pt_feats.float().contiguous())
         if self.parametric_output:
-            raise NotImplementedError("parametric decoding goes through POEM_Generalized_Head (needs the MANO layer)")
+            # get_parametric_output (pt_metro_transformer.py:139-151 upstream): the last block's coordinates are REPLACED by
+            # the MANO layer's output for the regressed (pose, betas) -- rows 21.. the vertices, rows 0..20 the joints
+            mano = self.mano_layer if self.mano_layer is not None else getattr(self._engine_owner, "mano_layer", None)
+            if mano is None:
+                raise RuntimeError("PARAMETRIC_OUTPUT needs a MANO layer: set_mano_layer(poem_v2_amd.ManoLayer(assets)) "
+                                   "(the MANO assets are licence-gated and never read from disk here)")
+            m = mano(pose, shape)
+            verts, joints = (m.verts, m.joints) if hasattr(m, "verts") else m
+            out[-1, :, 21:] = verts
+            out[-1, :, :21] = joints
         return out, pose, shape
+
+    mano_layer = None
+
+    def set_mano_layer(self, fn):
+        """callable (pose_aa (B,48), betas (B,10)) -> object with .verts (B,778,3) / .joints (B,21,3) or that pair."""
+        self.mano_layer = fn
+        return self

@@ -66,20 +66,24 @@ def live_key_shapes(embed, in_channels=160, nquery=799, nblocks=3, parametric=Fa
     return k
 
 
-def seeded_state_dict(embed, seed=0, gain=1.0, **kw):
+def seeded_state_dict(embed, seed=0, gain=1.0, ln_spread=0.02, **kw):
     """Deterministic, well-conditioned weights: every tensor is drawn from its own CPU generator seeded by
     (seed, crc32(key)), so the reference module and this build can be filled identically without shipping blobs.
 
     Scales follow the reference's initialisers: N(0, 0.02) for every Linear inside a decoder block (BERT v4
     ``init_weights``, applied by point_METRO_block to all sub-modules), U(+-1/sqrt(fan_in)) for head-level
     Linear/Conv, N(0,1) for the query embedding; biases and LayerNorm offsets get small non-zero values so that
-    every term of the arithmetic is exercised.  ``gain`` scales the block weights ("hot" stress variant)."""
+    every term of the arithmetic is exercised.  ``gain`` scales the block weights and ``ln_spread`` the deviation of the
+    LayerNorm gains from 1 ("hot" stress variant: with gain 1 the coordinate update of a block is ~1e-3 normalised units, so
+    attention-path error is attenuated ~1000x before it reaches a vertex and the neighbour sets of blocks 1, 2 are
+    essentially the template's; gain 2.5 makes activations, updates and neighbour changes O(1) -- the conditioning of a
+    trained checkpoint, tests/golden/*_hot.npz)."""
     out = OrderedDict()
     for key, shape in live_key_shapes(embed, **kw).items():
         g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF)
         in_block = key.startswith("transformer.")
         if key.endswith("LayerNorm.weight"):
-            t = 1.0 + 0.02 * torch.randn(shape, generator=g)
+            t = 1.0 + ln_spread * torch.randn(shape, generator=g)
         elif key.endswith("LayerNorm.bias"):
             t = 0.02 * torch.randn(shape, generator=g)
         elif key == "query_feat_embedding.weight":
