@@ -4,6 +4,13 @@
  * points are stream-ordered, allocate nothing, never throw, and return 0 on success or a negative POEM_E_* code.
  * Tensors are fp32, row-major/contiguous; indices are int32.  hipStream_t is passed as void*.
  *
+ * Threading contract.  The operator-level entry points are re-entrant: they keep no host state, and two host threads may
+ * call them concurrently on different streams.  A handle (poem_create) is used by ONE host thread at a time (its side
+ * streams, events and cached index upload are per handle; different handles on different threads -- one thread per GPU --
+ * are independent).  The opt-in split-precision modes carry their per-call context in thread-local host state that only the
+ * call which installed it clears, so a forward on one thread never changes the arithmetic of a forward on another.
+ * poem_last_hip_error is per thread.
+ *
  * What each entry point replaces in the upstream reference (paths relative to the reference root) -- the
  * reference has no FFI of its own (it is pure Python on torch / pytorch3d / transformers), so these are the
  * native calls its hot path makes today:
@@ -41,6 +48,8 @@
  *   poem_warp_affine          cv2.warpAffine + colour jitter + to_tensor / normalize of SimpleTransform2D.__call__
  *                             (lib/utils/transform.py:153-170) and the mirror warp of process_data_item
  *                             (lib/data_wds/multiview_wds.py:112-118) -- the image side of the input pipeline
+ *   poem_rot6d_to_axis_angle  rot6d_to_aa of get_parametric_output (pt_metro_transformer.py:144-146, lib/utils/transform.py:448-466)
+ *   poem_mano_lbs             manotorch ManoLayer.forward (pt_metro_transformer.py:120-124,147-148; ptEmb_head.py:732-736,886-892)
  *   poem_head_forward         POEM_Generalized_Head.forward + PtEmbedTRv4.forward (ptEmb_head.py:825-964,
  *                             lib/models/layers/ptEmb_transformer.py:371-376)
  */

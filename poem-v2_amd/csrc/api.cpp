@@ -1203,9 +1203,12 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   if (c.parametric && (!pose_aa || !betas)) return POEM_E_ARG;
   // SPLIT_F16X3_ALL: every panel GEMM enqueued by this call whose weight lies in this handle's packed arena takes the split
   // image at the same offset (gemm.hip); cleared on every way out
+  // (the context is thread-local host state and only a call that installed it clears it: an fp32 forward never touches it)
   struct SplitCtx {
+    bool set = false;
     explicit SplitCtx(poem_handle_t hh) {
       if (hh->precision == POEM_PRECISION_SPLIT_F16X3_ALL) {
+        set = true;
         poem_gemm_split_context(hh->packed_base, hh->packed_size, hh->gemm_split, hh->gemm_scales);
         poem_cross_attention_split(1);
         const int dh = hh->cfg.embed / hh->cfg.heads;
@@ -1213,6 +1216,7 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
       }
     }
     ~SplitCtx() {
+      if (!set) return;
       poem_gemm_split_context(nullptr, 0, nullptr, nullptr);
       poem_cross_attention_split(0);
       poem_gemm_split_images(0);

@@ -629,7 +629,7 @@ static int poem_attn_cus() {
 
 // opt-in split precision for the calls enqueued while it is set (api.cpp: around poem_head_forward in SPLIT_F16X3_ALL mode,
 // and by the operator-level entry point); head dims 32 and 64 only, the others keep the exact kernels
-static int g_xattn_split = 0;      // 1: split from fp32 images, 2: the images are already split (gemm.hip split output modes)
+static thread_local int g_xattn_split = 0;      // per host thread, like gemm.hip's split context.  1: split from fp32 images, 2: the images are already split (gemm.hip split output modes)
 extern "C" void poem_cross_attention_split(int on) { g_xattn_split = on; }
 
 // q (B, NQ, ldq) row-major; kimg / vimg: fragment images of the (B*NK, C) key / value matrices
@@ -674,7 +674,11 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
   hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
   if (g_xattn_split && (dh == 32 || dh == 64)) {
+#ifdef POEM_LAB
     static const int w3 = getenv("POEM_XS_W") ? atoi(getenv("POEM_XS_W")) : 2;      // lab A/B: waves per SIMD, head dim 64
+#else
+    constexpr int w3 = 2;
+#endif
     if (g_xattn_split == 2) { if (dh == 32) { POEM_XSPLIT(32, 3, true); } else if (w3 == 3) { POEM_XSPLIT(64, 3, true); } else { POEM_XSPLIT(64, 2, true); } }
     else { if (dh == 32) { POEM_XSPLIT(32, 3, false); } else { POEM_XSPLIT(64, 2, false); } }
     return hipGetLastError();

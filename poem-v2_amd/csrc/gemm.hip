@@ -74,9 +74,11 @@ __device__ __forceinline__ void split_pair(const float4 a, const float4 b, h8& h
 
 // The split arena of the handle whose forward is being enqueued (api.cpp sets / clears it around poem_head_forward):
 // fp32 image pointers inside [packed, packed + bytes) are redirected to the split image at the same offset; the tile
-// scales sit at one float per 256 bytes of image.  Host-side state, single enqueueing thread (as the reference).
-static struct { const char* packed; size_t bytes; const char* split; const float* scales; } g_split_ctx = {nullptr, 0, nullptr, nullptr};
-static struct { const void* img; const float* scales; } g_explicit_split = {nullptr, nullptr};
+// scales sit at one float per 256 bytes of image.  Per-THREAD host state: a forward is enqueued by one host thread from start
+// to end, so the context a call installs is seen by exactly the launches that call makes -- forwards of other handles on
+// other host threads (one thread per GPU, say) neither see nor clear it (include/poem_hip.h, threading contract).
+static thread_local struct { const char* packed; size_t bytes; const char* split; const float* scales; } g_split_ctx = {nullptr, 0, nullptr, nullptr};
+static thread_local struct { const void* img; const float* scales; } g_explicit_split = {nullptr, nullptr};
 extern "C" void poem_gemm_split_explicit(const void* img, const float* scales) { g_explicit_split = {img, scales}; }
 extern "C" void poem_gemm_split_context(const void* packed, size_t bytes, const void* split, const float* scales) {
   g_split_ctx = {(const char*)packed, bytes, (const char*)split, scales};
@@ -84,7 +86,7 @@ extern "C" void poem_gemm_split_context(const void* packed, size_t bytes, const 
 
 // Will a panel GEMM with this weight pointer run the split variant (and therefore write SPLIT K / V images)?  Same rule as
 // the dispatch in launch_gemm_split_impl; api.cpp tells the cross attention which image format it gets.
-static int g_split_images = 0;
+static thread_local int g_split_images = 0;
 extern "C" void poem_gemm_split_images(int on) { g_split_images = on; }
 extern "C" int poem_gemm_split_applies(const void* Wp, int M, int ldx, int K) {
   const bool in_arena = g_split_ctx.packed && (const char*)Wp >= g_split_ctx.packed &&
@@ -658,7 +660,11 @@ static hipError_t launch_gemm_split_impl(const float* X, int ldx, const void* Wp
   if (Wsplit && K % 16 == 0 && (unsigned long long)M * ldx * 4ull + 64ull < (1ull << 32)) {
     // 32-row wave tiles always: the fp32->f16 split of the X fragment is serial work in front of each chunk's MFMAs,
     // and a 64-row tile doubles it per wave (measured: 131072 x 1536 x 256 0.47 vs 0.64 ms, 1M x 256 x 384 1.33 vs 2.5 ms)
+#ifdef POEM_LAB
     static const int force_mt = getenv("POEM_GS_MT") ? atoi(getenv("POEM_GS_MT")) : 1;       // lab A/B: 2 = 64-row tiles
+#else
+    constexpr int force_mt = 1;
+#endif
     const bool mt2 = force_mt == 2;
     (void)mt2_default;
 #define POEM_PANEL_S(NTV)                                                                                                \

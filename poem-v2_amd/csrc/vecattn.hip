@@ -580,7 +580,10 @@ extern "C" hipError_t poem_launch_vector_attention(const float* query_xyz, const
                                                    int ldq, int ldk, int ldv, int composed, hipStream_t s) {
   VecAttnArgs a{query_xyz, src_xyz, anchor_xyz, idx, shared_idx, q, k, v, nsrc, wd1, bd1, (const float4*)wd2, bd2,
                 (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q, ldq, ldk, ldv, 0, composed, nullptr, nullptr};
-  if (const char* e = getenv("POEM_VA_STAGGER")) a.stagger = atoi(e);
+#ifdef POEM_LAB
+  static const int stagger_env = getenv("POEM_VA_STAGGER") ? atoi(getenv("POEM_VA_STAGGER")) : 0;   // lab only, read once
+  a.stagger = stagger_env;
+#endif
 #ifdef POEM_VA_DBG
   if (C == 256)
     if (const char* e = getenv("POEM_VA_CFG")) {

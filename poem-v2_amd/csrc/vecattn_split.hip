@@ -427,7 +427,9 @@ static hipError_t launch_vs(const VecAttnSplitArgs& a, hipStream_t s) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     slots = cus * ((size_t)2 * lds <= 160 * 1024 ? 2 : 1);
+#ifdef POEM_LAB
     if (const char* e = getenv("POEM_VS_PERSIST")) if (atoi(e) == 0) slots = 1 << 30;
+#endif
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long long>((long long)a.B * groups, slots)), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
@@ -445,7 +447,11 @@ extern "C" hipError_t poem_launch_vector_attention_split(const float* query_xyz,
   switch (C) {
     case 128: return launch_vs<128, 4, 4, 2>(a, s);
     case 256: {
+#ifdef POEM_LAB
       static const int cfg = getenv("POEM_VS_CFG") ? atoi(getenv("POEM_VS_CFG")) : 0;      // lab A/B of the block shape
+#else
+      constexpr int cfg = 0;
+#endif
       if (cfg == 1) return launch_vs<256, 4, 8, 2>(a, s);     // one 8-wave block per CU, 4 queries share a weight stream
       if (cfg == 2) return launch_vs<256, 2, 8, 4>(a, s);     // two 8-wave blocks per CU (4 waves per SIMD)
       return launch_vs<256, 2, 4, 2>(a, s);

@@ -579,6 +579,30 @@ def test_full_size_config_c5_ragged_2_to_10_views_batch_64():
     _full_size_properties(dict(embed=256, nsample=4096, views=views, seed=51, parametric=False), n_oracle=2)
 
 
+def test_bench_gpus_2_launches_two_ranks_or_refuses():
+    """bench.py --gpus 2 without a launcher: on a box with one GPU it refuses (no line claiming 2 GPUs); with
+    POEM_SINGLE_DEVICE=1 it rehearses the 2-rank code path itself (torch.distributed.run, gloo, both ranks on cuda:0) and the
+    line reports the ranks that actually joined and the process group's own world size."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "POEM_SINGLE_DEVICE", "POEM_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--rotate", "2", "--cpu-samples", "0", "--no-e2e", "--no-extra-configs"]
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode != 0 and "refusing" in (out.stderr + out.stdout)
+        env["POEM_SINGLE_DEVICE"] = "1"
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["config"]["ranks_joined"] == 2 and "world_size=2" in res["config"]["process_group"]
+    assert res["value"] > 0 and res["scaling"] == "weak"
+
+
 def test_eval_single_script_runs_the_path(tmp_path):
     """The eval_single.py counterpart end to end on the GPU (tiny synthetic epoch), cfg written back as upstream does."""
     import json

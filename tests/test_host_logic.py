@@ -264,3 +264,16 @@ def test_internal_launcher_declarations_match_their_definitions():
     spec.loader.exec_module(mod)
     decls, bad = mod.main()
     assert len(decls) >= 30 and not bad, bad
+
+
+def test_bench_refuses_to_report_n_gpus_from_fewer_devices():
+    """``python bench.py --gpus N`` without a launcher starts its own ranks; with fewer than N devices it must fail loudly,
+    never print a line that claims N GPUs (here: no GPU at all)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "POEM_SINGLE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0 and "refusing" in (out.stderr + out.stdout), (out.stdout[-500:], out.stderr[-500:])
+    assert "\"n_gpus\"" not in out.stdout
