@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="0: issue every kernel on one stream (A/B of the side streams)")
     ap.add_argument("--anchor-tables", type=int, default=1,
                     help="0: block 0's vector attentions in the per-sample form (A/B of poem_set_anchor_tables)")
+    ap.add_argument("--chains", type=int, default=1,
+                    help="0: one launch per query-side operator instead of the row-tile chain kernels (A/B of poem_set_chains)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short legs for the other BASELINE per-GPU loads (c3 medium_MANO, c4 large x 10 views x 16, "
                          "c5 ragged 2-10 views x 64)")
@@ -311,6 +313,10 @@ def main():
                 step()
         if not args.anchor_tables:
             head.set_anchor_tables(False)
+            for _ in range(args.warmup):
+                step()
+        if not args.chains:
+            head.set_chains(False)
             for _ in range(args.warmup):
                 step()
         if not args.overlap:

@@ -130,6 +130,10 @@ int poem_decoder_forward(poem_handle_t h, const float* query_xyz, const float* q
  * internal side streams ordered against `stream` by events; everything is joined back before the call returns its
  * last launch, so the caller only ever synchronises its own stream.  0 = issue everything on `stream` in order. */
 int poem_set_overlap(poem_handle_t h, int enable);
+/* Query-side row-tile chains (csrc/chain.hip), default ON for embed in {128, 256, 512} in fp32 mode: the Linears, residual
+ * adds and LayerNorms between the attention kernels of a decoder block (pt_metro_transformer.py:56-91,34-40) run as four chain
+ * launches per block with the activations resident in LDS; 0 = one launch per operator (the round-1 sequence; A/B and tests). */
+int poem_set_chains(poem_handle_t h, int enable);
 /* Block-0 anchor tables of poem_head_forward (default on, fp32 mode).  In the first decoder block every query's
  * neighbours are the 32 fixed anchors (anchor_points, lib/models/bricks/point_transformers.py:10-32) and every sample's
  * query coordinates are the hand template (lib/models/heads/ptEmb_head.py:886-894,935: ((c + t) - c) / r, i.e. t / r up

@@ -1,6 +1,7 @@
 // C ABI of libpoem_hip.so (see include/poem_hip.h): handle, weight packing, workspace plan and the launch sequence
 // of the whole POEM_Generalized_Head + PtEmbedTRv4 path.  Host code only; all kernels live in the .hip files.
 #include "../../include/poem_hip.h"
+#include "chain.h"
 
 #include <hip/hip_runtime.h>
 
@@ -40,6 +41,10 @@ hipError_t poem_launch_cross_attention_img(const float* q, int ldq, const void* 
                                            int NQ, int NK, int C, int heads, float* scratch, hipStream_t s);
 hipError_t poem_launch_gemm_segs(const float* X, int ldx, const void* Wp, const float* bias, int M, int K, int act,
                                  int seg_cols, int nsegs, float* const* outs, const int* modes, hipStream_t s);
+hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, int q_batch_rows, const void* kimg, const void* vimg,
+                                            float* ctx, int B, int NQ, int NK, int C, int heads, float* scratch, hipStream_t s);
+int poem_chain_supported(int C);
+hipError_t poem_launch_chain(const ChainArgs* a, int C, hipStream_t s);
 hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS, hipStream_t s);
 hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                         const int* idx, int shared_idx, const float* q, const float* k, const float* v,
@@ -246,6 +251,9 @@ struct poem_handle_s {
   // of the coordinate); same distance from the reference (tools/lab/hoist_probe.py).  poem_decoder_forward, whose
   // query coordinates are the caller's, never uses it.
   bool anchor_tables = true;
+  // Query-side row-tile chains (chain.hip): the Linears / residuals / LayerNorms between the attention kernels of a block
+  // run as four chain launches with the activations in LDS instead of ~14 operator launches (fp32 mode, C in {128,256,512}).
+  bool chains = true;
   hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {};
   bool overlap = true;
   // Per-view index arrays (view_offsets | view_sample | pe_index) live in handle-owned device memory and are re-uploaded
@@ -484,17 +492,53 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       const int rc = bps_side(i);
       if (rc != POEM_OK) return rc;
     }
+    const bool chain = h->chains && h->precision == POEM_PRECISION_FP32 && poem_chain_supported(C) != 0;
     // F2: qe = embedding(feats) | query projection of the first attention (composed with the embedding)
+    const float* hidden = p.qeqp;      // residual of the first attention: qe
+    int ldh = 2 * C, hidden_mod = 0, q_batch = Q;
+    const float* q0 = p.qeqp + C;
     if (tables && i == 0) {
-      // every sample's block-0 query features are the learned embedding table: F2 on its Q rows, then one copy per sample
+      // every sample's block-0 query features are the learned embedding table: F2 on its Q rows, once
       HIPCHK(poem_launch_gemm_split(h->R(T_QEMB), C, h->fused[i].w[1], h->fused[i].b[1], nullptr, 0, p.qeqp0, 2 * C, Q,
                                     2 * C, C, POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, s));
-      HIPCHK(poem_launch_broadcast(p.qeqp0, p.qeqp, (long)Q * 2 * C, B, s));
-    } else
-    HIPCHK(poem_launch_gemm_split(feats, C, h->fused[i].w[1], h->fused[i].b[1], nullptr, 0, p.qeqp, 2 * C, BQ, 2 * C, C,
-                                  POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, s));
-    const float* hidden = p.qeqp;
-    int ldh = 2 * C;
+      if (chain) {       // ... and read by every sample in place: queries with batch stride 0, residual rows modulo Q
+        hidden = p.qeqp0; hidden_mod = Q; q0 = p.qeqp0 + C; q_batch = 0;
+      } else {
+        HIPCHK(poem_launch_broadcast(p.qeqp0, p.qeqp, (long)Q * 2 * C, B, s));
+      }
+    } else if (!(chain && i > 0)) {    // (chain mode: block i-1's last chain already wrote p.qeqp)
+      HIPCHK(poem_launch_gemm_split(feats, C, h->fused[i].w[1], h->fused[i].b[1], nullptr, 0, p.qeqp, 2 * C, BQ, 2 * C, C,
+                                    POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, s));
+    }
+    const int vsb = bb + B_VS;
+    if (chain) {
+      const int a1 = bb + B_A1, a2 = bb + B_A2;
+      if (ov) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
+      HIPCHK(poem_launch_cross_attention_imgq(q0, 2 * C, q_batch, p.y1[i], p.y1[i] + (size_t)BS * C, p.ctx, B, Q, S, C, c.heads,
+                                              p.attn_scratch, s));
+      ChainArgs ca{};
+      ca.kind = 0; ca.M = BQ; ca.x = p.ctx; ca.ldx = C;
+      ca.w1 = (const float4*)h->P(a1 + 6); ca.b1 = h->R(a1 + 7); ca.res = hidden; ca.ldres = ldh; ca.res_mod = hidden_mod;
+      ca.ln_g = h->R(a1 + 8); ca.ln_b = h->R(a1 + 9); ca.eps = c.ln_eps; ca.y1 = p.h_attn; ca.ldy1 = C;
+      ca.w2 = (const float4*)h->P(a2 + 0); ca.b2 = h->R(a2 + 1); ca.n2 = 1; ca.y2 = p.qp; ca.ldy2 = C;
+      HIPCHK(poem_launch_chain(&ca, C, s));
+      HIPCHK(poem_launch_cross_attention_imgq(p.qp, C, Q, p.y1[i] + (size_t)2 * BS * C, p.y1[i] + (size_t)3 * BS * C, p.ctx, B, Q,
+                                              S, C, c.heads, p.attn_scratch, s));
+      ChainArgs cb{};
+      cb.kind = 0; cb.M = BQ; cb.x = p.ctx; cb.ldx = C;
+      cb.w1 = (const float4*)h->P(a2 + 6); cb.b1 = h->R(a2 + 7); cb.res = p.h_attn; cb.ldres = C; cb.res_mod = 0;
+      cb.ln_g = h->R(a2 + 8); cb.ln_b = h->R(a2 + 9); cb.eps = c.ln_eps; cb.y1 = p.h_cross[i]; cb.ldy1 = C;
+      // F3: (w_qs | w_ks | w_vs) o fc1 on h_cross; block 0 on the tables needs qg for every row and (kg | v) for the anchor rows only
+      cb.w2 = (const float4*)h->fused[i].w[2]; cb.b2 = h->fused[i].b[2]; cb.n2 = (tables && i == 0) ? 1 : 3; cb.y2 = p.y3; cb.ldy2 = 3 * C;
+      HIPCHK(poem_launch_chain(&cb, C, s));
+      hidden = p.h_cross[i];
+      ldh = C;
+      if (tables && i == 0) {
+        HIPCHK(poem_launch_gather_anchor_rows(hidden, C, h->anchor_idx, Q, p.anch_x[0], B, C, nullptr, s));
+        HIPCHK(poem_launch_gemm(p.anch_x[0], C, (const float*)h->fused[i].w[2] + (size_t)C * C, h->fused[i].b[2] + C,
+                                nullptr, 0, p.anch_kv[0], 2 * C, B * 32, 2 * C, C, POEM_ACT_NONE, s));
+      }
+    } else {
     for (int a = 0; a < 2; ++a) {
       const int ab = bb + (a == 0 ? B_A1 : B_A2);
       float* hout = a == 0 ? p.h_attn : p.h_cross[i];
@@ -516,7 +560,6 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       ldh = C;
     }
     // vector self-attention over the queries
-    const int vsb = bb + B_VS;
     // F3: (w_qs | w_ks | w_vs) o fc1 on h_cross
     if (tables && i == 0) {
       // block 0 gathers keys / values from the 32 anchor rows only: qg for every row, (kg | v) for the anchor rows
@@ -528,6 +571,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     } else
     HIPCHK(poem_launch_gemm_split(hidden, C, h->fused[i].w[2], h->fused[i].b[2], nullptr, 0, p.y3, 3 * C, BQ, 3 * C, C,
                                   POEM_ACT_NONE, 3 * C, POEM_ACT_NONE, s));
+    }   // !chain
     if (ov && i > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
     {
     PROF_START();
@@ -546,10 +590,19 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
                                         h->P(vsb + 10), h->R(vsb + 11), p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, 1, s));
     PROF_STOP(tables && i == 0 ? 1 : 0);
     }
-    GEMM(p.rs, C, vsb + 2, vsb + 3, hidden, C, p.f_self[i], C, BQ, C, C, POEM_ACT_NONE);
     // vector cross-attention over the basis points
     const int vcb = bb + B_VC;
+    if (chain) {       // f_self = fc2(r) + h_cross ; qc = (W_g1 w_qs) f_self + (W_g1 b_d2 + b_g1)
+      ChainArgs cc{};
+      cc.kind = 1; cc.M = BQ; cc.x = p.rs; cc.ldx = C;
+      cc.w1 = (const float4*)h->P(vsb + 2); cc.b1 = h->R(vsb + 3); cc.res = hidden; cc.ldres = C; cc.res_mod = 0;
+      cc.y1 = p.f_self[i]; cc.ldy1 = C;
+      cc.w2 = (const float4*)h->fused[i].w[4]; cc.b2 = h->fused[i].b[4]; cc.n2 = 1; cc.y2 = p.qc; cc.ldy2 = C;
+      HIPCHK(poem_launch_chain(&cc, C, s));
+    } else {
+    GEMM(p.rs, C, vsb + 2, vsb + 3, hidden, C, p.f_self[i], C, BQ, C, C, POEM_ACT_NONE);
     HIPCHK(poem_launch_gemm(p.f_self[i], C, h->fused[i].w[4], h->fused[i].b[4], nullptr, 0, p.qc, C, BQ, C, C, POEM_ACT_NONE, s));
+    }
     {
     PROF_START();
     if (h->precision != POEM_PRECISION_FP32) {
@@ -567,13 +620,37 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
                                         h->P(vcb + 10), h->R(vcb + 11), p.rc, B, Q, C, C, C, C, 1, s));
     PROF_STOP(tables && i == 0 ? 1 : 0);
     }
-    GEMM(p.rc, C, vcb + 2, vcb + 3, p.f_self[i], C, p.f_cross[i], C, BQ, C, C, POEM_ACT_NONE);
     // xyz update
     // F4: reg_branch.0 (relu) | intermediate.dense (gelu) share f_cross
     // The last block's feed-forward output (intermediate -> output -> LayerNorm) feeds nothing: PtEmbedTRv4.forward returns
     // the coordinate stack only (ptEmb_transformer.py:115-121,371-376 upstream; the reference evaluates it and drops it).  It
     // is computed only when something reads it: the parametric tail (medium_MANO) or the debug taps.
     const bool feats_dead = i == c.nblocks - 1 && !c.parametric && !h->taps;
+    if (chain) {
+      // f_cross = fc2(r) + f_self ; reg_branch -> xyz_{i+1} ; feed forward + LayerNorm -> feats ; next block's F2
+      ChainArgs cd{};
+      cd.kind = 2; cd.M = BQ; cd.x = p.rc; cd.ldx = C;
+      cd.w1 = (const float4*)h->P(vcb + 2); cd.b1 = h->R(vcb + 3); cd.res = p.f_self[i]; cd.ldres = C; cd.res_mod = 0;
+      cd.y1 = p.f_cross[i]; cd.ldy1 = C; cd.eps = c.ln_eps;
+      cd.wf4 = (const float4*)h->fused[i].w[3]; cd.bf4 = h->fused[i].b[3];
+      cd.wreg2 = h->R(bb + B_REG2_W); cd.breg2 = h->R(bb + B_REG2_B); cd.xyz_in = xyz; cd.xyz_out = p.xyz[i + 1];
+      cd.ffn = feats_dead ? 0 : 1;
+      cd.wout = (const float4*)h->P(bb + B_OUT_W); cd.bout = h->R(bb + B_OUT_B);
+      cd.ln2_g = h->R(bb + B_LN_W); cd.ln2_b = h->R(bb + B_LN_B); cd.y3 = p.feats[i]; cd.ldy3 = C;
+      if (i + 1 < c.nblocks) {
+        cd.w2 = (const float4*)h->fused[i + 1].w[1]; cd.b2 = h->fused[i + 1].b[1]; cd.n2 = 2; cd.y2 = p.qeqp; cd.ldy2 = 2 * C;
+      }
+      HIPCHK(poem_launch_chain(&cd, C, s));
+      if (feats_dead) break;
+      feats = p.feats[i];
+      if (c.parametric && i == c.nblocks - 1) {
+        HIPCHK(poem_launch_q3_flatten(feats, h->R(bb + B_FLAT_W), h->R(bb + B_FLAT_B), p.q3t, B, Q, C, s));
+        HIPCHK(poem_launch_narrow_linear(p.q3t, C, h->R(bb + B_MANO_W), h->R(bb + B_MANO_B), nullptr, p.par, B, C, 106, s));
+        HIPCHK(poem_launch_rot6d_to_aa(p.par, pose_aa, betas, B, s));
+      }
+      continue;
+    }
+    GEMM(p.rc, C, vcb + 2, vcb + 3, p.f_self[i], C, p.f_cross[i], C, BQ, C, C, POEM_ACT_NONE);
     if (feats_dead) {
       HIPCHK(poem_launch_gemm(p.f_cross[i], C, h->fused[i].w[3], h->fused[i].b[3], nullptr, 0, p.y4, 5 * C, BQ, C, C,
                               POEM_ACT_RELU, s));
@@ -879,6 +956,12 @@ void poem_destroy(poem_handle_t h) {
 int poem_set_overlap(poem_handle_t h, int enable) {
   if (!h) return POEM_E_ARG;
   h->overlap = enable != 0;
+  return POEM_OK;
+}
+
+int poem_set_chains(poem_handle_t h, int enable) {
+  if (!h) return POEM_E_ARG;
+  h->chains = enable != 0;
   return POEM_OK;
 }
 

@@ -101,7 +101,7 @@ __device__ long long xattn_ph[8];
 #endif
 
 template <int DH, int W>
-__global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restrict__ q, int ldq,
+__global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restrict__ q, int ldq, int qbr,
                                                            const float4* __restrict__ kimg,
                                                            const float4* __restrict__ vimg,
                                                            float4* __restrict__ part_o, float2* __restrict__ part_ml,
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
     // Q fragment: lane (query r, half h) holds Q[r][8kc + 4h + t]
     float4 qf[KC];
     {
-      const float* qp = q + ((size_t)b * NQ + qrow) * ldq + head * DH + 4 * h;
+      const float* qp = q + ((size_t)b * qbr + qrow) * ldq + head * DH + 4 * h;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) qf[kc] = *reinterpret_cast<const float4*>(qp + 8 * kc);
     }
@@ -284,7 +284,7 @@ __device__ __forceinline__ f32x16 xmfma16(xh8 a, xh8 b, f32x16 c) { return __bui
 // PRE: the images already hold hi | lo f16 operands (written by the split projection GEMM, gemm.hip output modes 1 / 2 in
 // the split variant): fragment 2c = the hi halfs of chunk c, fragment 2c+1 = the lo halfs -- no conversion of K / V here.
 template <int DH, int W, bool PRE>
-__global__ __launch_bounds__(256 * W, W) void xattn_split_kernel(const float* __restrict__ q, int ldq,
+__global__ __launch_bounds__(256 * W, W) void xattn_split_kernel(const float* __restrict__ q, int ldq, int qbr,
                                                                  const float4* __restrict__ kimg,
                                                                  const float4* __restrict__ vimg,
                                                                  float4* __restrict__ part_o, float2* __restrict__ part_ml,
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_split_kernel(const float* __
     const int qrow = min(qt * 32 + r, NQ - 1);
     xh8 qh[KC16], ql[KC16];
     {
-      const float* qp = q + ((size_t)b * NQ + qrow) * ldq + head * DH + 4 * h;
+      const float* qp = q + ((size_t)b * qbr + qrow) * ldq + head * DH + 4 * h;
 #pragma unroll
       for (int c = 0; c < KC16; ++c)
         xsplit8(*reinterpret_cast<const float4*>(qp + 16 * c), *reinterpret_cast<const float4*>(qp + 16 * c + 8), qh[c], ql[c]);
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_split_kernel(const float* __
 // group n issue, group n+1 (the next tile's first K group after the last V pair) is in flight into the other slot.
 // NG is even, so the slot of every group is a compile-time constant.  Same items, partials and combine as above.
 template <int DH, int W>
-__global__ __launch_bounds__(256 * W, W) void xattn_stream_kernel(const float* __restrict__ q, int ldq,
+__global__ __launch_bounds__(256 * W, W) void xattn_stream_kernel(const float* __restrict__ q, int ldq, int qbr,
                                                                   const float4* __restrict__ kimg,
                                                                   const float4* __restrict__ vimg,
                                                                   float4* __restrict__ part_o,
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_stream_kernel(const float* _
     const int qrow = min(qt * 32 + r, NQ - 1);
     float4 qf[KC];
     {
-      const float* qp = q + ((size_t)b * NQ + qrow) * ldq + head * DH + 4 * h;
+      const float* qp = q + ((size_t)b * qbr + qrow) * ldq + head * DH + 4 * h;
 #pragma unroll
       for (int kc = 0; kc < KC; ++kc) qf[kc] = *reinterpret_cast<const float4*>(qp + 8 * kc);
     }
@@ -633,9 +633,18 @@ static thread_local int g_xattn_split = 0;      // per host thread, like gemm.hi
 extern "C" void poem_cross_attention_split(int on) { g_xattn_split = on; }
 
 // q (B, NQ, ldq) row-major; kimg / vimg: fragment images of the (B*NK, C) key / value matrices
+// q_batch_rows: rows between consecutive samples' queries (NQ; 0 = every sample reads the same NQ query rows)
+extern "C" hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, int q_batch_rows, const void* kimg,
+                                                       const void* vimg, float* ctx, int B, int NQ, int NK, int C,
+                                                       int heads, float* scratch, hipStream_t s);
 extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, const void* kimg, const void* vimg,
                                                       float* ctx, int B, int NQ, int NK, int C, int heads,
                                                       float* scratch, hipStream_t s) {
+  return poem_launch_cross_attention_imgq(q, ldq, NQ, kimg, vimg, ctx, B, NQ, NK, C, heads, scratch, s);
+}
+extern "C" hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, int qbr, const void* kimg,
+                                                       const void* vimg, float* ctx, int B, int NQ, int NK, int C,
+                                                       int heads, float* scratch, hipStream_t s) {
   const int dh = C / heads;
   if (NK % 32 || C % 32 || (size_t)B * NK * C * 4 >= (1ull << 31)) return hipErrorInvalidValue;
   const int nqt = (NQ + 31) / 32;
@@ -652,12 +661,12 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
   const int grid = (int)std::min<size_t>((size_t)cus, (items + 3) / 4);
   const int waves = B * heads * nqt;
 #define POEM_XATTN(D, WV)                                                                                         \
-  hipLaunchKernelGGL((xattn_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, (const float4*)kimg,        \
+  hipLaunchKernelGGL((xattn_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, qbr, (const float4*)kimg,        \
                      (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map, prio_rot); \
   hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
 #define POEM_XSTREAM(D, WV)                                                                                        \
-  hipLaunchKernelGGL((xattn_stream_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, (const float4*)kimg,   \
+  hipLaunchKernelGGL((xattn_stream_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, qbr, (const float4*)kimg,   \
                      (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map);           \
   hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
@@ -669,7 +678,7 @@ extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, c
   if (const char* e = getenv("POEM_ATTN_MAP")) map = atoi(e);
 #endif
 #define POEM_XSPLIT(D, WV, PREV)                                                                                         \
-  hipLaunchKernelGGL((xattn_split_kernel<D, WV, PREV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, (const float4*)kimg, \
+  hipLaunchKernelGGL((xattn_split_kernel<D, WV, PREV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, qbr, (const float4*)kimg, \
                      (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw);                \
   hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)

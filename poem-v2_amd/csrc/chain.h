@@ -1,0 +1,23 @@
+// Arguments of the query-side row-tile chain kernels (chain.hip); shared with the host sequence in api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct ChainArgs {
+  int kind;                  // 0 = A, 1 = C, 2 = D
+  int M;                     // rows
+  const float* x; int ldx;   // chain input (M, C)
+  const float4* w1; const float* b1;            // first Linear (C x C packed)
+  const float* res; int ldres; int res_mod;     // residual rows (row % res_mod when res_mod > 0: one copy shared by all samples)
+  const float* ln_g; const float* ln_b; float eps;   // kind A: LayerNorm after the first Linear
+  float* y1; int ldy1;       // result of the first stage (h / f), row-major
+  const float4* w2; const float* b2; int n2;    // trailing Linear: n2 C-wide column passes (0 = none), packed (n2*C x C)
+  float* y2; int ldy2;
+  // kind D
+  const float4* wf4; const float* bf4;          // packed (5C x C): reg_branch.0 | intermediate.dense ; bias (5C)
+  const float* wreg2; const float* breg2;       // (3, C) raw, (3)
+  const float* xyz_in; float* xyz_out;          // (M, 3)
+  const float4* wout; const float* bout;        // packed (C x 4C)
+  const float* ln2_g; const float* ln2_b;
+  float* y3; int ldy3;       // feats
+  int ffn;                   // 0: stop after the coordinate update (last block, nothing reads the feed-forward output)
+};

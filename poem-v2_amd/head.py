@@ -107,6 +107,8 @@ class POEM_Generalized_Head(nn.Module):
                 self._engine.set_precision(self._precision)
             if not self._anchor_tables:
                 self._engine.set_anchor_tables(False)
+            if not self._chains:
+                self._engine.set_chains(False)
         return self._engine
 
     _anchor_tables = True
@@ -118,6 +120,16 @@ class POEM_Generalized_Head(nn.Module):
         self._anchor_tables = bool(flag)
         if self._engine is not None:
             self._engine.set_anchor_tables(flag)
+        return self
+
+    _chains = True
+
+    def set_chains(self, flag=True):
+        """Query-side Linears / residuals / LayerNorms of a block as LDS-resident row-tile chains (default) or one launch per
+        operator (include/poem_hip.h poem_set_chains)."""
+        self._chains = bool(flag)
+        if self._engine is not None:
+            self._engine.set_chains(flag)
         return self
 
     _precision = "fp32"
