@@ -262,6 +262,8 @@ def main():
                     help="0: block 0's vector attentions in the per-sample form (A/B of poem_set_anchor_tables)")
     ap.add_argument("--chains", type=int, default=1,
                     help="0: one launch per query-side operator instead of the row-tile chain kernels (A/B of poem_set_chains)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="poem_set_option switches for A/B runs, e.g. --option knn_early=0")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short legs for the other BASELINE per-GPU loads (c3 medium_MANO, c4 large x 10 views x 16, "
                          "c5 ragged 2-10 views x 64)")
@@ -313,6 +315,12 @@ def main():
                 step()
         if not args.anchor_tables:
             head.set_anchor_tables(False)
+            for _ in range(args.warmup):
+                step()
+        for kv in args.option:
+            k_, v_ = kv.split("=")
+            eng.set_option(k_, int(v_))
+        if args.option:
             for _ in range(args.warmup):
                 step()
         if not args.chains:

@@ -134,6 +134,10 @@ int poem_set_overlap(poem_handle_t h, int enable);
  * adds and LayerNorms between the attention kernels of a decoder block (pt_metro_transformer.py:56-91,34-40) run as four chain
  * launches per block with the activations resident in LDS; 0 = one launch per operator (the round-1 sequence; A/B and tests). */
 int poem_set_chains(poem_handle_t h, int enable);
+/* Scheduling switches by name, for A/B measurements (results are unaffected): "overlap", "anchor_tables", "chains" as the
+ * setters above; "knn_early" (default 1): in chain mode the neighbour searches of block i+1 are issued right behind block i's
+ * coordinate update instead of at the top of block i+1.  Unknown names return POEM_E_ARG. */
+int poem_set_option(poem_handle_t h, const char* name, int value);
 /* Block-0 anchor tables of poem_head_forward (default on, fp32 mode).  In the first decoder block every query's
  * neighbours are the 32 fixed anchors (anchor_points, lib/models/bricks/point_transformers.py:10-32) and every sample's
  * query coordinates are the hand template (lib/models/heads/ptEmb_head.py:886-894,935: ((c + t) - c) / r, i.e. t / r up

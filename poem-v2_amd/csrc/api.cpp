@@ -254,6 +254,7 @@ struct poem_handle_s {
   // Query-side row-tile chains (chain.hip): the Linears / residuals / LayerNorms between the attention kernels of a block
   // run as four chain launches with the activations in LDS instead of ~14 operator launches (fp32 mode, C in {128,256,512}).
   bool chains = true;
+  bool knn_early = true;     // chain mode: issue block i+1's neighbour searches right behind block i's coordinate update
   hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {};
   bool overlap = true;
   // Per-view index arrays (view_offsets | view_sample | pe_index) live in handle-owned device memory and are re-uploaded
@@ -465,6 +466,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     }
   }
   const float* feats = feats_in;
+  bool knn_issued[9] = {};
   for (int i = 0; i < c.nblocks; ++i) {
     const int bb = h->block_base(i);
     const float* xyz = p.xyz[i];
@@ -474,6 +476,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     const float* anchor = h->anchor;
     int shared = 1;
     if (i > 0) {
+      if (!knn_issued[i]) {   // (chain mode issues them right behind the coordinate update of block i-1)
       if (ov) {
         HIPCHK(hipEventRecord(h->ev_xyz[i], s));          // xyz_i is final here (written at the end of block i-1)
         HIPCHK(hipStreamWaitEvent(sk, h->ev_xyz[i], 0));
@@ -483,6 +486,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       HIPCHK(poem_launch_knn(xyz, pt_xyz, p.idx_cross[i], B, Q, S, sk));
       HIPCHK(poem_launch_knn(xyz, xyz, p.idx_self[i], B, Q, Q, sk));
       if (ov) HIPCHK(hipEventRecord(h->ev_knn[i], sk));
+      }
       idx_s = p.idx_self[i];
       idx_c = p.idx_cross[i];
       anchor = nullptr;
@@ -634,14 +638,25 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       cd.y1 = p.f_cross[i]; cd.ldy1 = C; cd.eps = c.ln_eps;
       cd.wf4 = (const float4*)h->fused[i].w[3]; cd.bf4 = h->fused[i].b[3];
       cd.wreg2 = h->R(bb + B_REG2_W); cd.breg2 = h->R(bb + B_REG2_B); cd.xyz_in = xyz; cd.xyz_out = p.xyz[i + 1];
-      cd.ffn = feats_dead ? 0 : 1;
-      cd.wout = (const float4*)h->P(bb + B_OUT_W); cd.bout = h->R(bb + B_OUT_B);
-      cd.ln2_g = h->R(bb + B_LN_W); cd.ln2_b = h->R(bb + B_LN_B); cd.y3 = p.feats[i]; cd.ldy3 = C;
-      if (i + 1 < c.nblocks) {
-        cd.w2 = (const float4*)h->fused[i + 1].w[1]; cd.b2 = h->fused[i + 1].b[1]; cd.n2 = 2; cd.y2 = p.qeqp; cd.ldy2 = 2 * C;
-      }
-      HIPCHK(poem_launch_chain(&cd, C, s));
+      HIPCHK(poem_launch_chain(&cd, C, s));       // D1: xyz_{i+1} is final behind it (the next block's searches wait for it)
       if (feats_dead) break;
+      if (ov && h->knn_early && i + 1 < c.nblocks) {
+        HIPCHK(hipEventRecord(h->ev_xyz[i + 1], s));
+        HIPCHK(hipStreamWaitEvent(sk, h->ev_xyz[i + 1], 0));
+        HIPCHK(poem_launch_knn(p.xyz[i + 1], pt_xyz, p.idx_cross[i + 1], B, Q, S, sk));
+        HIPCHK(poem_launch_knn(p.xyz[i + 1], p.xyz[i + 1], p.idx_self[i + 1], B, Q, Q, sk));
+        HIPCHK(hipEventRecord(h->ev_knn[i + 1], sk));
+        knn_issued[i + 1] = true;
+      }
+      ChainArgs ce{};
+      ce.kind = 3; ce.M = BQ; ce.x = p.f_cross[i]; ce.ldx = C; ce.eps = c.ln_eps;
+      ce.wf4 = (const float4*)h->fused[i].w[3]; ce.bf4 = h->fused[i].b[3];
+      ce.wout = (const float4*)h->P(bb + B_OUT_W); ce.bout = h->R(bb + B_OUT_B);
+      ce.ln2_g = h->R(bb + B_LN_W); ce.ln2_b = h->R(bb + B_LN_B); ce.y3 = p.feats[i]; ce.ldy3 = C;
+      if (i + 1 < c.nblocks) {
+        ce.w2 = (const float4*)h->fused[i + 1].w[1]; ce.b2 = h->fused[i + 1].b[1]; ce.n2 = 2; ce.y2 = p.qeqp; ce.ldy2 = 2 * C;
+      }
+      HIPCHK(poem_launch_chain(&ce, C, s));
       feats = p.feats[i];
       if (c.parametric && i == c.nblocks - 1) {
         HIPCHK(poem_launch_q3_flatten(feats, h->R(bb + B_FLAT_W), h->R(bb + B_FLAT_B), p.q3t, B, Q, C, s));
@@ -962,6 +977,17 @@ int poem_set_overlap(poem_handle_t h, int enable) {
 int poem_set_chains(poem_handle_t h, int enable) {
   if (!h) return POEM_E_ARG;
   h->chains = enable != 0;
+  return POEM_OK;
+}
+
+int poem_set_option(poem_handle_t h, const char* name, int value) {
+  if (!h || !name) return POEM_E_ARG;
+  const std::string k(name);
+  if (k == "overlap") h->overlap = value != 0;
+  else if (k == "anchor_tables") h->anchor_tables = value != 0;
+  else if (k == "chains") h->chains = value != 0;
+  else if (k == "knn_early") h->knn_early = value != 0;
+  else return POEM_E_ARG;
   return POEM_OK;
 }
 

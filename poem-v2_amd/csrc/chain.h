@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 
 struct ChainArgs {
-  int kind;                  // 0 = A, 1 = C, 2 = D
+  int kind;                  // 0 = A, 1 = C, 2 = D1, 3 = D2
   int M;                     // rows
   const float* x; int ldx;   // chain input (M, C)
   const float4* w1; const float* b1;            // first Linear (C x C packed)
@@ -19,5 +19,4 @@ struct ChainArgs {
   const float4* wout; const float* bout;        // packed (C x 4C)
   const float* ln2_g; const float* ln2_b;
   float* y3; int ldy3;       // feats
-  int ffn;                   // 0: stop after the coordinate update (last block, nothing reads the feed-forward output)
 };

@@ -9,9 +9,11 @@
 //                                                                                             the fused (w_qs|w_ks|w_vs) o fc1)
 //   kind C  (after the vector self attention) x = r
 //           f = x Wfc2^T + b + residual -> y1 ; y2 = f W2^T + b2                             (W2: composed cross query)
-//   kind D  (after the vector cross attention) x = r
+//   kind D1 (after the vector cross attention) x = r
 //           f = x Wfc2^T + b + residual -> y1
 //           u = relu(f Wreg0^T + b) ; xyz' = xyz + u Wreg2^T + b                             (reg_branch, 3 outputs)
+//           -- its own launch: the next block's neighbour searches wait for xyz' only and overlap the rest of the tail
+//   kind D2 x = f
 //           o = sum_s gelu(f Wint_s^T + b_s) Wout_s^T  (four C-wide slabs of the 4C intermediate, never materialised:
 //               the K = 4C contraction accumulates slab by slab in k order) ; t = o + bout + f ; g = LayerNorm(t) -> y3
 //           y2 = g W2^T + b2                                                                  (W2: next block's embedding | query)
@@ -88,13 +90,13 @@ __device__ __forceinline__ void lds_gemm(const __amdgpu_buffer_rsrc_t wrs, int w
 }  // namespace
 
 template <int C, int P, int NW, int KIND>
-__global__ __launch_bounds__(NW * 64, KIND == 2 ? NW / 4 : NW / 2) void chain_kernel(ChainArgs A) {
+__global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain_kernel(ChainArgs A) {
   constexpr int XS = 32 * P, XSP = XS + 1, NTILE = C / 32, TPW = NTILE / NW, KCH = C / 8, NT = NW * 64;
   static_assert(NTILE % NW == 0, "waves must divide the channel tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* X0 = smem;                       // C * XSP
-  float* X1 = X0 + C * XSP;               // C * XSP (kind D only)
-  float* red = KIND == 2 ? X1 + C * XSP : X0 + C * XSP;   // NW * XS partial row sums
+  float* X1 = X0 + C * XSP;               // C * XSP (kind D2 only)
+  float* red = KIND == 3 ? X1 + C * XSP : X0 + C * XSP;   // NW * XS partial row sums
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
   const int items = (A.M + XS - 1) / XS;
   const int tile0 = wv * TPW;             // this wave's first channel tile within a C-wide pass
@@ -234,47 +236,51 @@ __global__ __launch_bounds__(NW * 64, KIND == 2 ? NW / 4 : NW / 2) void chain_ke
       }
     }
     __syncthreads();
-    // ---- stage 1: first Linear + bias + residual [+ LayerNorm] -> y1 and back into X0
-    f32x16 acc[TPW][P];
-    lds_gemm<KCH, XSP, P, TPW, true>(frag_rsrc(A.w1, CC4), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, acc, lane);
-    add_bias(acc, A.b1, 0);
-    add_rows(acc, A.res, A.ldres, A.res_mod, row0);
-    if (KIND == 0) layer_norm(acc, A.ln_g, A.ln_b, A.eps);
-    to_global(acc, A.y1, A.ldy1, 0, row0);
-    __syncthreads();                          // every wave is done reading the input tile
-    to_lds(acc, X0);
-    __syncthreads();
-    if (KIND != 2) {
-      if (A.n2 > 0) wide_linear(A.w2, A.b2, A.n2, X0, A.y2, A.ldy2, row0);
+    const __amdgpu_buffer_rsrc_t f4rs = frag_rsrc(A.wf4, 5u * CC4);
+    if (KIND != 3) {
+      // ---- stage 1: first Linear + bias + residual [+ LayerNorm] -> y1 and back into X0
+      f32x16 acc[TPW][P];
+      lds_gemm<KCH, XSP, P, TPW, true>(frag_rsrc(A.w1, CC4), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, acc, lane);
+      add_bias(acc, A.b1, 0);
+      add_rows(acc, A.res, A.ldres, A.res_mod, row0);
+      if (KIND == 0) layer_norm(acc, A.ln_g, A.ln_b, A.eps);
+      to_global(acc, A.y1, A.ldy1, 0, row0);
+      __syncthreads();                          // every wave is done reading the input tile
+      to_lds(acc, X0);
+      __syncthreads();
+      if (KIND != 2) {
+        if (A.n2 > 0) wide_linear(A.w2, A.b2, A.n2, X0, A.y2, A.ldy2, row0);
+        continue;
+      }
+      // ---- kind D1.  reg_branch: u = relu(f Wreg0^T + b) (over f in X0: f is in HBM already), xyz' = xyz + u Wreg2^T + b
+      {
+        f32x16 u[TPW][P];
+        lds_gemm<KCH, XSP, P, TPW, true>(f4rs, __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, u, lane);
+        add_bias(u, A.bf4, 1);
+        __syncthreads();                        // every wave is done reading f
+        to_lds(u, X0);
+      }
+      __syncthreads();
+      // one wave per row, lanes stride the channels: the fma chain and the reduction order of narrow_linear_kernel
+      for (int r = wv; r < XS; r += NW) {
+        const int row = row0 + r;
+        float s3[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          float s = 0.f;
+          for (int c = lane; c < C; c += 64) s = fmaf(X0[c * XSP + r], A.wreg2[n * C + c], s);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+          s3[n] = s;
+        }
+        if (lane < 3 && row < A.M) {
+          const float s = lane == 0 ? s3[0] : (lane == 1 ? s3[1] : s3[2]);
+          A.xyz_out[(size_t)row * 3 + lane] = A.xyz_in[(size_t)row * 3 + lane] + (s + A.breg2[lane]);
+        }
+      }
       continue;
     }
-    // ---- kind D.  reg_branch: u = relu(f Wreg0^T + b) -> X1, xyz' = xyz + u Wreg2^T + b
-    const __amdgpu_buffer_rsrc_t f4rs = frag_rsrc(A.wf4, 5u * CC4);
-    {
-      f32x16 u[TPW][P];
-      lds_gemm<KCH, XSP, P, TPW, true>(f4rs, __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, u, lane);
-      add_bias(u, A.bf4, 1);
-      to_lds(u, X1);
-    }
-    __syncthreads();
-    // one wave per row, lanes stride the channels: the fma chain and the reduction order of narrow_linear_kernel
-    for (int r = wv; r < XS; r += NW) {
-      const int row = row0 + r;
-      float s3[3];
-#pragma unroll
-      for (int n = 0; n < 3; ++n) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s = fmaf(X1[c * XSP + r], A.wreg2[n * C + c], s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        s3[n] = s;
-      }
-      if (lane < 3 && row < A.M) {
-        const float s = lane == 0 ? s3[0] : (lane == 1 ? s3[1] : s3[2]);
-        A.xyz_out[(size_t)row * 3 + lane] = A.xyz_in[(size_t)row * 3 + lane] + (s + A.breg2[lane]);
-      }
-    }
-    if (!A.ffn) continue;
+    // ---- kind D2 (X0 = f)
     // ---- feed forward: o = sum_s gelu(f Wint_s^T + b_s) Wout[:, sC:(s+1)C]^T, slab by slab in k order
     f32x16 o[TPW][P];
     const __amdgpu_buffer_rsrc_t wors = frag_rsrc(A.wout, 4u * CC4);
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 2 ? NW / 4 : NW / 2) void chain_ke
       f32x16 t[TPW][P];
       lds_gemm<KCH, XSP, P, TPW, true>(f4rs, __builtin_amdgcn_readfirstlane(((1 + sl) * NTILE + tile0) * KCH * 1024), KCH * 1024, X0, t, lane);
       add_bias(t, A.bf4 + (1 + sl) * C, 2);
-      __syncthreads();                        // readers of X1 (the reg_branch rows / the previous slab's contraction)
+      __syncthreads();                        // readers of X1 (the previous slab's contraction)
       to_lds(t, X1);
       __syncthreads();
       // tile t of the (C x 4C) image spans 4 KCH chunks: slab sl starts sl * KCH chunks in
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 2 ? NW / 4 : NW / 2) void chain_ke
 template <int C, int P, int NW, int KIND>
 static hipError_t launch_chain_k(const ChainArgs& a, hipStream_t s) {
   constexpr int XS = 32 * P, XSP = XS + 1;
-  const size_t lds = ((size_t)(KIND == 2 ? 2 : 1) * C * XSP + (size_t)NW * XS) * sizeof(float);
+  const size_t lds = ((size_t)(KIND == 3 ? 2 : 1) * C * XSP + (size_t)NW * XS) * sizeof(float);
   auto kern = chain_kernel<C, P, NW, KIND>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -339,6 +345,7 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
     case 0: return launch_chain_k<C, P, NW, 0>(a, s);
     case 1: return launch_chain_k<C, P, NW, 1>(a, s);
     case 2: return launch_chain_k<C, P, NW, 2>(a, s);
+    case 3: return launch_chain_k<C, P, NW, 3>(a, s);
     default: return hipErrorInvalidValue;
   }
 }

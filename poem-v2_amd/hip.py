@@ -53,6 +53,7 @@ SIGNATURES = {
     "poem_set_overlap": (_i, [_vp, _i]),
     "poem_set_anchor_tables": (_i, [_vp, _i]),
     "poem_set_chains": (_i, [_vp, _i]),
+    "poem_set_option": (_i, [_vp, ctypes.c_char_p, _i]),
     "poem_set_precision": (_i, [_vp, _i]),
     "poem_pack_split_linear": (_i, [_vp, _i, _vp, _vp, _vp]),
     "poem_pack_split_gemm": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
@@ -233,6 +234,9 @@ class Engine:
     def set_anchor_tables(self, flag=True):
         """Block-0 positional products once per forward instead of per sample (include/poem_hip.h)."""
         check(lib().poem_set_anchor_tables(self.handle, int(flag)), "poem_set_anchor_tables")
+
+    def set_option(self, name, value):
+        check(lib().poem_set_option(self.handle, name.encode(), int(value)), f"poem_set_option({name})")
 
     def set_chains(self, flag=True):
         """Query-side row-tile chain kernels (default on) vs one launch per operator (include/poem_hip.h)."""
