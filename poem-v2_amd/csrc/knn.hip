@@ -12,21 +12,32 @@
 
 // Block = QPB waves = QPB queries of ONE sample; the sample's source coordinates are staged once in LDS (12-byte
 // stride: conflict-free) instead of every query wave streaming all NS points from L2.
+//
+// Selection (fast path).  The 32 extraction rounds above are latency chains over all PER registers of every lane; almost
+// all of that work looks at candidates that are nowhere near the answer.  A bound comes for free: the 32nd smallest of
+// the 64 per-lane minima is >= the 32nd smallest distance overall (those 32 lane minima are 32 distinct candidates below
+// it).  So: T = 32nd smallest lane minimum (64 broadcast compares), survivors = every candidate with d <= T (for
+// uniformly scattered points ~44 of 4096), compacted into a per-wave LDS list with ballots, then ranked among themselves
+// by (distance, index) -- rank < 32 writes the output slot directly.  Same distances, same strict order: the result is
+// identical to the extraction loop, which stays as the fall-back when more than SURV_CAP candidates tie below T or fewer
+// than 32 survive (NaN coordinates).
+#define POEM_KNN_SURV_CAP 128
 template <int PER, int QPB>
 __global__ __launch_bounds__(QPB * 64) void knn_kernel(const float* __restrict__ qxyz, const float* __restrict__ sxyz,
                                                        int* __restrict__ idx, int B, int NQ, int NS) {
   constexpr int NG = PER / 8;                 // groups of 8 registers
-  extern __shared__ float sp[];               // NS * 3
-  const int lane = threadIdx.x & 63;
+  extern __shared__ float sp[];               // NS * 3 floats, then QPB survivor lists of SURV_CAP (distance, index) pairs
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int qgroups = (NQ + QPB - 1) / QPB;
   const int b = blockIdx.x / qgroups;
-  const int qi = (blockIdx.x % qgroups) * QPB + (threadIdx.x >> 6);
+  const int qi = (blockIdx.x % qgroups) * QPB + wv;
   {
     const float* src = sxyz + (size_t)b * NS * 3;
     for (int i = threadIdx.x; i < NS * 3; i += QPB * 64) sp[i] = src[i];
   }
   __syncthreads();
   if (qi >= NQ) return;
+  float2* surv = reinterpret_cast<float2*>(sp + ((NS * 3 + 1) & ~1)) + wv * POEM_KNN_SURV_CAP;
   const long wid = (long)b * NQ + qi;
   const float* qp = qxyz + wid * 3;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
@@ -41,6 +52,52 @@ __global__ __launch_bounds__(QPB * 64) void knn_kernel(const float* __restrict__
       d[i] = INFINITY;
     }
   }
+  int* out = idx + wid * 32;
+#ifndef POEM_KNN_EXTRACT_ONLY
+  {
+    // ---- T = 32nd smallest lane minimum
+    float lm = d[0];
+#pragma unroll
+    for (int i = 1; i < PER; ++i) lm = fminf(lm, d[i]);
+    int below = 0;                              // lanes whose minimum is strictly smaller than mine
+#pragma unroll
+    for (int l = 0; l < 64; ++l) {
+      const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lm), l));
+      below += o < lm ? 1 : 0;
+    }
+    float t = below <= 31 ? lm : -INFINITY;     // the sorted position-31 value is the largest minimum with <= 31 below it
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t = fmaxf(t, __shfl_xor(t, o, 64));
+    // ---- survivors -> LDS list (order irrelevant: they are ranked below)
+    int n = 0;                                  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const bool keep = d[i] <= t;
+      const unsigned long long m = __ballot(keep);
+      if (m == 0ull) continue;
+      const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      if (keep && pos < POEM_KNN_SURV_CAP) surv[pos] = make_float2(d[i], __int_as_float(lane + 64 * i));
+      n += __popcll(m);
+    }
+    if (n >= 32 && n <= POEM_KNN_SURV_CAP && t < INFINITY) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- rank every survivor among the survivors by (distance, index); ranks 0..31 are the answer, in order
+      for (int base = 0; base < n; base += 64) {
+        const int me = base + lane;
+        const float2 mine = surv[min(me, n - 1)];
+        const int mi = __float_as_int(mine.y);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+          const float2 o = surv[j];             // same address in every lane: an LDS broadcast
+          rank += (o.x < mine.x || (o.x == mine.x && __float_as_int(o.y) < mi)) ? 1 : 0;
+        }
+        if (me < n && rank < 32) out[rank] = mi;
+      }
+      return;
+    }
+  }
+#endif
   // group minima (value, register index); strict '<' keeps the lower register = lower source index on ties
   float gmin[NG];
   int gidx[NG];
@@ -57,7 +114,6 @@ __global__ __launch_bounds__(QPB * 64) void knn_kernel(const float* __restrict__
     gmin[g] = best;
     gidx[g] = bi;
   }
-  int* out = idx + wid * 32;
   for (int round = 0; round < 32; ++round) {
     float best = gmin[0];
     int bi = gidx[0];
@@ -124,7 +180,7 @@ extern "C" hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int*
                                       hipStream_t s) {
   constexpr int QPB = 16;
   dim3 grid((unsigned)(B * ((NQ + QPB - 1) / QPB))), block(QPB * 64);
-  const size_t lds = (size_t)NS * 3 * sizeof(float);
+  const size_t lds = (size_t)((NS * 3 + 1) & ~1) * sizeof(float) + (size_t)QPB * POEM_KNN_SURV_CAP * sizeof(float2);
   if (NS <= 64 * 16) hipLaunchKernelGGL((knn_kernel<16, QPB>), grid, block, lds, s, qxyz, sxyz, idx, B, NQ, NS);
   else if (NS <= 64 * 64) hipLaunchKernelGGL((knn_kernel<64, QPB>), grid, block, lds, s, qxyz, sxyz, idx, B, NQ, NS);
   else return hipErrorInvalidValue;

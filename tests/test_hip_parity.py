@@ -149,6 +149,35 @@ def test_knn_matches_oracle(NQ, NS):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("NS,mode", [(4096, "same"), (4096, "grid"), (799, "grid"), (1024, "cluster"), (4096, "cluster"),
+                                     (300, "nan")])
+def test_knn_selection_paths(NS, mode):
+    """The threshold-selection fast path of knn.hip and its fall-back (more than 128 candidates tie at or below the
+    bound; fewer than 32 finite distances) must give the extraction loop's answer: (distance, index) order."""
+    g = torch.Generator().manual_seed(NS + len(mode))
+    B, NQ = 2, 70
+    qx = torch.rand(B, NQ, 3, generator=g) * 2 - 1
+    if mode == "same":
+        sx = torch.zeros(B, NS, 3)                               # every distance equal: 4096 survivors -> fall-back
+    elif mode == "grid":
+        sx = torch.round((torch.rand(B, NS, 3, generator=g) * 2 - 1) * 2) / 2      # 5^3 lattice: ties by the hundred
+        qx = torch.round(qx * 2) / 2
+    elif mode == "cluster":
+        sx = torch.rand(B, NS, 3, generator=g) * 2 - 1
+        sx[:, : NS // 2] = sx[:, :1] + 1e-4 * torch.randn(B, NS // 2, 3, generator=g)   # half the set in one lane's reach
+        qx[:, :8] = sx[:, :8]
+    else:
+        sx = torch.rand(B, NS, 3, generator=g) * 2 - 1
+        sx[:, 20:] = float("nan")                                # 20 finite candidates < 32
+    got = hip.knn(qx.to(DEV), sx.to(DEV)).cpu().long()
+    if mode == "nan":
+        ref = po.knn_indices(qx, sx[:, :20], 20)
+        assert torch.equal(got[..., :20], ref)
+        return
+    ref = po.knn_indices(qx, sx, 32)
+    assert torch.equal(got, ref)
+
+
 def test_knn_ties_take_lower_index():
     sx = torch.zeros(1, 64, 3)
     sx[0, :, 0] = torch.arange(64).float() // 2          # every distance appears twice
