@@ -2,6 +2,7 @@
 // of the whole POEM_Generalized_Head + PtEmbedTRv4 path.  Host code only; all kernels live in the .hip files.
 #include "../../include/poem_hip.h"
 #include "chain.h"
+#include "merge.h"
 
 #include <hip/hip_runtime.h>
 
@@ -26,8 +27,15 @@ hipError_t poem_launch_layernorm(const float* x, const float* g, const float* b,
 hipError_t poem_launch_narrow_linear(const float* x, int ldx, const float* w, const float* b, const float* base,
                                      float* out, int rows, int K, int N, hipStream_t s);
 hipError_t poem_launch_sine_pe(float* out, int F, int H, int W, int max_views, hipStream_t s);
+int poem_sample_merge_supported(int C, int S, int hw);
+hipError_t poem_launch_project_table(const float* bps, const float* centre, const int* view_sample, const float* intr,
+                                     const float* inv_extr, void* tab, float* uv, int views, int C, int fh, int fw, int S,
+                                     int img_w, int img_h, hipStream_t s);
+hipError_t poem_launch_sample_merge(const SampleMergeArgs* a, int C, hipStream_t s);
+hipError_t poem_launch_merge_tail(const MergeTailArgs* a, int C, hipStream_t s);
+hipError_t poem_launch_invert_extr(const float* extr, float* inv, int views, hipStream_t s);
 hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, const float* bias, const float* table,
-                               const int* pe_index, float* x, int views, int K, int C, int hw, hipStream_t s);
+                               const int* pe_index, float* x, float* xt, int views, int K, int C, int hw, hipStream_t s);
 hipError_t poem_launch_project_sample(const float* x, const float* bps, const float* centre, const int* view_sample,
                                       const float* intr, const float* extr, float* inv_scratch, float* uv, float* g,
                                       int views, int C, int fh, int fw, int S, int img_w, int img_h, hipStream_t s);
@@ -254,6 +262,9 @@ struct poem_handle_s {
   // Query-side row-tile chains (chain.hip): the Linears / residuals / LayerNorms between the attention kernels of a block
   // run as four chain launches with the activations in LDS instead of ~14 operator launches (fp32 mode, C in {128,256,512}).
   bool chains = true;
+  // Fused sampling front end (merge.hip): sampling + Q1 + merge MLP in two kernels, g / h1 never in HBM (fp32 mode, C in
+  // {128,256,512}); 0 = the operator sequence of sample.hip + gemm.hip.
+  bool fused_sampling = true;
   bool knn_early = true;     // chain mode: issue block i+1's neighbour searches right behind block i's coordinate update
   hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {};
   bool overlap = true;
@@ -304,6 +315,7 @@ struct Plan {
   int32_t *offs, *view_sample, *pe_index, *idx_self[8], *idx_cross[8];
   // sampling stage
   float *x, *uv, *g, *h1, *h2, *mm, *mh, *y, *bps_feat, *centre, *pt_xyz, *xyz[9];
+  float *xt, *ptab, *q1;   // fused sampling: channel-last planes, projection table, residual rows
   // decoder (per call scratch)
   float *feats0, *qp, *ctx, *att, *h_attn, *y3, *rs, *qc, *rc, *y4, *ffo;
   // basis-point side, one set per block (produced ahead of time on the side stream):
@@ -337,6 +349,9 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   p.mh = a.take<float>(BS * C / 2);
   p.y = a.take<float>(BS * C);
   p.bps_feat = a.take<float>(BS * C);
+  p.xt = a.take<float>((size_t)BN * C * HW);
+  p.ptab = a.take<float>(VS * 8);
+  p.q1 = a.take<float>(BS * C);
   p.centre = a.take<float>((size_t)B * 3);
   p.pt_xyz = a.take<float>(BS * 3);
   for (int i = 0; i <= c.nblocks; ++i) p.xyz[i] = nullptr;
@@ -707,7 +722,8 @@ static void register_taps(poem_handle_t h, const Plan& p, int B, int BN, bool sa
   auto put = [&](const std::string& k, const void* ptr, int64_t n) { h->tapmap[k] = {ptr, n}; };
   if (sampling) {
     put("x", p.x, (int64_t)BN * C * HW);
-    put("g", p.g, (int64_t)BN * C * S);
+    if (!(h->fused_sampling && h->precision == POEM_PRECISION_FP32 && poem_sample_merge_supported((int)C, (int)S, (int)HW)))
+      put("g", p.g, (int64_t)BN * C * S);
     put("bps_feat", p.bps_feat, BS * C);
     put("pt_xyz", p.pt_xyz, BS * 3);
   }
@@ -987,6 +1003,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "anchor_tables") h->anchor_tables = value != 0;
   else if (k == "chains") h->chains = value != 0;
   else if (k == "knn_early") h->knn_early = value != 0;
+  else if (k == "fused_sampling") h->fused_sampling = value != 0;
   else return POEM_E_ARG;
   return POEM_OK;
 }
@@ -1064,7 +1081,7 @@ int poem_pe_table(const void* adapt_w_packed, const float* adapt_b, int embed, i
   if (!adapt_w_packed || !adapt_b || !scratch_sine || !table || embed % 2 || (fh * fw) % 32) return POEM_E_ARG;
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(poem_launch_sine_pe(scratch_sine, embed / 2, fh, fw, max_views, s));
-  HIPCHK(poem_launch_conv1x1(scratch_sine, adapt_w_packed, adapt_b, nullptr, nullptr, table, (int)pe_views(max_views),
+  HIPCHK(poem_launch_conv1x1(scratch_sine, adapt_w_packed, adapt_b, nullptr, nullptr, table, nullptr, (int)pe_views(max_views),
                              3 * embed / 2, embed, fh * fw, s));
   return POEM_OK;
 }
@@ -1073,7 +1090,7 @@ int poem_input_proj(const float* feat, const void* w_packed, const float* bias, 
                     const int32_t* pe_index, float* x, int views, int in_channels, int embed, int hw, void* stream) {
   if (!feat || !w_packed || !x || views <= 0 || in_channels % 8 || hw % 32) return POEM_E_ARG;
   if (table && !pe_index) return POEM_E_ARG;
-  HIPCHK(poem_launch_conv1x1(feat, w_packed, bias, table, pe_index, x, views, in_channels, embed, hw, (hipStream_t)stream));
+  HIPCHK(poem_launch_conv1x1(feat, w_packed, bias, table, pe_index, x, nullptr, views, in_channels, embed, hw, (hipStream_t)stream));
   return POEM_OK;
 }
 
@@ -1381,9 +1398,26 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   const bool prof_fe = h->prof_on && (size_t)(2 * h->prof_used + 1) < h->prof_ev.size();
   const int prof_fe_slot = h->prof_used;
   if (prof_fe) { HIPCHK(hipEventRecord(h->prof_ev[2 * prof_fe_slot], s)); h->prof_kind[h->prof_used++] = POEM_PROF_SAMPLING; }
-  HIPCHK(poem_launch_conv1x1(mlvl_feat, h->P(T_INPROJ_W), h->R(T_INPROJ_B), h->pe_table, p.pe_index, p.x, BN,
-                             c.in_channels, C, HW, s));
+  const bool fused_fe = h->fused_sampling && h->precision == POEM_PRECISION_FP32 && poem_sample_merge_supported(C, S, HW) != 0;
+  HIPCHK(poem_launch_conv1x1(mlvl_feat, h->P(T_INPROJ_W), h->R(T_INPROJ_B), h->pe_table, p.pe_index,
+                             (fused_fe && !h->taps) ? nullptr : p.x, fused_fe ? p.xt : nullptr, BN, c.in_channels, C, HW, s));
   HIPCHK(poem_launch_prep_xyz(reference_joints, h->bps, h->tmpl, p.centre, p.pt_xyz, p.xyz[0], B, S, Q, c.radius, s));
+  if (fused_fe) {
+    float* inv = p.uv + (size_t)BN * S * 2;
+    HIPCHK(poem_launch_invert_extr(cam_extr, inv, BN, s));
+    HIPCHK(poem_launch_project_table(h->bps, p.centre, p.view_sample, cam_intr, inv, p.ptab, nullptr, BN, C, c.feat_h, c.feat_w,
+                                     S, img_w, img_h, s));
+    SampleMergeArgs sm{};
+    sm.xt = p.xt; sm.tab = (const float4*)p.ptab; sm.view_sample = p.view_sample; sm.offs = p.offs;
+    sm.w0 = (const float4*)h->P(T_M00_W); sm.b0 = h->R(T_M00_B); sm.w1 = (const float4*)h->P(T_M02_W); sm.b1 = h->R(T_M02_B);
+    sm.h2 = p.h2; sm.q1 = p.q1; sm.views = BN; sm.S = S; sm.hw = HW; sm.h2_tiled = 1;
+    HIPCHK(poem_launch_sample_merge(&sm, C, s));
+    MergeTailArgs mt{};
+    mt.h2 = p.h2; mt.q1 = p.q1; mt.offs = p.offs;
+    mt.w0 = (const float4*)h->P(T_M10_W); mt.b0 = h->R(T_M10_B); mt.w1 = (const float4*)h->P(T_M12_W); mt.b1 = h->R(T_M12_B);
+    mt.out = p.bps_feat; mt.B = B; mt.S = S; mt.h2_tiled = 1;
+    HIPCHK(poem_launch_merge_tail(&mt, C, s));
+  } else {
   HIPCHK(poem_launch_project_sample(p.x, h->bps, p.centre, p.view_sample, cam_intr, cam_extr, p.uv + (size_t)BN * S * 2,
                                     p.uv, p.g, BN, C, c.feat_h, c.feat_w, S, img_w, img_h, s));
   // merge MLP 0 on the Q1 rows == the (BN*S, C) row-major view of g's memory
@@ -1393,6 +1427,7 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   GEMM(p.mm, C / 2, T_M10_W, T_M10_B, nullptr, 0, p.mh, C / 2, BS, C / 2, C / 2, POEM_ACT_RELU);
   GEMM(p.mh, C / 2, T_M12_W, T_M12_B, nullptr, 0, p.y, C, BS, C, C / 2, POEM_ACT_NONE);
   HIPCHK(poem_launch_merge_finalize(p.g, p.y, p.offs, p.bps_feat, B, S, C, s));
+  }
   if (prof_fe) HIPCHK(hipEventRecord(h->prof_ev[2 * prof_fe_slot + 1], s));
 
   // ---- decoder ---------------------------------------------------------------------------------------------------

@@ -46,8 +46,12 @@ __global__ __launch_bounds__(QPB * 64) void knn_kernel(const float* __restrict__
   for (int i = 0; i < PER; ++i) {
     const int c = lane + 64 * i;
     if (c < NS) {
-      const float dx = __fsub_rn(qx, sp[c * 3 + 0]), dy = __fsub_rn(qy, sp[c * 3 + 1]), dz = __fsub_rn(qz, sp[c * 3 + 2]);
-      d[i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      // every product and sum individually rounded (HIP's __fmul_rn / __fadd_rn are plain operators and DO contract to
+      // v_fma_f32 under hipcc's default -ffp-contract=fast: a 1-ulp difference that reorders near-tied candidates)
+#pragma clang fp contract(off)
+      const float dx = qx - sp[c * 3 + 0], dy = qy - sp[c * 3 + 1], dz = qz - sp[c * 3 + 2];
+      const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+      d[i] = (xx + yy) + zz;
     } else {
       d[i] = INFINITY;
     }

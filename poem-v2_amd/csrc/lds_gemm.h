@@ -1,0 +1,65 @@
+// LDS-resident row-tile GEMM shared by the chain kernels (chain.hip) and the fused sampling + merge kernels (merge.hip):
+// activations X[channel][row] in LDS (row stride XSP), packed weight fragments (common.h "fragment order") as the A operand
+// streamed from L2 through a buffer descriptor, an X row as the B operand.
+#pragma once
+#include "common.h"
+
+namespace {
+
+// D[c'][j] (+)= sum_k W[c'][k0 + k] X[k][j] for this wave's TPW tiles; KCH = K / 8 chunks, tile t of the image starts at
+// t * tile_stride bytes, the contraction at byte k0.  Same two-stage software pipeline as vecattn.hip's chain_gemm.
+template <int KCH, int XSP, int P, int TPW, bool INIT0>
+__device__ __forceinline__ void lds_gemm(const __amdgpu_buffer_rsrc_t wrs, int wbase, int tile_stride, const float* __restrict__ X,
+                                         f32x16 (&acc)[TPW][P], int lane) {
+  static_assert(KCH % 2 == 0, "K must be a multiple of 16");
+  const int j = lane & 31, h = lane >> 5;
+  const int loff = lane * 16;
+  const float* xc = X + (4 * h) * XSP + j;
+  float4 a0[TPW], a1[TPW];
+  float xa[P], xb[P];
+#define CH_LOADW(A, KCI)                                                                  \
+  {                                                                                       \
+    const int kq_ = min((KCI), KCH - 1);                                                  \
+    _Pragma("unroll") for (int tp = 0; tp < TPW; ++tp) A[tp] = frag_load(wrs, loff, wbase + tp * tile_stride + kq_ * 1024); \
+  }
+#define CH_READX(XR, KCI, T)                                                              \
+  {                                                                                       \
+    const int kq_ = min((KCI), KCH - 1);                                                  \
+    _Pragma("unroll") for (int p = 0; p < P; ++p) XR[p] = xc[(kq_ * 8 + (T)) * XSP + 32 * p]; \
+  }
+#define CH_MMA(A, T, XR, INIT)                                                            \
+  _Pragma("unroll") for (int tp = 0; tp < TPW; ++tp) {                                    \
+    const float av = (&A[tp].x)[T];                                                       \
+    _Pragma("unroll") for (int p = 0; p < P; ++p) {                                       \
+      const f32x16 c_ = (INIT) ? zero16() : acc[tp][p];                                   \
+      acc[tp][p] = mfma32(av, XR[p], c_);                                                 \
+    }                                                                                     \
+  }
+#define CH_CHUNK(A, KCI, INIT)                                                            \
+  CH_READX(xb, KCI, 1) __builtin_amdgcn_sched_barrier(0); CH_MMA(A, 0, xa, INIT) __builtin_amdgcn_sched_barrier(0); \
+  CH_READX(xa, KCI, 2) __builtin_amdgcn_sched_barrier(0); CH_MMA(A, 1, xb, false) __builtin_amdgcn_sched_barrier(0); \
+  CH_READX(xb, KCI, 3) __builtin_amdgcn_sched_barrier(0); CH_MMA(A, 2, xa, false) __builtin_amdgcn_sched_barrier(0); \
+  CH_READX(xa, (KCI) + 1, 0) __builtin_amdgcn_sched_barrier(0); CH_MMA(A, 3, xb, false) __builtin_amdgcn_sched_barrier(0);
+  CH_LOADW(a0, 0)
+  CH_READX(xa, 0, 0)
+  CH_LOADW(a1, 1)
+  __builtin_amdgcn_sched_barrier(0);
+  CH_CHUNK(a0, 0, INIT0)
+  CH_LOADW(a0, 2)
+  __builtin_amdgcn_sched_barrier(0);
+  CH_CHUNK(a1, 1, false)
+  for (int kc = 2; kc < KCH; kc += 2) {
+    CH_LOADW(a1, kc + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    CH_CHUNK(a0, kc, false)
+    CH_LOADW(a0, kc + 2)
+    __builtin_amdgcn_sched_barrier(0);
+    CH_CHUNK(a1, kc + 1, false)
+  }
+#undef CH_LOADW
+#undef CH_READX
+#undef CH_MMA
+#undef CH_CHUNK
+}
+
+}  // namespace

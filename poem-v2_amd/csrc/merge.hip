@@ -1,0 +1,395 @@
+// Fused sampling front end (ptEmb_head.py:900-926 + merge_features_mv / _sv :745-771 upstream): bilinear sampling of the
+// view feature planes, the Q1 re-interpretation and the whole merge MLP in two kernels, so that the sampled tensor
+// g (sum N, C, S) -- 1.07 GB per 32-sample step at C = 256, written once and read once by the unfused sequence -- and the
+// hidden layer of merge_net[0] never exist in HBM.
+//
+// Q1 (ptEmb_head.py:914-915): a sample's (N, C, S) block is *viewed* as (S, N, C), so Q1 row r of the sample holds the
+// C consecutive floats f = r*C .. r*C + C-1 of the block: view n' = f / (C*S), channel c' = (f / S) % C, points
+// s' = f % S.  With S % C == 0 a row is C consecutive basis points ("segment" seg = r % (S/C)) of ONE (view, channel)
+// plane (plane index r / (S/C)), and merge_net[0]'s first Linear contracts over those C points.  Globally (all views of
+// the batch back to back) row R = v*S + c'*(S/C) + seg, independent of the sample the view belongs to.
+//
+// sample_merge_kernel: a block owns the XS (64 or 32) rows {channels c0 .. c0+XS-1} x one (view, segment) and builds their
+// activations X[k = point][row = channel] in LDS by sampling: the projection of a point is shared by all channels, so
+// the per-point bilinear weights / tap offsets come from a table the projection kernel wrote (32 B per point), and with
+// the feature planes stored channel-LAST a tap of 4 channels is one 16-byte load, 16 lanes covering the 64 channels of a
+// point contiguously (256 B).  Then, exactly like the chain kernels (chain.hip): Linear(C, C) + ReLU with the packed
+// weights streamed from L2, result back into LDS, Linear(C, C/2), h2 tile to HBM.  The rows with n == 0 (r % N == 0)
+// are also written out (q1: the residual term), 1/N of the sampled values.
+//   Work order: blocks of one XCD (blockIdx % 8) walk the tiles of the same view, so a view's 256 KB of planes and its
+// 128 KB table are fetched into that XCD's L2 once.
+//   h2 is written tile-major: [(view * tiles_per_view + tile) * XS + row-in-tile][C/2] -- a block's 64 rows are one
+// contiguous 32 KB instead of 64 rows 8 KB apart.
+//
+// merge_tail_kernel: a block owns 64 basis points of one sample: dot / weighted sum over the views (merge_features_mv;
+// N = 1: the master row itself), merge_net[1] as two LDS-resident GEMMs, / N, + q1 -> bps_feat.
+//
+// Arithmetic: every sampled value, every Linear output element and every reduction is the same fma chain as in the
+// unfused kernels (sample.hip, gemm.hip) except the order of the dot-product reduction over channels (16-lane groups
+// here, a full-wave tree there); the two paths agree to fp32 round-off (tests/test_hip_parity.py).
+#include "common.h"
+#include <algorithm>
+
+#include "lds_gemm.h"
+#include "merge.h"
+
+namespace {
+
+// bias (+ ReLU) on a wave's accumulators: register i of tile `tile` is channel tile*32 + mfma_row(i, h)
+template <int TPW, int P>
+__device__ __forceinline__ void bias_act(f32x16 (&acc)[TPW][P], const float* __restrict__ bias, int tile0, int h, bool relu) {
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp) {
+    const int cbase = (tile0 + tp) * 32 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bb = *reinterpret_cast<const float4*>(bias + cbase + 8 * g);
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[tp][p][4 * g + e] + (&bb.x)[e];
+          if (relu) v = fmaxf(v, 0.f);
+          acc[tp][p][4 * g + e] = v;
+        }
+    }
+  }
+}
+
+template <int TPW, int P, int XSP>
+__device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[TPW][P], float* __restrict__ X, int tile0, int col0, int j, int h) {
+#pragma unroll
+  for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) X[((tile0 + tp) * 32 + mfma_row(i, h)) * XSP + col0 + 32 * p + j] = acc[tp][p][i];
+}
+
+}  // namespace
+
+template <int C, int P, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMergeArgs A) {
+  constexpr int XS = 32 * P, XSP = XS + 1, NTILE = C / 32, TPW = NTILE / NW, KCH = C / 8, HALF = C / 2;
+  constexpr int LPP = XS / 4, PPW = 64 / LPP, PPI = NW * PPW, NIT = C / PPI;   // lanes per point, points per wave / block pass
+  static_assert(NTILE % NW == 0 && (C / 64) * P == NW && C % PPI == 0 && NIT % 2 == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* X0 = smem;                       // C * XSP
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int NSEG = A.S / C, TPV = (C / XS) * NSEG;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, L = gridDim.x >> 3;
+  const int nv = (A.views - xcd + 7) >> 3;          // views xcd, xcd + 8, ... belong to this XCD's blocks
+  const unsigned CC4 = (unsigned)(C * C * 4);
+  const int q = lane / LPP, cg = lane % LPP;
+
+  for (int w = slot; w < nv * TPV; w += L) {
+    const int v = xcd + 8 * (w / TPV), t = w % TPV;
+    const int c0 = (t / NSEG) * XS, seg = t % NSEG;
+    __syncthreads();                          // the previous tile's readers of X0
+    // ---- fill: X0[k][row] = bilinear sample of plane (v, c0 + row) at point seg*C + k
+    {
+      const __amdgpu_buffer_rsrc_t xrs = frag_rsrc(A.xt + (size_t)v * A.hw * C, (unsigned)(A.hw * C * 4));
+      const float4* tb = A.tab + ((size_t)v * A.S + (size_t)seg * C) * 2;
+      const int loff = (c0 + 4 * cg) * 4;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        float4 tw[NIT / 2];
+        int4 to[NIT / 2];
+#pragma unroll
+        for (int i = 0; i < NIT / 2; ++i) {
+          const int k = (half * (NIT / 2) + i) * PPI + wv * PPW + q;
+          tw[i] = tb[2 * k];
+          const float4 o = tb[2 * k + 1];
+          to[i] = make_int4(__float_as_int(o.x), __float_as_int(o.y), __float_as_int(o.z), __float_as_int(o.w));
+        }
+#pragma unroll
+        for (int i = 0; i < NIT / 2; ++i) {
+          const int k = (half * (NIT / 2) + i) * PPI + wv * PPW + q;
+          const float4 nw = frag_load(xrs, to[i].x + loff, 0), ne = frag_load(xrs, to[i].y + loff, 0);
+          const float4 sw = frag_load(xrs, to[i].z + loff, 0), se = frag_load(xrs, to[i].w + loff, 0);
+          float* xo = X0 + k * XSP + 4 * cg;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // the accumulation order of ATen's grid_sampler_2d (nw, ne, sw, se), as sample.hip's grid_sample_kernel
+            float a = (&nw.x)[e] * tw[i].x;
+            a = fmaf((&ne.x)[e], tw[i].y, a);
+            a = fmaf((&sw.x)[e], tw[i].z, a);
+            a = fmaf((&se.x)[e], tw[i].w, a);
+            xo[e] = a;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- q1: the rows with n == 0 leave as they are (residual of the merge)
+    {
+      const int b = A.view_sample[v];
+      const int off = A.offs[b], N = A.offs[b + 1] - off;
+      for (int jj = wv; jj < XS; jj += NW) {
+        const int r = (v - off) * A.S + (c0 + jj) * NSEG + seg;
+        if (r % N) continue;
+        float* dst = A.q1 + ((size_t)b * A.S + r / N) * C;
+#pragma unroll
+        for (int k = lane; k < C; k += 64) dst[k] = X0[k * XSP + jj];
+      }
+    }
+    // ---- merge_net[0].0 + ReLU
+    {
+      f32x16 acc[TPW][P];
+      lds_gemm<KCH, XSP, P, TPW, true>(frag_rsrc(A.w0, CC4), __builtin_amdgcn_readfirstlane(wv * TPW * KCH * 1024), KCH * 1024, X0, acc, lane);
+      bias_act<TPW, P>(acc, A.b0, wv * TPW, h, true);
+      __syncthreads();                        // every wave is done reading the sampled tile
+      acc_to_lds<TPW, P, XSP>(acc, X0, wv * TPW, 0, j, h);
+    }
+    __syncthreads();
+    // ---- merge_net[0].2: C/64 output tiles x P column tiles = one (tile, p) per wave
+    {
+      const int t2 = wv / P, p2 = wv % P;
+      f32x16 acc[1][1];
+      lds_gemm<KCH, XSP, 1, 1, true>(frag_rsrc(A.w1, CC4 / 2), __builtin_amdgcn_readfirstlane(t2 * KCH * 1024), KCH * 1024, X0 + 32 * p2, acc, lane);
+      bias_act<1, 1>(acc, A.b1, t2, h, false);
+      const int jj = 32 * p2 + j;
+      const size_t row = A.h2_tiled ? ((size_t)v * TPV + t) * XS + jj : (size_t)v * A.S + (size_t)(c0 + jj) * NSEG + seg;
+      float* yp = A.h2 + row * HALF + t2 * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(yp + 8 * g) = make_float4(acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int C, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void merge_tail_kernel(MergeTailArgs A) {
+  constexpr int HALF = C / 2, XS = 64, XSP = XS + 1, P = 2;
+  constexpr int NTA = HALF / 32, NTB = C / 32, KCH = HALF / 8;
+  constexpr int TPWA = NTA >= NW ? NTA / NW : 1, PA = NTA >= NW ? 2 : 1;     // first GEMM: whole column range or one (tile, p)
+  constexpr int TPWB = NTB / NW;
+  constexpr int F4 = HALF / 64;           // float4 chunks per lane of a 16-lane row group
+  static_assert(NTA >= NW || NTA * 2 == NW, "shape");
+  static_assert(NTB % NW == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* X0 = smem;                       // HALF * XSP
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int rg = lane >> 4, l16 = lane & 15;
+  const int items = (A.B * A.S) / XS;
+  const int NSEG = A.S / C;
+  // tiles of the fused kernel (XS rows there = 32 * P' with P' = 2 for C <= 256, 1 for C = 512)
+  constexpr int FXS = C == 512 ? 32 : 64;
+  const int TPV = (C / FXS) * NSEG;
+
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int i0 = item * XS;               // first global basis-point row b * S + s
+    const int b = i0 / A.S, s0 = i0 % A.S;
+    const int off = A.offs[b], N = A.offs[b + 1] - off;
+    __syncthreads();                        // the previous item's readers of X0
+    // ---- reduce over the views: 16 lanes per row, rows jj = 4 * (pass * NW + wv) + rg
+    for (int pass = 0; pass < XS / (4 * NW); ++pass) {
+      const int jj = 4 * (pass * NW + wv) + rg;
+      const size_t r0 = (size_t)(s0 + jj) * N;                 // first Q1 row of this point within the sample
+      auto rowp = [&](size_t r) -> const float4* {
+        size_t row;
+        if (A.h2_tiled) {
+          const size_t vv = off + r / A.S, rem = r % A.S;
+          const size_t cp = rem / NSEG, sg = rem % NSEG;
+          row = (vv * TPV + (cp / FXS) * NSEG + sg) * FXS + cp % FXS;
+        } else {
+          row = (size_t)off * A.S + r;
+        }
+        return reinterpret_cast<const float4*>(A.h2 + row * HALF);
+      };
+      float4 mast[F4], acc[F4];
+      {
+        const float4* mp = rowp(r0);
+#pragma unroll
+        for (int i = 0; i < F4; ++i) { mast[i] = mp[l16 + 16 * i]; acc[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      }
+      if (N == 1) {
+#pragma unroll
+        for (int i = 0; i < F4; ++i) acc[i] = mast[i];
+      }
+      for (int n = 1; n < N; ++n) {
+        const float4* hp = rowp(r0 + n);
+        float4 v[F4];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+          v[i] = hp[l16 + 16 * i];
+          dot = fmaf(v[i].x, mast[i].x, dot);
+          dot = fmaf(v[i].y, mast[i].y, dot);
+          dot = fmaf(v[i].z, mast[i].z, dot);
+          dot = fmaf(v[i].w, mast[i].w, dot);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+          acc[i].x = fmaf(dot, v[i].x, acc[i].x);
+          acc[i].y = fmaf(dot, v[i].y, acc[i].y);
+          acc[i].z = fmaf(dot, v[i].z, acc[i].z);
+          acc[i].w = fmaf(dot, v[i].w, acc[i].w);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < F4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) X0[(4 * (l16 + 16 * i) + e) * XSP + jj] = (&acc[i].x)[e];
+    }
+    __syncthreads();
+    // ---- merge_net[1].0 + ReLU (HALF -> HALF)
+    {
+      const int tile0 = NTA >= NW ? wv * TPWA : wv / 2, col0 = NTA >= NW ? 0 : 32 * (wv % 2);
+      f32x16 acc[TPWA][PA];
+      lds_gemm<KCH, XSP, PA, TPWA, true>(frag_rsrc(A.w0, (unsigned)(HALF * HALF * 4)), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024,
+                                         X0 + col0, acc, lane);
+      bias_act<TPWA, PA>(acc, A.b0, tile0, h, true);
+      __syncthreads();
+      acc_to_lds<TPWA, PA, XSP>(acc, X0, tile0, col0, j, h);
+    }
+    __syncthreads();
+    // ---- merge_net[1].2 (HALF -> C), / N, + q1 -> bps_feat
+    {
+      const int tile0 = wv * TPWB;
+      f32x16 acc[TPWB][P];
+      lds_gemm<KCH, XSP, P, TPWB, true>(frag_rsrc(A.w1, (unsigned)(C * HALF * 4)), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, acc, lane);
+      bias_act<TPWB, P>(acc, A.b1, tile0, h, false);
+      const float fn = (float)N;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const size_t row = (size_t)i0 + 32 * p + j;
+        const float* qp = A.q1 + row * C + 4 * h;
+        float* yp = A.out + row * C + 4 * h;
+#pragma unroll
+        for (int tp = 0; tp < TPWB; ++tp)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 qq = *reinterpret_cast<const float4*>(qp + (tile0 + tp) * 32 + 8 * g);
+            float4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float yv = acc[tp][p][4 * g + e];
+              (&o.x)[e] = (&qq.x)[e] + (N == 1 ? yv : yv / fn);      // merge_finalize_kernel's expression
+            }
+            *reinterpret_cast<float4*>(yp + (tile0 + tp) * 32 + 8 * g) = o;
+          }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Projection of the basis points into every view (project_kernel of sample.hip, same fp32 chain) down to the bilinear
+// weights and tap offsets of grid_sample(align_corners=False, zero padding): 32 bytes per (view, point).
+__global__ void project_table_kernel(const float* __restrict__ bps, const float* __restrict__ centre,
+                                     const int* __restrict__ view_sample, const float* __restrict__ intr,
+                                     const float* __restrict__ inv_extr, float4* __restrict__ tab, float* __restrict__ uv,
+                                     int views, int S, int fw, int fh, float inv_w, float inv_h, int C) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  if (s >= S) return;
+  const float* c = centre + (size_t)view_sample[v] * 3;
+  const float px = bps[s * 3 + 0] + c[0], py = bps[s * 3 + 1] + c[1], pz = bps[s * 3 + 2] + c[2];
+  const float* T = inv_extr + (size_t)v * 16;
+  const float cx = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3];
+  const float cy = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7];
+  const float cz = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11];
+  const float* K = intr + (size_t)v * 9;
+  const float qx = fmaf(K[2], cz, fmaf(K[1], cy, K[0] * cx));
+  const float qy = fmaf(K[5], cz, fmaf(K[4], cy, K[3] * cx));
+  float qz = fmaf(K[8], cz, fmaf(K[7], cy, K[6] * cx));
+  if (fabsf(qz) < 1e-7f) qz = 1e-7f;
+  const float u = qx / qz, w = qy / qz;
+  const float gx = u * inv_w * 2.0f - 1.0f, gy = w * inv_h * 2.0f - 1.0f;
+  const float ix = ((gx + 1.0f) * (float)fw - 1.0f) / 2.0f;
+  const float iy = ((gy + 1.0f) * (float)fh - 1.0f) / 2.0f;
+  if (uv) reinterpret_cast<float2*>(uv)[(size_t)v * S + s] = make_float2(ix, iy);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx0, wy1 = iy - fy0;
+  const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+  const bool vx0 = x0 >= 0 && x0 < fw, vx1 = x1 >= 0 && x1 < fw, vy0 = y0 >= 0 && y0 < fh, vy1 = y1 >= 0 && y1 < fh;
+  const float w_nw = (vx0 && vy0) ? wx0 * wy0 : 0.f, w_ne = (vx1 && vy0) ? wx1 * wy0 : 0.f;
+  const float w_sw = (vx0 && vy1) ? wx0 * wy1 : 0.f, w_se = (vx1 && vy1) ? wx1 * wy1 : 0.f;
+  const int cx0 = min(max(x0, 0), fw - 1), cx1 = min(max(x1, 0), fw - 1);
+  const int cy0 = min(max(y0, 0), fh - 1), cy1 = min(max(y1, 0), fh - 1);
+  const int sc = C * 4;
+  float4* o = tab + ((size_t)v * S + s) * 2;
+  o[0] = make_float4(w_nw, w_ne, w_sw, w_se);
+  o[1] = make_float4(__int_as_float((cy0 * fw + cx0) * sc), __int_as_float((cy0 * fw + cx1) * sc),
+                     __int_as_float((cy1 * fw + cx0) * sc), __int_as_float((cy1 * fw + cx1) * sc));
+}
+
+static int g_cus = 0;
+static int cu_count() {
+  if (!g_cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_cus <= 0)
+      g_cus = 256;
+  }
+  return g_cus;
+}
+
+template <int C, int P, int NW>
+static hipError_t launch_sample_merge_t(const SampleMergeArgs& a, hipStream_t s) {
+  constexpr int XS = 32 * P, XSP = XS + 1;
+  const size_t lds = (size_t)C * XSP * sizeof(float);
+  auto kern = sample_merge_kernel<C, P, NW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int tpv = (C / XS) * (a.S / C);
+  const long items = (long)a.views * tpv;
+  long grid = std::min<long>(items, (long)cu_count() * 2);
+  grid = std::max<long>(8, (grid + 7) / 8 * 8);        // the XCD-aware work order needs a multiple of 8 blocks
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, a);
+  return hipGetLastError();
+}
+
+template <int C, int NW>
+static hipError_t launch_merge_tail_t(const MergeTailArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)(C / 2) * 65 * sizeof(float);
+  auto kern = merge_tail_kernel<C, NW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const long items = (long)a.B * a.S / 64;
+  hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long>(items, (long)cu_count() * 2)), dim3(NW * 64), lds, s, a);
+  return hipGetLastError();
+}
+
+// Shapes the fused front end serves: the chain widths, segments that tile the point axis, 64-point tail tiles.
+extern "C" int poem_sample_merge_supported(int C, int S, int hw) {
+  return (C == 128 || C == 256 || C == 512) && S % C == 0 && S % 64 == 0 && (long)hw * C * 4 < (1l << 31);
+}
+
+extern "C" hipError_t poem_launch_project_table(const float* bps, const float* centre, const int* view_sample, const float* intr,
+                                                const float* inv_extr, void* tab, float* uv, int views, int C, int fh, int fw,
+                                                int S, int img_w, int img_h, hipStream_t s) {
+  hipLaunchKernelGGL(project_table_kernel, dim3((S + 255) / 256, views), dim3(256), 0, s, bps, centre, view_sample, intr, inv_extr,
+                     (float4*)tab, uv, views, S, fw, fh, 1.0f / (float)img_w, 1.0f / (float)img_h, C);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t poem_launch_sample_merge(const SampleMergeArgs* a, int C, hipStream_t s) {
+  switch (C) {
+    case 128: return launch_sample_merge_t<128, 2, 4>(*a, s);
+    case 256: return launch_sample_merge_t<256, 2, 8>(*a, s);
+    case 512: return launch_sample_merge_t<512, 1, 8>(*a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+extern "C" hipError_t poem_launch_merge_tail(const MergeTailArgs* a, int C, hipStream_t s) {
+  switch (C) {
+    case 128: return launch_merge_tail_t<128, 4>(*a, s);
+    case 256: return launch_merge_tail_t<256, 8>(*a, s);
+    case 512: return launch_merge_tail_t<512, 8>(*a, s);
+    default: return hipErrorInvalidValue;
+  }
+}

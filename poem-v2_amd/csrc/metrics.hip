@@ -102,8 +102,15 @@ __global__ void pck_accumulate_kernel(const float* __restrict__ pred, const floa
   for (int b = 0; b < B; ++b) {
     const float* p = pred + ((size_t)b * P + k) * 3;
     const float* g = gt + ((size_t)b * P + k) * 3;
-    const float dx = __fsub_rn(p[0], g[0]), dy = __fsub_rn(p[1], g[1]), dz = __fsub_rn(p[2], g[2]);
-    const float d = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    float d;
+    {
+      // numpy's operation order, every product and sum individually rounded (no v_fma contraction: the `<=` below must
+      // agree with the reference's for a distance within an ulp of a threshold)
+#pragma clang fp contract(off)
+      const float dx = p[0] - g[0], dy = p[1] - g[1], dz = p[2] - g[2];
+      const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+      d = __fsqrt_rn((xx + yy) + zz);
+    }
     acc += (double)d;
     if (dist_out) dist_out[(size_t)b * P + k] = d;
     // thresholds ascend: first index whose threshold admits d, every later one does too

@@ -48,7 +48,7 @@ template <int PT>
 __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ feat, const float4* __restrict__ Wp,
                                                       const float* __restrict__ bias, const float* __restrict__ table,
                                                       const int* __restrict__ pe_index, float* __restrict__ x,
-                                                      int views, int K, int C, int hw) {
+                                                      float* __restrict__ xt, int views, int K, int C, int hw) {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int pgroups = hw / (32 * PT);
@@ -83,23 +83,34 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
       const int p = pg * 32 * PT + pt * 32 + r;
       float val = acc[pt][i] + bv;
       if (tab) val += tab[(size_t)c * hw + p];
-      x[((size_t)v * C + c) * hw + p] = val;
+      acc[pt][i] = val;
+      if (x) x[((size_t)v * C + c) * hw + p] = val;
+    }
+  }
+  // channel-last copy xt[v][p][c] for the fused sampling kernel (merge.hip): registers 4g .. 4g+3 are four consecutive channels
+  if (xt && C % 32 == 0) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      float* dst = xt + ((size_t)v * hw + pg * 32 * PT + pt * 32 + r) * C + ct * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(acc[pt][4 * g], acc[pt][4 * g + 1], acc[pt][4 * g + 2], acc[pt][4 * g + 3]);
     }
   }
 }
 
 extern "C" hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, const float* bias, const float* table,
-                                          const int* pe_index, float* x, int views, int K, int C, int hw,
+                                          const int* pe_index, float* x, float* xt, int views, int K, int C, int hw,
                                           hipStream_t s) {
   const int ctiles = (C + 31) / 32;
   if (hw % 128 == 0) {
     const long waves = (long)views * ctiles * (hw / 128);
     hipLaunchKernelGGL((conv1x1_kernel<4>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, feat, (const float4*)Wp,
-                       bias, table, pe_index, x, views, K, C, hw);
+                       bias, table, pe_index, x, xt, views, K, C, hw);
   } else {
     const long waves = (long)views * ctiles * (hw / 32);
     hipLaunchKernelGGL((conv1x1_kernel<1>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, feat, (const float4*)Wp,
-                       bias, table, pe_index, x, views, K, C, hw);
+                       bias, table, pe_index, x, xt, views, K, C, hw);
   }
   return hipGetLastError();
 }
@@ -196,6 +207,11 @@ __global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restric
       g[((size_t)v * C + c0 + c) * S + s] = acc;
     }
   }
+}
+
+extern "C" hipError_t poem_launch_invert_extr(const float* extr, float* inv, int views, hipStream_t s) {
+  hipLaunchKernelGGL(invert_extr_kernel, dim3((views + 63) / 64), dim3(64), 0, s, extr, inv, views);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t poem_launch_project_sample(const float* x, const float* bps, const float* centre,

@@ -449,6 +449,51 @@ def test_row_tile_chains_vs_operator_launches(name):
     assert mp(out[True], out[False]) < (1e-6 if "hot" in name else 2e-7)
 
 
+@pytest.mark.parametrize("name", ["small", "medium", "large", "ragged", "mediummano", "medium_hot"])
+def test_fused_sampling_vs_operator_sequence(name):
+    """csrc/merge.hip (default): bilinear sampling + the Q1 re-interpretation + the merge MLP in two kernels (the sampled
+    tensor g and merge_net[0]'s hidden layer never reach HBM); set_option("fused_sampling", 0) = sample.hip + gemm.hip, one
+    launch per operator.  Same fma chain per sampled value and per Linear output; only the reduction order of the cross-view
+    dot products differs.  Both forms: `bps_feat` against the REFERENCE's own tensor (fixture tap, every 64th basis point,
+    views [2] .. [3,10,1,6] incl. the single-view branch), against each other, and the final vertices against the fixture."""
+    z, meta = load_golden(name)
+    spec = meta["spec"]
+    cfg, w, consts, batch = case_setup(spec)
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    eng = head._engine_for(torch.device(DEV))
+    eng.enable_taps(True)
+    B, C, S = len(spec["views"]), spec["embed"], spec["nsample"]
+    out, bf = {}, {}
+    for mode in (1, 0, 1):
+        eng.set_option("fused_sampling", mode)
+        with torch.no_grad():
+            res = head(feat, metas, rj)["all_coords_preds"].cpu()
+        if mode in out:
+            assert torch.equal(out[mode], res)
+            continue
+        out[mode] = res
+        bf[mode] = eng.tap("bps_feat", (B, S, C)).cpu()
+        x = eng.tap("x", (sum(spec["views"]), C, 16, 16)).cpu()
+        if mode == 1:
+            x_fused = x
+            with pytest.raises(RuntimeError):
+                eng.tap("g", (1,))                     # the sampled tensor does not exist in the fused form
+        else:
+            assert torch.equal(x, x_fused)             # input_proj writes both layouts from the same registers
+    eng.enable_taps(False)
+    ref_bf = torch.from_numpy(z["tap.bps_feat"])
+    scale = float(ref_bf.abs().max())
+    for mode in (1, 0):
+        assert _md(bf[mode][:, ::64], ref_bf) < 2e-5 * max(scale, 1.0), (mode, _md(bf[mode][:, ::64], ref_bf), scale)
+    assert not torch.equal(bf[1], bf[0])                # the fused kernels really ran
+    assert _md(bf[1], bf[0]) < 1e-5 * max(scale, 1.0), (_md(bf[1], bf[0]), scale)
+    ref = torch.from_numpy(z["all_coords_preds"])
+    mp = lambda a, b: float(torch.norm(a[-1, :, 21:] - b[-1, :, 21:], dim=-1).mean(dim=1).max())
+    assert mp(out[1], ref) < 1e-6 and mp(out[0], ref) < 1e-6, (mp(out[1], ref), mp(out[0], ref))
+    assert mp(out[1], out[0]) < (1e-6 if "hot" in name else 2e-7)
+
+
 def test_last_block_feed_forward_is_computed_only_when_read():
     """PtEmbedTRv4.forward returns the coordinate stack only (ptEmb_transformer.py:115-121,371-376): the last block's
     feed-forward output feeds nothing unless the parametric tail or a debug tap reads it, and the path does not compute
