@@ -267,9 +267,15 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the short legs for the other BASELINE per-GPU loads (c3 medium_MANO, c4 large x 10 views x 16, "
                          "c5 ragged 2-10 views x 64)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline leg (no opt-in / A-B / extra-config / pyramid / E2E / input / CPU / eager legs): the command "
+                         "tools/collect_profiles.sh profiles, so that the per-kernel averages of rocprofv3 --stats are the headline's")
     ap.add_argument("--rotate", type=int, default=8, help="resident input batches cycled through the steps (>= 8 x 42 MB of "
                     "features outruns the 256 MB Infinity Cache, so the sampling front end is timed cold)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_e2e = args.no_extra_configs = True
+        args.cpu_samples = 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
 
@@ -423,7 +429,7 @@ def main():
             res["roofline"].update(kernel="vecattn_split_kernel", peak=F16_MFMA_PEAK_TFLOPS / 3.0,
                                    frac=res["roofline"]["achieved"] / (F16_MFMA_PEAK_TFLOPS / 3.0), traffic=None,
                                    note="peak = dense f16 MFMA peak / 3 (three MFMAs per fp32-equivalent product)")
-    elif C >= 128 and not parametric and world == 1:
+    elif C >= 128 and not parametric and world == 1 and not args.headline_only:
         # OPT-IN split-precision leg, reported beside the headline (never as `value`): same step with
         # poem_set_precision(SPLIT_F16X3); distance of its vertices from the fp32 path's on the same batch.
         try:
@@ -466,7 +472,7 @@ def main():
                                                 "everything else fp32; the headline `value` is the exact-fp32 default"}
         except Exception as e:
             res["split_f16x3_scope"] = {"error": repr(e)[:200]}
-    if world == 1 and args.precision == "fp32" and args.anchor_tables:
+    if world == 1 and args.precision == "fp32" and args.anchor_tables and not args.headline_only:
         # the same step with block 0's positional products evaluated per sample, term by term as the reference does
         # (poem_set_anchor_tables(0)): what the anchor tables buy, and how far the two forms are apart on this batch
         try:
@@ -514,7 +520,7 @@ def main():
             except Exception as e:   # informational: never fail the bench line on it
                 extras[name] = {"error": repr(e)[:200]}
         res["extra_configs"] = extras
-    if world == 1 and not args.views_range and not parametric:
+    if world == 1 and not args.views_range and not parametric and not args.headline_only:
         # one stage earlier (SURVEY 8f rows N1 + N2): backbone pyramid -> feat_decode / heatmap_stage -> DLT -> head.  The
         # HRNet backbone itself is out of scope; its output pyramid is synthetic.  Reported beside the headline, never as it.
         try:

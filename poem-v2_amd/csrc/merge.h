@@ -4,7 +4,7 @@
 
 struct SampleMergeArgs {
   const float* xt;            // (views, hw, C): input_proj + positional table, channel-LAST
-  const float4* tab;          // (views, S, 2): per projected point the four bilinear weights | four tap byte offsets (pix * C * 4)
+  const float4* tab;          // (views, S, 2): per projected point the four bilinear weights | four tap pixels, 16 bits each, in two dwords (+ two unused)
   const int* view_sample;     // (views)  view -> sample
   const int* offs;            // (B + 1)  sample -> first view
   const float4* w0; const float* b0;   // merge_net_feature.0.0, packed (C x C)

@@ -82,6 +82,22 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
   const unsigned CC4 = (unsigned)(C * C * 4);
   const int q = lane / LPP, cg = lane % LPP;
 
+  // The per-point table entries of a tile (NIT points per thread, 32 B each) are requested one tile ahead, right before the
+  // short second GEMM of the previous tile: the fill then starts with its tap loads instead of two dependent L2 trips.
+  float4 tw[NIT];
+  uint2 to[NIT];                          // tap pixels, 16 bits each: (nw | ne << 16, sw | se << 16)
+  auto load_table = [&](int w) {
+    const int v = xcd + 8 * (w / TPV), t = w % TPV;
+    const float4* tb = A.tab + ((size_t)v * A.S + (size_t)(t % NSEG) * C) * 2;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int k = i * PPI + wv * PPW + q;
+      tw[i] = tb[2 * k];
+      to[i] = *reinterpret_cast<const uint2*>(tb + 2 * k + 1);
+    }
+  };
+  if (slot < nv * TPV) load_table(slot);
+
   for (int w = slot; w < nv * TPV; w += L) {
     const int v = xcd + 8 * (w / TPV), t = w % TPV;
     const int c0 = (t / NSEG) * XS, seg = t % NSEG;
@@ -89,36 +105,42 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
     // ---- fill: X0[k][row] = bilinear sample of plane (v, c0 + row) at point seg*C + k
     {
       const __amdgpu_buffer_rsrc_t xrs = frag_rsrc(A.xt + (size_t)v * A.hw * C, (unsigned)(A.hw * C * 4));
-      const float4* tb = A.tab + ((size_t)v * A.S + (size_t)seg * C) * 2;
       const int loff = (c0 + 4 * cg) * 4;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        float4 tw[NIT / 2];
-        int4 to[NIT / 2];
-#pragma unroll
-        for (int i = 0; i < NIT / 2; ++i) {
-          const int k = (half * (NIT / 2) + i) * PPI + wv * PPW + q;
-          tw[i] = tb[2 * k];
-          const float4 o = tb[2 * k + 1];
-          to[i] = make_int4(__float_as_int(o.x), __float_as_int(o.y), __float_as_int(o.z), __float_as_int(o.w));
-        }
-#pragma unroll
-        for (int i = 0; i < NIT / 2; ++i) {
-          const int k = (half * (NIT / 2) + i) * PPI + wv * PPW + q;
-          const float4 nw = frag_load(xrs, to[i].x + loff, 0), ne = frag_load(xrs, to[i].y + loff, 0);
-          const float4 sw = frag_load(xrs, to[i].z + loff, 0), se = frag_load(xrs, to[i].w + loff, 0);
-          float* xo = X0 + k * XSP + 4 * cg;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // the accumulation order of ATen's grid_sampler_2d (nw, ne, sw, se), as sample.hip's grid_sample_kernel
-            float a = (&nw.x)[e] * tw[i].x;
-            a = fmaf((&ne.x)[e], tw[i].y, a);
-            a = fmaf((&sw.x)[e], tw[i].z, a);
-            a = fmaf((&se.x)[e], tw[i].w, a);
-            xo[e] = a;
-          }
-        }
+      // software pipeline, DEPTH point-iterations of tap loads in flight (16 registers each; the table entries free theirs as
+      // they are consumed): the scheduling barriers keep hipcc from hoisting all 4 * NIT loads and spilling
+#ifndef POEM_SM_DEPTH
+#define POEM_SM_DEPTH 3
+#endif
+      constexpr int DEPTH = POEM_SM_DEPTH;
+      constexpr unsigned PIXB = C * 4;        // bytes per pixel of the channel-last planes
+      float4 tap[DEPTH][4];
+#define SM_TAPS(I)                                                                               \
+      {                                                                                          \
+        tap[(I) % DEPTH][0] = frag_load(xrs, (int)((to[I].x & 0xffffu) * PIXB) + loff, 0);       \
+        tap[(I) % DEPTH][1] = frag_load(xrs, (int)((to[I].x >> 16) * PIXB) + loff, 0);           \
+        tap[(I) % DEPTH][2] = frag_load(xrs, (int)((to[I].y & 0xffffu) * PIXB) + loff, 0);       \
+        tap[(I) % DEPTH][3] = frag_load(xrs, (int)((to[I].y >> 16) * PIXB) + loff, 0);           \
       }
+#pragma unroll
+      for (int i = 0; i < DEPTH - 1; ++i) SM_TAPS(i)
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        if (i + DEPTH - 1 < NIT) SM_TAPS(i + DEPTH - 1)
+        __builtin_amdgcn_sched_barrier(0);
+        const int k = i * PPI + wv * PPW + q;
+        float* xo = X0 + k * XSP + 4 * cg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // the accumulation order of ATen's grid_sampler_2d (nw, ne, sw, se), as sample.hip's grid_sample_kernel
+          float a = (&tap[i % DEPTH][0].x)[e] * tw[i].x;
+          a = fmaf((&tap[i % DEPTH][1].x)[e], tw[i].y, a);
+          a = fmaf((&tap[i % DEPTH][2].x)[e], tw[i].z, a);
+          a = fmaf((&tap[i % DEPTH][3].x)[e], tw[i].w, a);
+          xo[e] = a;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef SM_TAPS
     }
     __syncthreads();
     // ---- q1: the rows with n == 0 leave as they are (residual of the merge)
@@ -142,6 +164,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
       acc_to_lds<TPW, P, XSP>(acc, X0, wv * TPW, 0, j, h);
     }
     __syncthreads();
+    load_table(w + L < nv * TPV ? w + L : w);   // unconditional: a conditional definition would keep the consumed entries live through the GEMMs
     // ---- merge_net[0].2: C/64 output tiles x P column tiles = one (tile, p) per wave
     {
       const int t2 = wv / P, p2 = wv % P;
@@ -208,26 +231,37 @@ __global__ __launch_bounds__(NW * 64, 2) void merge_tail_kernel(MergeTailArgs A)
 #pragma unroll
         for (int i = 0; i < F4; ++i) acc[i] = mast[i];
       }
-      for (int n = 1; n < N; ++n) {
-        const float4* hp = rowp(r0 + n);
-        float4 v[F4];
-        float dot = 0.f;
+      // the other views, four rows' loads in flight (a row's dot product needs the whole row: one load at a time would
+      // serialise N - 1 HBM round trips per point); the sum runs in view order
+      constexpr int UN = 4;
+      for (int n0 = 1; n0 < N; n0 += UN) {
+        float4 v[UN][F4];
 #pragma unroll
-        for (int i = 0; i < F4; ++i) {
-          v[i] = hp[l16 + 16 * i];
-          dot = fmaf(v[i].x, mast[i].x, dot);
-          dot = fmaf(v[i].y, mast[i].y, dot);
-          dot = fmaf(v[i].z, mast[i].z, dot);
-          dot = fmaf(v[i].w, mast[i].w, dot);
+        for (int u = 0; u < UN; ++u) {
+          const float4* hp = rowp(r0 + min(n0 + u, N - 1));
+#pragma unroll
+          for (int i = 0; i < F4; ++i) v[u][i] = hp[l16 + 16 * i];
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        for (int u = 0; u < UN; ++u) {
+          if (n0 + u >= N) break;
+          float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < F4; ++i) {
-          acc[i].x = fmaf(dot, v[i].x, acc[i].x);
-          acc[i].y = fmaf(dot, v[i].y, acc[i].y);
-          acc[i].z = fmaf(dot, v[i].z, acc[i].z);
-          acc[i].w = fmaf(dot, v[i].w, acc[i].w);
+          for (int i = 0; i < F4; ++i) {
+            dot = fmaf(v[u][i].x, mast[i].x, dot);
+            dot = fmaf(v[u][i].y, mast[i].y, dot);
+            dot = fmaf(v[u][i].z, mast[i].z, dot);
+            dot = fmaf(v[u][i].w, mast[i].w, dot);
+          }
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+#pragma unroll
+          for (int i = 0; i < F4; ++i) {
+            acc[i].x = fmaf(dot, v[u][i].x, acc[i].x);
+            acc[i].y = fmaf(dot, v[u][i].y, acc[i].y);
+            acc[i].z = fmaf(dot, v[u][i].z, acc[i].z);
+            acc[i].w = fmaf(dot, v[u][i].w, acc[i].w);
+          }
         }
       }
 #pragma unroll
@@ -312,11 +346,10 @@ __global__ void project_table_kernel(const float* __restrict__ bps, const float*
   const float w_sw = (vx0 && vy1) ? wx0 * wy1 : 0.f, w_se = (vx1 && vy1) ? wx1 * wy1 : 0.f;
   const int cx0 = min(max(x0, 0), fw - 1), cx1 = min(max(x1, 0), fw - 1);
   const int cy0 = min(max(y0, 0), fh - 1), cy1 = min(max(y1, 0), fh - 1);
-  const int sc = C * 4;
   float4* o = tab + ((size_t)v * S + s) * 2;
   o[0] = make_float4(w_nw, w_ne, w_sw, w_se);
-  o[1] = make_float4(__int_as_float((cy0 * fw + cx0) * sc), __int_as_float((cy0 * fw + cx1) * sc),
-                     __int_as_float((cy1 * fw + cx0) * sc), __int_as_float((cy1 * fw + cx1) * sc));
+  o[1] = make_float4(__uint_as_float((unsigned)(cy0 * fw + cx0) | ((unsigned)(cy0 * fw + cx1) << 16)),
+                     __uint_as_float((unsigned)(cy1 * fw + cx0) | ((unsigned)(cy1 * fw + cx1) << 16)), 0.f, 0.f);
 }
 
 static int g_cus = 0;
@@ -365,7 +398,7 @@ static hipError_t launch_merge_tail_t(const MergeTailArgs& a, hipStream_t s) {
 
 // Shapes the fused front end serves: the chain widths, segments that tile the point axis, 64-point tail tiles.
 extern "C" int poem_sample_merge_supported(int C, int S, int hw) {
-  return (C == 128 || C == 256 || C == 512) && S % C == 0 && S % 64 == 0 && (long)hw * C * 4 < (1l << 31);
+  return (C == 128 || C == 256 || C == 512) && S % C == 0 && S % 64 == 0 && hw <= 65536 && (long)hw * C * 4 < (1l << 31);
 }
 
 extern "C" hipError_t poem_launch_project_table(const float* bps, const float* centre, const int* view_sample, const float* intr,
