@@ -77,8 +77,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
   float* X0 = smem;                       // C * XSP
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
   const int NSEG = A.S / C, TPV = (C / XS) * NSEG;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, L = gridDim.x >> 3;
-  const int nv = (A.views - xcd + 7) >> 3;          // views xcd, xcd + 8, ... belong to this XCD's blocks
+  // Work order.  XCD-aware (views spread evenly over the 8 XCDs: a multiple of 8, or many): the blocks of XCD x = blockIdx % 8
+  // walk the tiles of views x, x + 8, ... together; otherwise (a handful of views) plain round-robin over all tiles.
+  const bool by_xcd = (A.views % 8 == 0) || A.views >= 64;
+  const int xcd = by_xcd ? (int)(blockIdx.x & 7) : 0, vstep = by_xcd ? 8 : 1;
+  const int slot = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, L = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int nv = by_xcd ? (A.views - xcd + 7) >> 3 : A.views;          // views xcd, xcd + vstep, ... belong to this block's list
   const unsigned CC4 = (unsigned)(C * C * 4);
   const int q = lane / LPP, cg = lane % LPP;
 
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
   float4 tw[NIT];
   uint2 to[NIT];                          // tap pixels, 16 bits each: (nw | ne << 16, sw | se << 16)
   auto load_table = [&](int w) {
-    const int v = xcd + 8 * (w / TPV), t = w % TPV;
+    const int v = xcd + vstep * (w / TPV), t = w % TPV;
     const float4* tb = A.tab + ((size_t)v * A.S + (size_t)(t % NSEG) * C) * 2;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
   if (slot < nv * TPV) load_table(slot);
 
   for (int w = slot; w < nv * TPV; w += L) {
-    const int v = xcd + 8 * (w / TPV), t = w % TPV;
+    const int v = xcd + vstep * (w / TPV), t = w % TPV;
     const int c0 = (t / NSEG) * XS, seg = t % NSEG;
     __syncthreads();                          // the previous tile's readers of X0
     // ---- fill: X0[k][row] = bilinear sample of plane (v, c0 + row) at point seg*C + k

@@ -99,10 +99,89 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
   }
 }
 
+// The same product for the path's input_proj shape (hw % 128 == 0, K * 512 B of LDS): a block owns 128 pixels of one view
+// and stages their K feature rows in LDS ONCE (80 KB at K = 160) instead of every channel tile's wave streaming them from
+// L2 with dependent 4-byte loads; wave w computes channel tiles w, w + NW, ... x 128 pixels with the packed weight
+// fragments as A (1 KiB wave loads) and conflict-free LDS row reads as B.  Same k-ordered fma chain per output element.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __restrict__ feat, const float4* __restrict__ Wp,
+                                                             const float* __restrict__ bias, const float* __restrict__ table,
+                                                             const int* __restrict__ pe_index, float* __restrict__ x,
+                                                             float* __restrict__ xt, int views, int K, int C, int hw) {
+  extern __shared__ __attribute__((aligned(16))) float ftile[];    // K * 128
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int pgroups = hw / 128;
+  const int v = blockIdx.x / pgroups, pg = blockIdx.x % pgroups;
+  const int KC = K >> 3, ctiles = C / 32;
+  {
+    const float* src = feat + (size_t)v * K * hw + pg * 128;
+    for (int i = tid; i < K * 32; i += NW * 64) {
+      const int k = i >> 5, c4 = i & 31;
+      reinterpret_cast<float4*>(ftile)[i] = *reinterpret_cast<const float4*>(src + (size_t)k * hw + 4 * c4);
+    }
+  }
+  __syncthreads();
+  const float* tab = table ? table + (size_t)pe_index[v] * C * hw : nullptr;
+  const float* fb = ftile + (4 * h) * 128 + r;
+  for (int ct = wv; ct < ctiles; ct += NW) {
+    const float4* wp = Wp + (size_t)ct * KC * 64 + lane;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    float4 a = wp[0];
+    for (int kc = 0; kc < KC; ++kc) {
+      const float4 an = wp[(size_t)min(kc + 1, KC - 1) * 64];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float* row = fb + (kc * 8 + t) * 128;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) acc[pt] = mfma32((&a.x)[t], row[pt * 32], acc[pt]);
+      }
+      a = an;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = ct * 32 + mfma_row(i, h);
+      const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        const int p = pg * 128 + pt * 32 + r;
+        float val = acc[pt][i] + bv;
+        if (tab) val += tab[(size_t)c * hw + p];
+        acc[pt][i] = val;
+        if (x) x[((size_t)v * C + c) * hw + p] = val;
+      }
+    }
+    if (xt) {
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        float* dst = xt + ((size_t)v * hw + pg * 128 + pt * 32 + r) * C + ct * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(acc[pt][4 * g], acc[pt][4 * g + 1], acc[pt][4 * g + 2], acc[pt][4 * g + 3]);
+      }
+    }
+  }
+}
+
 extern "C" hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, const float* bias, const float* table,
                                           const int* pe_index, float* x, float* xt, int views, int K, int C, int hw,
                                           hipStream_t s) {
   const int ctiles = (C + 31) / 32;
+  if (hw % 128 == 0 && C % 32 == 0 && K % 8 == 0 && (size_t)K * 512 <= 96 * 1024 && ((uintptr_t)feat & 15) == 0) {
+    const size_t lds = (size_t)K * 512;
+    const int nw = ctiles >= 8 ? 8 : 4;
+    auto kern = nw == 8 ? conv1x1_lds_kernel<8> : conv1x1_lds_kernel<4>;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[nw == 8]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e != hipSuccess) return e;
+      attr_done[nw == 8] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(views * (hw / 128))), dim3(nw * 64), lds, s, feat, (const float4*)Wp, bias, table,
+                       pe_index, x, xt, views, K, C, hw);
+    return hipGetLastError();
+  }
   if (hw % 128 == 0) {
     const long waves = (long)views * ctiles * (hw / 128);
     hipLaunchKernelGGL((conv1x1_kernel<4>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, feat, (const float4*)Wp,
