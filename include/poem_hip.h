@@ -140,7 +140,9 @@ int poem_set_chains(poem_handle_t h, int enable);
  * F.grid_sample + the Q1 view + merge_features_mv / _sv (lib/models/heads/ptEmb_head.py:900-926,745-771) as the two kernels of
  * csrc/merge.hip -- the sampled tensor (sum N, C, S) and merge_net[0]'s hidden layer never reach HBM, the debug tap "g"
  * does not exist; 0 = the operator sequence (poem_project_sample, poem_gemm x4, poem_merge_reduce / _finalize), same
- * results to fp32 round-off (the cross-view dot products reduce in another order).  Unknown names return POEM_E_ARG. */
+ * results to fp32 round-off (the cross-view dot products reduce in another order); "chain_combine" (default 1, chain mode,
+ * 4 heads): the chain kernel behind a cross attention merges the attention's split-key partials while it fills its tile
+ * instead of a separate combine launch writing the context rows (bit-identical).  Unknown names return POEM_E_ARG. */
 int poem_set_option(poem_handle_t h, const char* name, int value);
 /* Block-0 anchor tables of poem_head_forward (default on, fp32 mode).  In the first decoder block every query's
  * neighbours are the 32 fixed anchors (anchor_points, lib/models/bricks/point_transformers.py:10-32) and every sample's

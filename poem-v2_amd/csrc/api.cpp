@@ -52,6 +52,9 @@ hipError_t poem_launch_gemm_segs(const float* X, int ldx, const void* Wp, const 
 hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, int q_batch_rows, const void* kimg, const void* vimg,
                                             float* ctx, int B, int NQ, int NK, int C, int heads, float* scratch, hipStream_t s);
 int poem_chain_supported(int C);
+int poem_chain_combines(int C, int heads, int chunks);
+void poem_cross_attention_partials(int B, int NQ, int NK, int C, int heads, float* scratch, const void** part_o,
+                                   const void** part_ml, int* chunks, float* kc2);
 hipError_t poem_launch_chain(const ChainArgs* a, int C, hipStream_t s);
 hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS, hipStream_t s);
 hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
@@ -265,6 +268,7 @@ struct poem_handle_s {
   // Fused sampling front end (merge.hip): sampling + Q1 + merge MLP in two kernels, g / h1 never in HBM (fp32 mode, C in
   // {128,256,512}); 0 = the operator sequence of sample.hip + gemm.hip.
   bool fused_sampling = true;
+  bool chain_combine = true;   // chain kind A combines the cross attention's split-key partials itself (no attn_combine launch)
   bool knn_early = true;     // chain mode: issue block i+1's neighbour searches right behind block i's coordinate update
   hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {};
   bool overlap = true;
@@ -533,18 +537,31 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     if (chain) {
       const int a1 = bb + B_A1, a2 = bb + B_A2;
       if (ov) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
-      HIPCHK(poem_launch_cross_attention_imgq(q0, 2 * C, q_batch, p.y1[i], p.y1[i] + (size_t)BS * C, p.ctx, B, Q, S, C, c.heads,
-                                              p.attn_scratch, s));
+      // the chain combines the attention's split-key partials while it fills its tile (no attn_combine launch, no ctx round trip)
+      const void *part_o = nullptr, *part_ml = nullptr;
+      int pchunks = 0;
+      float pkc2 = 0.f;
+      poem_cross_attention_partials(B, Q, S, C, c.heads, p.attn_scratch, &part_o, &part_ml, &pchunks, &pkc2);
+      const bool comb = h->chain_combine && poem_chain_combines(C, c.heads, pchunks) != 0;
+      auto from_partials = [&](ChainArgs& a) {
+        if (!comb) return;
+        a.x = nullptr; a.part_o = (const float4*)part_o; a.part_ml = (const float2*)part_ml;
+        a.pc_heads = c.heads; a.pc_chunks = pchunks; a.pc_nq = Q; a.pc_kc2 = pkc2;
+      };
+      HIPCHK(poem_launch_cross_attention_imgq(q0, 2 * C, q_batch, p.y1[i], p.y1[i] + (size_t)BS * C, comb ? nullptr : p.ctx, B, Q, S,
+                                              C, c.heads, p.attn_scratch, s));
       ChainArgs ca{};
       ca.kind = 0; ca.M = BQ; ca.x = p.ctx; ca.ldx = C;
+      from_partials(ca);
       ca.w1 = (const float4*)h->P(a1 + 6); ca.b1 = h->R(a1 + 7); ca.res = hidden; ca.ldres = ldh; ca.res_mod = hidden_mod;
       ca.ln_g = h->R(a1 + 8); ca.ln_b = h->R(a1 + 9); ca.eps = c.ln_eps; ca.y1 = p.h_attn; ca.ldy1 = C;
       ca.w2 = (const float4*)h->P(a2 + 0); ca.b2 = h->R(a2 + 1); ca.n2 = 1; ca.y2 = p.qp; ca.ldy2 = C;
       HIPCHK(poem_launch_chain(&ca, C, s));
-      HIPCHK(poem_launch_cross_attention_imgq(p.qp, C, Q, p.y1[i] + (size_t)2 * BS * C, p.y1[i] + (size_t)3 * BS * C, p.ctx, B, Q,
-                                              S, C, c.heads, p.attn_scratch, s));
+      HIPCHK(poem_launch_cross_attention_imgq(p.qp, C, Q, p.y1[i] + (size_t)2 * BS * C, p.y1[i] + (size_t)3 * BS * C,
+                                              comb ? nullptr : p.ctx, B, Q, S, C, c.heads, p.attn_scratch, s));
       ChainArgs cb{};
       cb.kind = 0; cb.M = BQ; cb.x = p.ctx; cb.ldx = C;
+      from_partials(cb);
       cb.w1 = (const float4*)h->P(a2 + 6); cb.b1 = h->R(a2 + 7); cb.res = p.h_attn; cb.ldres = C; cb.res_mod = 0;
       cb.ln_g = h->R(a2 + 8); cb.ln_b = h->R(a2 + 9); cb.eps = c.ln_eps; cb.y1 = p.h_cross[i]; cb.ldy1 = C;
       // F3: (w_qs | w_ks | w_vs) o fc1 on h_cross; block 0 on the tables needs qg for every row and (kg | v) for the anchor rows only
@@ -1004,6 +1021,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "chains") h->chains = value != 0;
   else if (k == "knn_early") h->knn_early = value != 0;
   else if (k == "fused_sampling") h->fused_sampling = value != 0;
+  else if (k == "chain_combine") h->chain_combine = value != 0;
   else return POEM_E_ARG;
   return POEM_OK;
 }

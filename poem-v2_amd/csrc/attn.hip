@@ -637,6 +637,18 @@ extern "C" void poem_cross_attention_split(int on) { g_xattn_split = on; }
 extern "C" hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, int q_batch_rows, const void* kimg,
                                                        const void* vimg, float* ctx, int B, int NQ, int NK, int C,
                                                        int heads, float* scratch, hipStream_t s);
+// Where poem_launch_cross_attention_imgq leaves its split-key partials inside `scratch` (ctx == nullptr there skips the
+// combine launch: the consumer -- chain.hip kind A -- combines them while it fills its activation tile).
+extern "C" void poem_cross_attention_partials(int B, int NQ, int NK, int C, int heads, float* scratch, const void** part_o,
+                                              const void** part_ml, int* chunks, float* kc2) {
+  const int dh = C / heads, nqt = (NQ + 31) / 32, DT = (dh + 31) / 32;
+  *chunks = (NK / 32) / attn_tiles_per_chunk(NK, dh);
+  const size_t items = (size_t)B * heads * (size_t)*chunks * nqt;
+  *part_o = scratch;
+  *part_ml = scratch + items * (size_t)DT * 4 * 64 * 4;
+  *kc2 = (float)(1.4426950408889634 / sqrt((double)dh));
+}
+
 extern "C" hipError_t poem_launch_cross_attention_img(const float* q, int ldq, const void* kimg, const void* vimg,
                                                       float* ctx, int B, int NQ, int NK, int C, int heads,
                                                       float* scratch, hipStream_t s) {
@@ -663,12 +675,12 @@ extern "C" hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, 
 #define POEM_XATTN(D, WV)                                                                                         \
   hipLaunchKernelGGL((xattn_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, qbr, (const float4*)kimg,        \
                      (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map, prio_rot); \
-  hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
+  if (ctx) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
 #define POEM_XSTREAM(D, WV)                                                                                        \
   hipLaunchKernelGGL((xattn_stream_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, qbr, (const float4*)kimg,   \
                      (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map);           \
-  hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
+  if (ctx) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
   int wsel = 0, map = 1, prio_rot = 0;
   (void)wsel;

@@ -6,6 +6,11 @@ struct ChainArgs {
   int kind;                  // 0 = A, 1 = C, 2 = D1, 3 = D2
   int M;                     // rows
   const float* x; int ldx;   // chain input (M, C)
+  // kind A, x == nullptr: the chain input is the cross attention's context, combined here from the attention kernel's
+  // split-key partials (attn.hip: part_o fragment images + (m, l) per row) instead of by a separate attn_combine launch
+  const float4* part_o; const float2* part_ml;
+  int pc_heads, pc_chunks, pc_nq;            // heads, key chunks (<= 4), queries per sample
+  float pc_kc2;                              // log2(e) / sqrt(head dim)
   const float4* w1; const float* b1;            // first Linear (C x C packed)
   const float* res; int ldres; int res_mod;     // residual rows (row % res_mod when res_mod > 0: one copy shared by all samples)
   const float* ln_g; const float* ln_b; float eps;   // kind A: LayerNorm after the first Linear

@@ -165,6 +165,66 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain_ke
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int row0 = item * XS;
     __syncthreads();                          // the previous item's readers of X0 / X1
+    if (KIND == 0 && A.x == nullptr) {
+      // ---- fill X0 with the cross attention's context, combined from the split-key partials (attn_combine_kernel's
+      // arithmetic, same order: w_s = 2^((m_s - M) kc2), ctx = sum_s w_s O_s / sum_s w_s l_s).  Lanes run along the rows:
+      // row r of query tile qt is lane r (+32 for the odd float4 of a channel octet) of a partial's fragment image, so a
+      // wave's 16-byte loads are contiguous.
+      constexpr int RS = NT / XS, DH4 = C / 4, HEADS = 4;      // row sets; float4 groups per row; heads (checked at launch)
+      constexpr int G = DH4 / (HEADS * RS), DT = C / HEADS / 32;   // groups per (thread, head); channel tiles per head
+      static_assert(G >= 1 && DH4 % (HEADS * RS) == 0 && DT >= 1, "shape");
+      const int rr = tid % XS, cgw = tid / XS;
+      const int i = min(row0 + rr, A.M - 1);
+      const int b = i / A.pc_nq, q = i % A.pc_nq, qt = q >> 5, r = q & 31;
+      const int nqt = (A.pc_nq + 31) >> 5, nch = A.pc_chunks;
+      // (m, l) of every (head, chunk) of this row: all loads first
+      float2 ml[HEADS][4];
+#pragma unroll
+      for (int hd = 0; hd < HEADS; ++hd)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          ml[hd][s] = A.part_ml[(((size_t)(b * HEADS + hd) * nch + min(s, nch - 1)) * nqt + qt) * 32 + r];
+      float w[HEADS][4], rden[HEADS];
+#pragma unroll
+      for (int hd = 0; hd < HEADS; ++hd) {
+        float mx = ml[hd][0].x;
+#pragma unroll
+        for (int s = 1; s < 4; ++s) mx = fmaxf(mx, ml[hd][s].x);
+        float den = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          w[hd][s] = s < nch ? ((ml[hd][s].x == mx) ? 1.0f : __builtin_amdgcn_exp2f((ml[hd][s].x - mx) * A.pc_kc2)) : 0.f;
+          den = s < nch ? fmaf(w[hd][s], ml[hd][s].y, den) : den;
+        }
+        rden[hd] = den;
+      }
+      // the partial outputs, one head (G groups x 4 chunks of 16-byte loads) in flight at a time
+#pragma unroll
+      for (int hd = 0; hd < HEADS; ++hd) {
+        float4 p[G][4];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          const int cg4 = hd * (DH4 / HEADS) + cgw + RS * gi;
+          const int d = (cg4 >> 3) % DT, g = (cg4 & 7) >> 1, hh = cg4 & 1;
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            p[gi][s] = A.part_o[((((size_t)(b * HEADS + hd) * nch + min(s, nch - 1)) * nqt + qt) * (DT * 4) + d * 4 + g) * 64 + r + 32 * hh];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          const int cg4 = hd * (DH4 / HEADS) + cgw + RS * gi;
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc.x = fmaf(w[hd][s], p[gi][s].x, acc.x); acc.y = fmaf(w[hd][s], p[gi][s].y, acc.y);
+            acc.z = fmaf(w[hd][s], p[gi][s].z, acc.z); acc.w = fmaf(w[hd][s], p[gi][s].w, acc.w);
+          }
+          float* xo = X0 + (4 * cg4) * XSP + rr;
+          xo[0] = acc.x / rden[hd]; xo[XSP] = acc.y / rden[hd]; xo[2 * XSP] = acc.z / rden[hd]; xo[3 * XSP] = acc.w / rden[hd];
+        }
+      }
+    } else
     // ---- fill X0 with the input tile, transposed: consecutive threads read consecutive channels of one row
     {
       static_assert(NT % C == 0 || C % NT == 0, "threads and channels must nest");
@@ -295,6 +355,8 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
 // Widths the chain kernel serves (two activation tiles of kind D must fit the CU's 160 KB of LDS); the caller keeps the
 // launch-per-operator path for the others (C = 32, 64: tiny test shapes; C = 1024).
 extern "C" int poem_chain_supported(int C) { return C == 128 || C == 256 || C == 512; }
+// kind A can take the cross attention's split-key partials as its input (ChainArgs::part_o) for 4 heads and <= 4 key chunks
+extern "C" int poem_chain_combines(int C, int heads, int chunks) { return poem_chain_supported(C) && heads == 4 && chunks >= 1 && chunks <= 4; }
 
 extern "C" hipError_t poem_launch_chain(const ChainArgs* a, int C, hipStream_t s) {
   switch (C) {
