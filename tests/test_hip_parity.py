@@ -605,6 +605,41 @@ def test_ragged_views_and_batch_independence():
         assert torch.equal(one[:, 0], full[:, i])
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+def test_projections_outside_the_image_and_behind_the_camera(fused):
+    """grid_sample's zero padding and the |z| < 1e-7 clamp of the projection (ptEmb_head.py:880-883,900): views that see the
+    hand only partly (taps with one, two or no valid corner), not at all, or from behind (negative depth), mixed with normal
+    ones in a ragged batch -- both front ends (sample.hip's clamped taps with zero weights, merge.hip's weight / pixel table)
+    against the oracle's F.grid_sample, at the sampling stage's output and at the final vertices."""
+    spec = dict(embed=128, nsample=4096, views=[4, 1, 3], seed=33, parametric=False)
+    cfg, w, consts, batch = case_setup(spec)
+    m = batch["img_metas"]
+    K, E = m["cam_intr"].clone(), m["cam_extr"].clone()
+    K[1, 0, 2] += 200.0                       # principal point shifted: the hand straddles the right image border
+    K[2, 1, 2] -= 150.0                       # ... and the top border
+    K[3, 0, 2] += 2000.0                      # nothing inside the image: every tap is padding
+    E[5] = E[5] @ torch.diag(torch.tensor([-1.0, 1.0, -1.0, 1.0]))      # camera turned round: the hand is behind it (z < 0)
+    K[6, 0, 0] = K[6, 1, 1] = 2000.0          # long lens: a few pixels of the map cover the whole ball
+    m["cam_intr"], m["cam_extr"] = K.contiguous(), E.contiguous()
+    taps = {}
+    orc = run_oracle(cfg, w, consts, batch, taps=taps)["all_coords_preds"]
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    eng = head._engine_for(torch.device(DEV))
+    eng.enable_taps(True)
+    eng.set_option("fused_sampling", fused)
+    with torch.no_grad():
+        got = head(feat, metas, rj)["all_coords_preds"].cpu()
+    bf = eng.tap("bps_feat", (3, 4096, 128)).cpu()
+    assert torch.isfinite(bf).all() and torch.isfinite(got).all()
+    assert _md(bf, taps["bps_feat"]) < 2e-5 * max(1.0, float(taps["bps_feat"].abs().max()))
+    assert float(torch.norm(got[-1] - orc[-1], dim=-1).mean()) < 1e-6
+    # the all-padding view really contributes zeros: its sampled planes vanish in the operator sequence's tensor
+    if not fused:
+        g = eng.tap("g", (8, 128, 4096)).cpu()
+        assert float(g[3].abs().max()) == 0.0 and float(g[0].abs().max()) > 0.0
+
+
 def test_errors_are_loud():
     head = pk.build_head(__import__("util").head_cfg(128), data_preset=pk.CN({}))
     b = pk.inputs.synthetic_batch([2], seed=0)
