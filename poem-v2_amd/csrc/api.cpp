@@ -268,6 +268,7 @@ struct poem_handle_s {
   // Fused sampling front end (merge.hip): sampling + Q1 + merge MLP in two kernels, g / h1 never in HBM (fp32 mode, C in
   // {128,256,512}); 0 = the operator sequence of sample.hip + gemm.hip.
   bool fused_sampling = true;
+  bool tables_first = true;    // the fused sampling kernel starts behind the anchor-table build (see poem_head_forward)
   bool chain_combine = true;   // chain kind A combines the cross attention's split-key partials itself (no attn_combine launch)
   bool knn_early = true;     // chain mode: issue block i+1's neighbour searches right behind block i's coordinate update
   hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {};
@@ -1022,6 +1023,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "knn_early") h->knn_early = value != 0;
   else if (k == "fused_sampling") h->fused_sampling = value != 0;
   else if (k == "chain_combine") h->chain_combine = value != 0;
+  else if (k == "tables_first") h->tables_first = value != 0;
   else return POEM_E_ARG;
   return POEM_OK;
 }
@@ -1429,6 +1431,12 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
     sm.xt = p.xt; sm.tab = (const float4*)p.ptab; sm.view_sample = p.view_sample; sm.offs = p.offs;
     sm.w0 = (const float4*)h->P(T_M00_W); sm.b0 = h->R(T_M00_B); sm.w1 = (const float4*)h->P(T_M02_W); sm.b1 = h->R(T_M02_B);
     sm.h2 = p.h2; sm.q1 = p.q1; sm.views = BN; sm.S = S; sm.hw = HW; sm.h2_tiled = 1;
+    // The anchor-table build on the neighbour-search stream holds 68 KB of LDS per block, and next to the MFMA-dense
+    // sample_merge waves its blocks linger: a CU that hosts one takes a single sample_merge block (2 x 66.5 KB no longer
+    // fit) and the persistent grid runs in two rounds -- 2.55 instead of 1.69 ms in a third of the forwards.  The build
+    // overlaps input_proj / the projection; sample_merge waits for it (+0.06 ms on the critical path, always).
+    if (h->tables_first && h->anchor_tables && h->precision == POEM_PRECISION_FP32 && h->overlap && h->bps_stream && h->knn_stream)
+      HIPCHK(hipStreamWaitEvent(s, h->ev_tab, 0));
     HIPCHK(poem_launch_sample_merge(&sm, C, s));
     MergeTailArgs mt{};
     mt.h2 = p.h2; mt.q1 = p.q1; mt.offs = p.offs;

@@ -16,8 +16,6 @@
 // point contiguously (256 B).  Then, exactly like the chain kernels (chain.hip): Linear(C, C) + ReLU with the packed
 // weights streamed from L2, result back into LDS, Linear(C, C/2), h2 tile to HBM.  The rows with n == 0 (r % N == 0)
 // are also written out (q1: the residual term), 1/N of the sampled values.
-//   Work order: blocks of one XCD (blockIdx % 8) walk the tiles of the same view, so a view's 256 KB of planes and its
-// 128 KB table are fetched into that XCD's L2 once.
 //   h2 is written tile-major: [(view * tiles_per_view + tile) * XS + row-in-tile][C/2] -- a block's 64 rows are one
 // contiguous 32 KB instead of 64 rows 8 KB apart.
 //
@@ -77,12 +75,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
   float* X0 = smem;                       // C * XSP
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
   const int NSEG = A.S / C, TPV = (C / XS) * NSEG;
-  // Work order.  XCD-aware (views spread evenly over the 8 XCDs: a multiple of 8, or many): the blocks of XCD x = blockIdx % 8
-  // walk the tiles of views x, x + 8, ... together; otherwise (a handful of views) plain round-robin over all tiles.
-  const bool by_xcd = (A.views % 8 == 0) || A.views >= 64;
-  const int xcd = by_xcd ? (int)(blockIdx.x & 7) : 0, vstep = by_xcd ? 8 : 1;
-  const int slot = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, L = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-  const int nv = by_xcd ? (A.views - xcd + 7) >> 3 : A.views;          // views xcd, xcd + vstep, ... belong to this block's list
+  // Work order: plain round-robin over (view, tile) -- the resident blocks work on a handful of views at a time, whose planes
+  // and tables (384 KB per view) stay in every XCD's L2.  (An XCD-aware order -- the blocks of XCD x = blockIdx % 8 walking
+  // the views x, x + 8, ... -- measured 1 % slower.)
+  const int slot = (int)blockIdx.x, L = (int)gridDim.x;
+  const int nv = A.views;
   const unsigned CC4 = (unsigned)(C * C * 4);
   const int q = lane / LPP, cg = lane % LPP;
 
@@ -91,7 +88,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
   float4 tw[NIT];
   uint2 to[NIT];                          // tap pixels, 16 bits each: (nw | ne << 16, sw | se << 16)
   auto load_table = [&](int w) {
-    const int v = xcd + vstep * (w / TPV), t = w % TPV;
+    const int v = w / TPV, t = w % TPV;
     const float4* tb = A.tab + ((size_t)v * A.S + (size_t)(t % NSEG) * C) * 2;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
@@ -103,7 +100,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
   if (slot < nv * TPV) load_table(slot);
 
   for (int w = slot; w < nv * TPV; w += L) {
-    const int v = xcd + vstep * (w / TPV), t = w % TPV;
+    const int v = w / TPV, t = w % TPV;
     const int c0 = (t / NSEG) * XS, seg = t % NSEG;
     __syncthreads();                          // the previous tile's readers of X0
     // ---- fill: X0[k][row] = bilinear sample of plane (v, c0 + row) at point seg*C + k
@@ -379,8 +376,7 @@ static hipError_t launch_sample_merge_t(const SampleMergeArgs& a, hipStream_t s)
   }
   const int tpv = (C / XS) * (a.S / C);
   const long items = (long)a.views * tpv;
-  long grid = std::min<long>(items, (long)cu_count() * 2);
-  grid = std::max<long>(8, (grid + 7) / 8 * 8);        // the XCD-aware work order needs a multiple of 8 blocks
+  const long grid = std::min<long>(items, (long)cu_count() * 2);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
 }
