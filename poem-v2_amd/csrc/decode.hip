@@ -91,10 +91,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args A) {
 #pragma unroll
     for (int p = 0; p < PT; ++p) acc[c][p] = zero16();
   const int wbase = (cg * CT) * 9 * KC * 1024;        // bytes
-  // Two-stage software pipeline over the KC * 9 (8-channel chunk, tap) steps with pinned order (sched_barrier): the
-  // operands of step q+1 are in flight while the 4*CT*PT MFMAs of step q issue.  Chunk-major: the nine taps of a chunk
-  // touch the same 8 planes x 3 rows (6 KB per wave) back to back, so eight of nine hit L1 -- tap-major swept all Cin
-  // planes per tap (95 KB per wave at Cin = 120) and every tap went back to HBM (PMC: 5.2 GB read for a 0.5 GB input).
+  // Two-stage software pipeline over the 9 * KC (tap, 8-channel chunk) steps with pinned order (sched_barrier): the
+  // operands of step q+1 are in flight while the 4*CT*PT MFMAs of step q issue.
   const int total = 9 * KC;
   int tap = 0, cc = 0, q = 0;
   float4 a0[CT], a1[CT];
@@ -107,7 +105,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args A) {
     _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                 \
       _Pragma("unroll") for (int p = 0; p < PT; ++p)                                                              \
         B[p][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoff[p], soff_ + t * plane * 4, 0)); \
-    if (q + 1 < total) { ++q; if (++tap == 9) { tap = 0; ++cc; } }   /* saturates on the last step */              \
+    if (q + 1 < total) { ++q; if (++cc == KC) { cc = 0; ++tap; } }   /* saturates on the last step */              \
   }
 #define POEM_CMMA(A, B)                                                                                           \
   _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                   \
