@@ -311,29 +311,40 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
     }
     __syncthreads();
   } else if (COMP) {
-    // ---- GEMM 1: pos = W_d2 h (+ b_d2 below)
-    chain_gemm<C, P, NW, TPW, false>(A.wd2, X, pos, wv, lane);
+    // ---- GEMM 1: pos = W_d2 h + b_d2, with the operands SWAPPED (as GEMM 3): the composed form needs pos only in the
+    // softmax-sum at the end, whose layout is lane = channel, registers = neighbours -- exactly what the swapped product
+    // leaves, so the [c'][j] -> [j][c'] transpose through LDS (32 LDS instructions per tile) disappears.  Same products, same
+    // k order: the same values.
+    chain_gemm<C, P, NW, TPW, true>(A.wd2, X, pos, wv, lane);
     VA_STAMP(2);
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) {
-      const int cbase = (wv * TPW + tp) * 32 + 4 * h;
+      const float bch = A.bd2[(wv * TPW + tp) * 32 + j];       // this lane's channel
+      const f32x2 bb2 = {bch, bch};
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bb = *reinterpret_cast<const float4*>(A.bd2 + cbase + 8 * g);
+      for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const float4 qq = MODE == 1 ? float4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const float4*>(qs + p * C + cbase + 8 * g);
+        for (int i = 0; i < 16; i += 2) {
+          const f32x2 pv = f32x2{pos[tp][p][i], pos[tp][p][i + 1]} + bb2;
+          pos[tp][p][i] = pv[0]; pos[tp][p][i + 1] = pv[1];
+        }
+    }
+    if (MODE != 1) {
 #pragma unroll
-          for (int e = 0; e < 4; e += 2) {      // register pairs -> v_pk_add_f32
-            const int i = 4 * g + e;
-            const f32x2 pv = f32x2{pos[tp][p][i], pos[tp][p][i + 1]} + f32x2{(&bb.x)[e], (&bb.x)[e + 1]};
-            pos[tp][p][i] = pv[0]; pos[tp][p][i + 1] = pv[1];
-            if (MODE != 1) {
+      for (int tp = 0; tp < TPW; ++tp) {
+        const int cbase = (wv * TPW + tp) * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            const float4 qq = *reinterpret_cast<const float4*>(qs + p * C + cbase + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {      // register pairs -> v_pk_add_f32
+              const int i = 4 * g + e;
               const f32x2 tv = f32x2{(&qq.x)[e], (&qq.x)[e + 1]} - f32x2{acc[tp][p][i], acc[tp][p][i + 1]};
               acc[tp][p][i] = tv[0]; acc[tp][p][i + 1] = tv[1];
             }
           }
-        }
       }
     }
     VA_STAMP(3);
@@ -345,24 +356,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       // both products leave as fragment images: 16 registers per lane = four 1 KiB wave stores per (tile, query)
       float4* tg = A.tab_g + ((size_t)ig * NTILE + wv * TPW) * (P * 4 * 64) + lane;
       float4* tq = A.tab_p + ((size_t)ig * NTILE + wv * TPW) * (P * 4 * 64) + lane;
-      float* scr1 = X + wv * (32 * 33);
 #pragma unroll
       for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) scr1[j * 33 + mfma_row(i, h)] = pos[tp][p][i];   // [c'][j] -> [j][c']
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          float pt[16];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) pt[i] = scr1[mfma_row(i, h) * 33 + j];
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int p = 0; p < P; ++p)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             tg[((tp * P + p) * 4 + g) * 64] = float4{acc[tp][p][4 * g], acc[tp][p][4 * g + 1], acc[tp][p][4 * g + 2], acc[tp][p][4 * g + 3]};
-            tq[((tp * P + p) * 4 + g) * 64] = float4{pt[4 * g], pt[4 * g + 1], pt[4 * g + 2], pt[4 * g + 3]};
+            tq[((tp * P + p) * 4 + g) * 64] = float4{pos[tp][p][4 * g], pos[tp][p][4 * g + 1], pos[tp][p][4 * g + 2], pos[tp][p][4 * g + 3]};
           }
-        }
       continue;
     }
 #pragma unroll
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   VA_STAMP(5);
   chain_gemm<C, P, NW, TPW, true>(A.wg2, X, acc, wv, lane);
   VA_STAMP(6);
-  if (MODE != 2) __syncthreads();   // X is dead from here on: reuse it as per-wave transpose scratch
+  if (!COMP) __syncthreads();   // plain form: X is dead from here on and serves as per-wave transpose scratch for pos
 
   // Softmax over the 32 neighbours (registers x 2 half-waves) and the weighted sum, written for instruction count --
   // every VALU instruction here comes out of the matrix pipe's time (tools/lab/phase_lab):
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       // pos tile [c'][j] (lane = neighbour) -> [j][c'] (lane = channel) through the wave-private scratch
-      if (MODE != 2) {
+      if (!COMP) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) scr[j * 33 + mfma_row(i, h)] = pos[tp][p][i];
       }
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       float pt[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pt[i] = MODE == 2 ? pos[tp][p][i] : scr[mfma_row(i, h) * 33 + j];
+      for (int i = 0; i < 16; ++i) pt[i] = COMP ? pos[tp][p][i] : scr[mfma_row(i, h) * 33 + j];
       f32x16& a = acc[tp][p];
       float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
 #pragma unroll
