@@ -142,7 +142,9 @@ int poem_set_chains(poem_handle_t h, int enable);
  * does not exist; 0 = the operator sequence (poem_project_sample, poem_gemm x4, poem_merge_reduce / _finalize), same
  * results to fp32 round-off (the cross-view dot products reduce in another order); "chain_combine" (default 1, chain mode,
  * 4 heads): the chain kernel behind a cross attention merges the attention's split-key partials while it fills its tile
- * instead of a separate combine launch writing the context rows (bit-identical).  Unknown names return POEM_E_ARG. */
+ * instead of a separate combine launch writing the context rows (bit-identical); "tables_first" (default 1): the fused
+ * sampling kernel is ordered behind the block-0 anchor-table build of the neighbour-search stream (a CU that hosts a table
+ * block takes one sampling block instead of two; results unaffected).  Unknown names return POEM_E_ARG. */
 int poem_set_option(poem_handle_t h, const char* name, int value);
 /* Block-0 anchor tables of poem_head_forward (default on, fp32 mode).  In the first decoder block every query's
  * neighbours are the 32 fixed anchors (anchor_points, lib/models/bricks/point_transformers.py:10-32) and every sample's
