@@ -150,6 +150,94 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args A) {
   }
 }
 
+// Stride-1 variant with the input staged in LDS (the three uv_decode convolutions: 9 x Cin x Cout x H x W = 177 M
+// multiply-adds per view each).  The direct kernel above re-reads its input for every tap and every channel-tile group
+// through caches that do not hold it (PMC: 5.2 GB fetched for the 0.5 GB input of the 120 -> 40 layer).  Here a block of 8
+// waves owns 256 raster-consecutive output pixels (256 / W rows) of one view and ALL output channels: per 8-channel chunk
+// the (rows + 2) x (W + 2) halo of the zero-bordered input -- contiguous in memory per channel -- is copied to LDS once
+// (double-buffered: the next chunk's loads are in flight during the MFMAs), every tap of every wave reads it from there
+// (lane = pixel: conflict-free), and the input leaves HBM (rows + 2) / rows times instead of nine times per channel-tile
+// group.  Chunk-major accumulation (for each chunk the nine taps) -- the direct kernel sums tap-major; both are within the
+// fp32 round-off the tests allow against the reference.
+template <int CT>
+__global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];      // 2 x 8 x trows x Wp
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int W = A.W, Wp = A.W + 2, Hp = A.H + 2, plane = Hp * Wp, KC = A.Cin / 8;
+  const int TR = 256 / W, rblocks = A.H / TR;
+  const int rb = (int)(blockIdx.x % rblocks), n = (int)(blockIdx.x / rblocks);
+  const int y0 = rb * TR, tplane = (TR + 2) * Wp, chunk_floats = 8 * tplane;
+  const int pix = wv * 32 + j, py = pix / W, px = pix % W;
+  const float* src = A.in + (size_t)n * A.Cin * plane + (size_t)y0 * Wp;
+  const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(A.wp, 0xffffffffu);
+  constexpr int MAXLD = 7;                 // staged floats per thread and chunk: 8 * 396 / 512
+  float st[MAXLD];
+  int soff[MAXLD];                         // source offset of this thread's u-th staged float inside a chunk (divisions once)
+#pragma unroll
+  for (int u = 0; u < MAXLD; ++u) {
+    const int i = min(tid + 512 * u, chunk_floats - 1);
+    soff[u] = (i / tplane) * plane + i % tplane;
+  }
+  auto stage_load = [&](int cc) {
+    const float* sc = src + (size_t)(8 * cc) * plane;
+#pragma unroll
+    for (int u = 0; u < MAXLD; ++u) st[u] = sc[soff[u]];
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < MAXLD; ++u) {
+      const int i = tid + 512 * u;
+      if (i < chunk_floats) tile[buf * chunk_floats + i] = st[u];
+    }
+  };
+  f32x16 acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) acc[c] = zero16();
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  const int boff = (4 * h) * tplane + py * Wp + px;
+  for (int cc = 0; cc < KC; ++cc) {
+    if (cc + 1 < KC) stage_load(cc + 1);
+    const float* tb = tile + (cc & 1) * chunk_floats + boff;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      float4 a[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) a[c] = frag_load(wrs, lane * 16, ((c * 9 + tap) * KC + cc) * 1024);
+      const int toff = (tap / 3) * Wp + (tap % 3);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float b = tb[t * tplane + toff];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[c] = mfma32((&a[c].x)[t], b, acc[c]);
+      }
+    }
+    if (cc + 1 < KC) stage_store((cc + 1) & 1);
+    __syncthreads();
+  }
+  // epilogue: affine (conv bias + BatchNorm), ReLU, lateral add; lane = pixel, register e = channel 8(e>>2) + 4h + (e&3)
+  const int Ho = A.H, Wo = A.W, oy = y0 + py;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const int cbase = c * 32 + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 sc = *reinterpret_cast<const float4*>(A.scale + cbase + 8 * g);
+      const float4 sh = *reinterpret_cast<const float4*>(A.shift + cbase + 8 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = cbase + 8 * g + e;
+        if (co >= A.Cout) continue;
+        float v = fmaf(acc[c][4 * g + e], (&sc.x)[e], (&sh.x)[e]);
+        if (A.relu) v = fmaxf(v, 0.f);
+        if (A.res) v += A.res[((size_t)n * A.Cout + co) * (Ho * Wo) + oy * Wo + px];
+        A.out[(size_t)n * A.out_ns + (size_t)co * A.out_cs + oy * A.out_rs + px + A.out_off] = v;
+      }
+    }
+  }
+}
+
 // in (views, Cin, H+2, W+2) zero-bordered; out element strides as in Conv3Args.  stride 1 or 2, H, W even,
 // (H/stride)*(W/stride) % 32 == 0, Cin % 8 == 0.
 extern "C" hipError_t poem_launch_conv3x3(const float* in, const void* wp, const float* scale, const float* shift,
@@ -162,6 +250,21 @@ extern "C" hipError_t poem_launch_conv3x3(const float* in, const void* wp, const
   if ((size_t)Cin * (H + 2) * (W + 2) * 4 >= (1ull << 31)) return hipErrorInvalidValue;
   Conv3Args a{in, (const float4*)wp, scale, shift, res, out, Cin, Cout, H, W, stride, relu, out_ns, out_cs, out_rs, out_off, views};
   const int cot = (Cout + 31) / 32, ptiles = Ho * Wo / 32;
+  if (stride == 1 && cot <= 5 && W <= 64 && 256 % W == 0 && H % (256 / W) == 0 && 8 * (256 / W + 2) * (W + 2) <= 7 * 512) {
+    const int TR = 256 / W;
+    const size_t lds = (size_t)2 * 8 * (TR + 2) * (W + 2) * sizeof(float);
+    const dim3 grid((unsigned)(views * (H / TR))), block(512);
+#define POEM_CONVL(CTV) hipLaunchKernelGGL((conv3x3_lds_kernel<CTV>), grid, block, lds, s, a)
+    switch (cot) {
+      case 1: POEM_CONVL(1); break;
+      case 2: POEM_CONVL(2); break;
+      case 3: POEM_CONVL(3); break;
+      case 4: POEM_CONVL(4); break;
+      default: POEM_CONVL(5); break;
+    }
+#undef POEM_CONVL
+    return hipGetLastError();
+  }
   const int pt = (ptiles % 2 == 0) ? 2 : 1;
   const int ct = (cot % 5 == 0) ? 5 : (cot % 3 == 0) ? 3 : (cot % 2 == 0) ? 2 : 1;
   const long items = (long)views * (cot / ct) * (ptiles / pt);
