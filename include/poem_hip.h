@@ -279,6 +279,14 @@ int poem_conv3x3(const float* in_padded, const void* w_packed, const float* scal
                  int64_t out_view_stride, int out_ch_stride, int out_row_stride, int out_offset, void* stream);
 int poem_upsample2_concat_pad(const float* a, int ca, const float* b, int cb, float* out, int views, int h, int w, int pad,
                               void* stream);
+/* One uv_decode stage in one launch (POEM.py:203-205: F.interpolate x2, torch.cat, ConvBlock): stride-1 conv3x3 of
+ * [bilinear x2 of a_half (views,ca,h/2,w/2) | b_full (views,cb,h,w)] with the concatenation, the zero border and the
+ * upsampling applied while the input halo is staged in LDS -- the concatenated tensor never exists.  Same epilogue and output
+ * addressing as poem_conv3x3.  POEM_E_UNSUPPORTED for shapes the LDS-staged kernel does not take (cout > 160, w > 64,
+ * 256 % w != 0, ...): call poem_upsample2_concat_pad + poem_conv3x3 then. */
+int poem_upcat_conv3x3(const float* a_half, int ca, const float* b_full, int cb, const void* w_packed, const float* scale,
+                       const float* shift, float* out, int views, int cout, int h, int w, int relu, int64_t out_view_stride,
+                       int out_ch_stride, int out_row_stride, int out_offset, void* stream);
 int poem_pool_conv1x1_sigmoid(const float* x, const float* w, const float* bias, float* heatmaps, int views, int c, int j,
                               int h, int w_, void* stream);
 /* Device-side evaluation metrics (replace the host loops of lib/metrics/pa_eval.py:45-83,104-124 and

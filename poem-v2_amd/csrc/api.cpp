@@ -98,6 +98,9 @@ hipError_t poem_launch_warp_affine(const unsigned char* src, const long long* sr
 hipError_t poem_launch_heatmap_uv(const float* hmap, float* uv, int maps, int hh, int hw, float img_w, float img_h,
                                   hipStream_t s);
 size_t poem_conv3x3_packed_floats(int Cout, int Cin);
+hipError_t poem_launch_upcat_conv3x3(const float* a_half, int Ca, const float* b_full, int Cb, const void* wp, const float* scale,
+                                     const float* shift, float* out, int views, int Cout, int H, int W, int relu, long out_ns,
+                                     int out_cs, int out_rs, int out_off, hipStream_t s);
 hipError_t poem_launch_pack_conv3x3(const float* w, int Cout, int Cin, void* out, hipStream_t s);
 hipError_t poem_launch_conv3x3(const float* in, const void* wp, const float* scale, const float* shift, const float* res,
                                float* out, int views, int Cin, int Cout, int H, int W, int stride, int relu, long out_ns,
@@ -1263,6 +1266,18 @@ int poem_conv3x3(const float* in_padded, const void* w_packed, const float* scal
     return POEM_E_UNSUPPORTED;
   HIPCHK(poem_launch_conv3x3(in_padded, w_packed, scale, shift, residual, out, views, cin, cout, h, w, stride, relu,
                              (long)out_view_stride, out_ch_stride, out_row_stride, out_offset, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_upcat_conv3x3(const float* a_half, int ca, const float* b_full, int cb, const void* w_packed, const float* scale,
+                       const float* shift, float* out, int views, int cout, int h, int w, int relu, int64_t out_view_stride,
+                       int out_ch_stride, int out_row_stride, int out_offset, void* stream) {
+  if ((!a_half && ca) || (!b_full && cb) || !w_packed || !scale || !shift || !out || views <= 0 || cout <= 0 || h <= 0 || w <= 0)
+    return POEM_E_ARG;
+  const hipError_t e = poem_launch_upcat_conv3x3(a_half, ca, b_full, cb, w_packed, scale, shift, out, views, cout, h, w, relu,
+                                                 (long)out_view_stride, out_ch_stride, out_row_stride, out_offset, (hipStream_t)stream);
+  if (e == hipErrorNotSupported) return POEM_E_UNSUPPORTED;
+  HIPCHK(e);
   return POEM_OK;
 }
 

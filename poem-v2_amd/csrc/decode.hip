@@ -59,6 +59,11 @@ struct Conv3Args {
   long out_ns;
   int out_cs, out_rs, out_off;
   int views;
+  // fused input (conv3x3_lds_kernel<CT, true>): in = [bilinear x2 of up_a (views, Ca, H/2, W/2) | skip_b (views, Cb, H, W)]
+  // with the zero border applied while the halo is staged -- the concatenated tensor never exists
+  const float* up_a;
+  const float* skip_b;
+  int Ca, Cb;
 };
 
 template <int CT, int PT>
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args A) {
 // (lane = pixel: conflict-free), and the input leaves HBM (rows + 2) / rows times instead of nine times per channel-tile
 // group.  Chunk-major accumulation (for each chunk the nine taps) -- the direct kernel sums tap-major; both are within the
 // fp32 round-off the tests allow against the reference.
-template <int CT>
+template <int CT, bool UPCAT>
 __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
   extern __shared__ __attribute__((aligned(16))) float tile[];      // 2 x 8 x trows x Wp
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
@@ -168,20 +173,59 @@ __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
   const int rb = (int)(blockIdx.x % rblocks), n = (int)(blockIdx.x / rblocks);
   const int y0 = rb * TR, tplane = (TR + 2) * Wp, chunk_floats = 8 * tplane;
   const int pix = wv * 32 + j, py = pix / W, px = pix % W;
-  const float* src = A.in + (size_t)n * A.Cin * plane + (size_t)y0 * Wp;
+  const float* src = UPCAT ? nullptr : A.in + (size_t)n * A.Cin * plane + (size_t)y0 * Wp;
   const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(A.wp, 0xffffffffu);
   constexpr int MAXLD = 7;                 // staged floats per thread and chunk: 8 * 396 / 512
   float st[MAXLD];
-  int soff[MAXLD];                         // source offset of this thread's u-th staged float inside a chunk (divisions once)
+  // per staged float of a chunk (the same for every chunk): plain input -> source offset; fused input -> the bilinear
+  // taps of F.interpolate(scale_factor=2, align_corners=False) (upcat_pad_kernel's arithmetic) and the skip tensor's offset
+  int soff[MAXLD], sob[MAXLD];
+  float sly[MAXLD], slx[MAXLD];
+  const int h2 = A.H / 2, w2 = A.W / 2;
 #pragma unroll
   for (int u = 0; u < MAXLD; ++u) {
     const int i = min(tid + 512 * u, chunk_floats - 1);
-    soff[u] = (i / tplane) * plane + i % tplane;
+    const int chl = i / tplane, o = i % tplane;
+    if (!UPCAT) {
+      soff[u] = chl * plane + o;
+      sob[u] = 0; sly[u] = 0.f; slx[u] = 0.f;
+    } else {
+      const int y = y0 + o / Wp - 1, x = o % Wp - 1;
+      const bool valid = y >= 0 && y < A.H && x >= 0 && x < W;
+      const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+      const int yy0 = (int)sy, xx0 = (int)sx;
+      const int yy1 = min(yy0 + 1, h2 - 1), xx1 = min(xx0 + 1, w2 - 1);
+      sly[u] = sy - (float)yy0;
+      slx[u] = sx - (float)xx0;
+      soff[u] = valid ? ((yy0 * w2 + xx0) | (chl << 20) | ((xx1 - xx0) << 23) | ((yy1 - yy0) << 24) | (1 << 25)) : (chl << 20);
+      sob[u] = valid ? y * W + x : 0;
+    }
   }
   auto stage_load = [&](int cc) {
-    const float* sc = src + (size_t)(8 * cc) * plane;
+    if (!UPCAT) {
+      const float* sc = src + (size_t)(8 * cc) * plane;
 #pragma unroll
-    for (int u = 0; u < MAXLD; ++u) st[u] = sc[soff[u]];
+      for (int u = 0; u < MAXLD; ++u) st[u] = sc[soff[u]];
+    } else if (8 * cc < A.Ca) {
+      const float* pa = A.up_a + ((size_t)n * A.Ca + 8 * cc) * (h2 * w2);
+#pragma unroll
+      for (int u = 0; u < MAXLD; ++u) {
+        const int pk = soff[u];
+        const float* p = pa + ((pk >> 20) & 7) * (h2 * w2) + (pk & 0xfffff);
+        const int dx = (pk >> 23) & 1, dyw = ((pk >> 24) & 1) * w2;
+        const float ly = sly[u], lx = slx[u], hy = 1.f - ly, hx = 1.f - lx;
+        const float v = hy * (hx * p[0] + lx * p[dx]) + ly * (hx * p[dyw] + lx * p[dyw + dx]);      // upcat_pad_kernel's expression
+        st[u] = (pk >> 25) & 1 ? v : 0.f;
+      }
+    } else {
+      const float* pb = A.skip_b + ((size_t)n * A.Cb + (8 * cc - A.Ca)) * (A.H * W);
+#pragma unroll
+      for (int u = 0; u < MAXLD; ++u) {
+        const int pk = soff[u];
+        const float v = pb[((pk >> 20) & 7) * (A.H * W) + sob[u]];
+        st[u] = (pk >> 25) & 1 ? v : 0.f;
+      }
+    }
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
@@ -238,6 +282,40 @@ __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
   }
 }
 
+static bool conv3x3_lds_ok(int Cout, int H, int W) {
+  return (Cout + 31) / 32 <= 5 && W <= 64 && 256 % W == 0 && H % (256 / W) == 0 && 8 * (256 / W + 2) * (W + 2) <= 7 * 512;
+}
+
+template <bool UPCAT>
+static hipError_t launch_conv3x3_lds(const Conv3Args& a, hipStream_t s) {
+  const int TR = 256 / a.W, cot = (a.Cout + 31) / 32;
+  const size_t lds = (size_t)2 * 8 * (TR + 2) * (a.W + 2) * sizeof(float);
+  const dim3 grid((unsigned)(a.views * (a.H / TR))), block(512);
+#define POEM_CONVL(CTV) hipLaunchKernelGGL((conv3x3_lds_kernel<CTV, UPCAT>), grid, block, lds, s, a)
+  switch (cot) {
+    case 1: POEM_CONVL(1); break;
+    case 2: POEM_CONVL(2); break;
+    case 3: POEM_CONVL(3); break;
+    case 4: POEM_CONVL(4); break;
+    default: POEM_CONVL(5); break;
+  }
+#undef POEM_CONVL
+  return hipGetLastError();
+}
+
+// conv3x3(stride 1) of [bilinear x2 of a | b] without materialising the concatenated, bordered input.
+// hipErrorNotSupported: the caller runs poem_launch_upcat_pad + poem_launch_conv3x3 instead.
+extern "C" hipError_t poem_launch_upcat_conv3x3(const float* a_half, int Ca, const float* b_full, int Cb, const void* wp,
+                                                const float* scale, const float* shift, float* out, int views, int Cout,
+                                                int H, int W, int relu, long out_ns, int out_cs, int out_rs, int out_off,
+                                                hipStream_t s) {
+  if (Ca % 8 || Cb % 8 || Ca + Cb <= 0 || H % 2 || W % 2 || !conv3x3_lds_ok(Cout, H, W) || (long)(H / 2) * (W / 2) >= (1 << 20))
+    return hipErrorNotSupported;
+  Conv3Args a{nullptr, (const float4*)wp, scale, shift, nullptr, out, Ca + Cb, Cout, H, W, 1, relu, out_ns, out_cs, out_rs, out_off,
+              views, a_half, b_full, Ca, Cb};
+  return launch_conv3x3_lds<true>(a, s);
+}
+
 // in (views, Cin, H+2, W+2) zero-bordered; out element strides as in Conv3Args.  stride 1 or 2, H, W even,
 // (H/stride)*(W/stride) % 32 == 0, Cin % 8 == 0.
 extern "C" hipError_t poem_launch_conv3x3(const float* in, const void* wp, const float* scale, const float* shift,
@@ -248,23 +326,10 @@ extern "C" hipError_t poem_launch_conv3x3(const float* in, const void* wp, const
   const int Ho = H / stride, Wo = W / stride;
   if ((Ho * Wo) % 32) return hipErrorInvalidValue;
   if ((size_t)Cin * (H + 2) * (W + 2) * 4 >= (1ull << 31)) return hipErrorInvalidValue;
-  Conv3Args a{in, (const float4*)wp, scale, shift, res, out, Cin, Cout, H, W, stride, relu, out_ns, out_cs, out_rs, out_off, views};
+  Conv3Args a{in, (const float4*)wp, scale, shift, res, out, Cin, Cout, H, W, stride, relu, out_ns, out_cs, out_rs, out_off, views,
+              nullptr, nullptr, 0, 0};
   const int cot = (Cout + 31) / 32, ptiles = Ho * Wo / 32;
-  if (stride == 1 && cot <= 5 && W <= 64 && 256 % W == 0 && H % (256 / W) == 0 && 8 * (256 / W + 2) * (W + 2) <= 7 * 512) {
-    const int TR = 256 / W;
-    const size_t lds = (size_t)2 * 8 * (TR + 2) * (W + 2) * sizeof(float);
-    const dim3 grid((unsigned)(views * (H / TR))), block(512);
-#define POEM_CONVL(CTV) hipLaunchKernelGGL((conv3x3_lds_kernel<CTV>), grid, block, lds, s, a)
-    switch (cot) {
-      case 1: POEM_CONVL(1); break;
-      case 2: POEM_CONVL(2); break;
-      case 3: POEM_CONVL(3); break;
-      case 4: POEM_CONVL(4); break;
-      default: POEM_CONVL(5); break;
-    }
-#undef POEM_CONVL
-    return hipGetLastError();
-  }
+  if (stride == 1 && conv3x3_lds_ok(Cout, H, W)) return launch_conv3x3_lds<false>(a, s);
   const int pt = (ptiles % 2 == 0) ? 2 : 1;
   const int ct = (cot % 5 == 0) ? 5 : (cot % 3 == 0) ? 3 : (cot % 2 == 0) ? 2 : 1;
   const long items = (long)views * (cot / ct) * (ptiles / pt);

@@ -50,6 +50,22 @@ class _Conv3x3:
                                          int(relu), ns, cs, rs, off, hip.stream()), "poem_conv3x3")
 
 
+def _conv_upcat(self, a, b, h, w, out, out_strides, relu=True):
+    """conv3x3 of [bilinear x2 of a | b] in one launch (poem_upcat_conv3x3); False when the shape is not taken."""
+    views = b.shape[0]
+    ns, cs, rs, off = out_strides
+    rc = hip.lib().poem_upcat_conv3x3(hip.ptr(a), int(a.shape[1]), hip.ptr(b), int(b.shape[1]), self.packed.data_ptr(),
+                                      hip.ptr(self.scale), hip.ptr(self.shift), hip.ptr(out), views, self.cout, h, w, int(relu),
+                                      ns, cs, rs, off, hip.stream())
+    if rc == hip.POEM_E_UNSUPPORTED:
+        return False
+    hip.check(rc, "poem_upcat_conv3x3")
+    return True
+
+
+_Conv3x3.upcat = _conv_upcat
+
+
 def _padded_strides(c, h, w):
     """strides of an (n, c, h+2, w+2) zero-bordered tensor addressed by interior (y, x)."""
     return (c * (h + 2) * (w + 2), (h + 2) * (w + 2), w + 2, (w + 2) + 1)
@@ -153,9 +169,10 @@ class FeatureDecoders:
             x, r = rev[0], rev[0].shape[-1]
             for i, conv in enumerate(self.uv_delayer):
                 r *= 2
-                xin = upsample2_concat_pad(x, rev[i + 1], r, r, 1)
-                x = torch.empty(views, conv.cout, r, r, dtype=torch.float32, device=self.device)
-                conv(xin, r, r, 1, x, _plain_strides(conv.cout, r, r))
+                y = torch.empty(views, conv.cout, r, r, dtype=torch.float32, device=self.device)
+                if not conv.upcat(x, rev[i + 1], r, r, y, _plain_strides(conv.cout, r, r)):     # one launch where the shape allows
+                    conv(upsample2_concat_pad(x, rev[i + 1], r, r, 1), r, r, 1, y, _plain_strides(conv.cout, r, r))
+                x = y
             hm = torch.empty(views, NUM_JOINTS, r // 2, r // 2, dtype=torch.float32, device=self.device)
             hip.check(hip.lib().poem_pool_conv1x1_sigmoid(hip.ptr(x), hip.ptr(self.uv_out_w), hip.ptr(self.uv_out_b),
                                                           hip.ptr(hm), views, int(x.shape[1]), NUM_JOINTS, r, r,

@@ -79,6 +79,7 @@ SIGNATURES = {
     "poem_pack_conv3x3": (_i, [_vp, _i, _i, _vp, _vp]),
     "poem_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp]),
     "poem_upsample2_concat_pad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "poem_upcat_conv3x3": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp]),
     "poem_pool_conv1x1_sigmoid": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_pa_epe": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "poem_mano_to_openpose": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
@@ -120,6 +121,9 @@ def lib():
             fn.argtypes = args
         _LIB = L
     return _LIB
+
+
+POEM_E_UNSUPPORTED = -4      # include/poem_hip.h
 
 
 def check(rc, what=""):
