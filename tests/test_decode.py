@@ -80,6 +80,40 @@ def test_conv3x3_operator(cin, cout, r, stride, relu, res):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ca,cb,cout,r", [(320, 160, 160, 16), (160, 80, 80, 32), (80, 40, 40, 64), (16, 8, 33, 16), (24, 16, 200, 16)])
+def test_upcat_conv3x3_matches_the_two_launch_sequence_and_torch(ca, cb, cout, r):
+    """poem_upcat_conv3x3 (one uv_decode stage in one launch: bilinear x2 | concat | zero border staged straight into the
+    LDS-staged convolution) against F.interpolate + torch.cat + the ConvBlock in fp64, and against the two-launch sequence
+    (poem_upsample2_concat_pad + poem_conv3x3) it replaces -- the three uv_decode shapes, a channel-tail shape, and a shape
+    the fused kernel does not take (cout > 160: the entry point says so and the caller falls back)."""
+    import torch.nn.functional as F
+    import poem_v2_amd as pk
+    g = torch.Generator().manual_seed(ca + cout)
+    views = 3
+    a, b = torch.randn(views, ca, r // 2, r // 2, generator=g), torch.randn(views, cb, r, r, generator=g)
+    cin = ca + cb
+    sd = {"c.conv.weight": torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5),
+          "c.conv.bias": 0.1 * torch.randn(cout, generator=g), "c.norm.weight": 1 + 0.2 * torch.randn(cout, generator=g),
+          "c.norm.bias": 0.1 * torch.randn(cout, generator=g), "c.norm.running_mean": 0.1 * torch.randn(cout, generator=g),
+          "c.norm.running_var": 0.5 + torch.rand(cout, generator=g)}
+    x = torch.cat((F.interpolate(a.double(), scale_factor=2, mode="bilinear", align_corners=False), b.double()), dim=1)
+    ref = do.conv_block(x, {k: v.double() for k, v in sd.items()}, "c", stride=1, relu=True)
+    conv = pk.decode._Conv3x3(sd, "c", torch.device(DEV))
+    two = torch.empty(views, cout, r, r, device=DEV)
+    conv(pk.decode.upsample2_concat_pad(a.to(DEV), b.to(DEV), r, r, 1), r, r, 1, two, pk.decode._plain_strides(cout, r, r))
+    one = torch.full((views, cout, r, r), float("nan"), device=DEV)
+    taken = conv.upcat(a.to(DEV), b.to(DEV), r, r, one, pk.decode._plain_strides(cout, r, r))
+    assert taken == (cout <= 160)
+    assert _md(two, ref) < 2e-5
+    if taken:
+        assert _md(one, ref) < 2e-5 and _md(one, two) < 2e-5
+        # ... and into a zero-bordered buffer, as the direct kernel can
+        onep = torch.zeros(views, cout, r + 2, r + 2, device=DEV)
+        assert conv.upcat(a.to(DEV), b.to(DEV), r, r, onep, pk.decode._padded_strides(cout, r, r))
+        assert _md(onep[:, :, 1:-1, 1:-1], ref) < 2e-5 and float(onep[:, :, 0].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 def test_upsample_concat_matches_torch():
     import torch.nn.functional as F
     import poem_v2_amd as pk
