@@ -605,6 +605,32 @@ def test_ragged_views_and_batch_independence():
         assert torch.equal(one[:, 0], full[:, i])
 
 
+@pytest.mark.parametrize("embed", [128, 256])
+def test_fused_sampling_every_view_count(embed):
+    """Q1 makes the merge address memory by r = s * N + n across (view, channel, segment) planes, so every view count has its
+    own pattern of rows with n == 0, of rows that straddle planes and of tiles that straddle samples: one sample of each
+    N = 1 .. 10 in one batch, fused front end against the oracle's sampling stage and against the operator sequence."""
+    spec = dict(embed=embed, nsample=4096, views=[7, 1, 10, 3, 2, 9, 5, 4, 8, 6], seed=77, parametric=False)
+    cfg, w, consts, batch = case_setup(spec)
+    taps = {}
+    orc = run_oracle(cfg, w, consts, batch, taps=taps)["all_coords_preds"]
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    eng = head._engine_for(torch.device(DEV))
+    eng.enable_taps(True)
+    bf = {}
+    for mode in (1, 0):
+        eng.set_option("fused_sampling", mode)
+        with torch.no_grad():
+            got = head(feat, metas, rj)["all_coords_preds"].cpu()
+        bf[mode] = eng.tap("bps_feat", (10, 4096, embed)).cpu()
+        scale = max(1.0, float(taps["bps_feat"].abs().max()))
+        per_sample = (bf[mode] - taps["bps_feat"]).abs().amax(dim=(1, 2))
+        assert float(per_sample.max()) < 2e-5 * scale, (mode, per_sample)
+        assert float(torch.norm(got[-1] - orc[-1], dim=-1).mean()) < 1e-6
+    assert _md(bf[1], bf[0]) < 1e-5 * scale
+
+
 @pytest.mark.parametrize("fused", [1, 0])
 def test_projections_outside_the_image_and_behind_the_camera(fused):
     """grid_sample's zero padding and the |z| < 1e-7 clamp of the projection (ptEmb_head.py:880-883,900): views that see the
