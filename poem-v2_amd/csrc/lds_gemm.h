@@ -40,6 +40,36 @@ __device__ __forceinline__ void lds_gemm(const __amdgpu_buffer_rsrc_t wrs, int w
   CH_READX(xa, KCI, 2) __builtin_amdgcn_sched_barrier(0); CH_MMA(A, 1, xb, false) __builtin_amdgcn_sched_barrier(0); \
   CH_READX(xb, KCI, 3) __builtin_amdgcn_sched_barrier(0); CH_MMA(A, 2, xa, false) __builtin_amdgcn_sched_barrier(0); \
   CH_READX(xa, (KCI) + 1, 0) __builtin_amdgcn_sched_barrier(0); CH_MMA(A, 3, xb, false) __builtin_amdgcn_sched_barrier(0);
+  if constexpr (TPW * P <= 2) {
+    // Few MFMAs per k-step (TPW * P <= 2: 128 cycles): an X operand requested one step ahead is not back when its MFMAs
+    // are due (the ISA showed an s_waitcnt lgkmcnt in front of nearly every MFMA pair).  Four operand registers per column
+    // tile, one per k-step of a chunk; each is re-requested for the NEXT chunk right behind the MFMAs that read it: a whole
+    // chunk (4 k-steps) of MFMAs between an LDS read and its use.
+    float x0[P], x1[P], x2[P], x3[P];
+#define CH_CHUNK4(A, KCI, INIT)                                                             \
+    CH_MMA(A, 0, x0, INIT) __builtin_amdgcn_sched_barrier(0); CH_READX(x0, (KCI) + 1, 0) __builtin_amdgcn_sched_barrier(0);  \
+    CH_MMA(A, 1, x1, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x1, (KCI) + 1, 1) __builtin_amdgcn_sched_barrier(0); \
+    CH_MMA(A, 2, x2, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x2, (KCI) + 1, 2) __builtin_amdgcn_sched_barrier(0); \
+    CH_MMA(A, 3, x3, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x3, (KCI) + 1, 3) __builtin_amdgcn_sched_barrier(0);
+    CH_LOADW(a0, 0)
+    CH_READX(x0, 0, 0) CH_READX(x1, 0, 1) CH_READX(x2, 0, 2) CH_READX(x3, 0, 3)
+    CH_LOADW(a1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    CH_CHUNK4(a0, 0, INIT0)
+    CH_LOADW(a0, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    CH_CHUNK4(a1, 1, false)
+    for (int kc = 2; kc < KCH; kc += 2) {
+      CH_LOADW(a1, kc + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      CH_CHUNK4(a0, kc, false)
+      CH_LOADW(a0, kc + 2)
+      __builtin_amdgcn_sched_barrier(0);
+      CH_CHUNK4(a1, kc + 1, false)
+    }
+#undef CH_CHUNK4
+    return;
+  }
   CH_LOADW(a0, 0)
   CH_READX(xa, 0, 0)
   CH_LOADW(a1, 1)
