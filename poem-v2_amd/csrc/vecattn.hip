@@ -63,11 +63,10 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
   const int wbase = __builtin_amdgcn_readfirstlane(wv) * TPW * KC * 1024;      // bytes, wave-uniform
   const int loff = lane * 16;
   const float* xc = X + (4 * h) * XS + j;
-  // Two-stage software pipeline with pinned order (sched_barrier): the weight fragments of chunk kc+1 and the LDS
-  // operand of k-step t+1 are in flight while the MFMAs of k-step t issue.  Left to itself hipcc sinks every load to
+  // Software pipeline with pinned order (sched_barrier): the weight fragments of chunk kc+1 are in flight while the MFMAs
+  // of chunk kc issue, and the LDS operands run a whole chunk ahead (below).  Left to itself hipcc sinks every load to
   // its first use and the wave stalls on L2/LDS latency in front of each MFMA group.
   float4 a0[TPW], a1[TPW];
-  float xa[P], xb[P];
 #define VA_LOADW(A, KCI)                                                                  \
   {                                                                                       \
     const int kq_ = min((KCI), KC - 1);                                                   \
@@ -88,31 +87,33 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
       acc[tp][p] = FLIP ? mfma32(XR[p], av, c_) : mfma32(av, XR[p], c_);                  \
     }                                                                                     \
   }
-#define VA_CHUNK(A, KCI, INIT)                                                            \
-  VA_READX(xb, KCI, 1) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 0, xa, INIT) __builtin_amdgcn_sched_barrier(0); \
-  VA_READX(xa, KCI, 2) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 1, xb, false) __builtin_amdgcn_sched_barrier(0); \
-  VA_READX(xb, KCI, 3) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 2, xa, false) __builtin_amdgcn_sched_barrier(0); \
-  VA_READX(xa, (KCI) + 1, 0) __builtin_amdgcn_sched_barrier(0); VA_MMA(A, 3, xb, false) __builtin_amdgcn_sched_barrier(0);
+  // X operands a whole chunk ahead (one register set per k-step of a chunk, re-requested right behind the MFMAs that read it)
+  float x0[P], x1[P], x2[P], x3[P];
+#define VA_CHUNK4(A, KCI, INIT)                                                             \
+  VA_MMA(A, 0, x0, INIT) __builtin_amdgcn_sched_barrier(0); VA_READX(x0, (KCI) + 1, 0) __builtin_amdgcn_sched_barrier(0);  \
+  VA_MMA(A, 1, x1, false) __builtin_amdgcn_sched_barrier(0); VA_READX(x1, (KCI) + 1, 1) __builtin_amdgcn_sched_barrier(0); \
+  VA_MMA(A, 2, x2, false) __builtin_amdgcn_sched_barrier(0); VA_READX(x2, (KCI) + 1, 2) __builtin_amdgcn_sched_barrier(0); \
+  VA_MMA(A, 3, x3, false) __builtin_amdgcn_sched_barrier(0); VA_READX(x3, (KCI) + 1, 3) __builtin_amdgcn_sched_barrier(0);
   VA_LOADW(a0, 0)
-  VA_READX(xa, 0, 0)
+  VA_READX(x0, 0, 0) VA_READX(x1, 0, 1) VA_READX(x2, 0, 2) VA_READX(x3, 0, 3)
   VA_LOADW(a1, 1)
   __builtin_amdgcn_sched_barrier(0);
-  VA_CHUNK(a0, 0, INIT0)
+  VA_CHUNK4(a0, 0, INIT0)
   VA_LOADW(a0, 2)
   __builtin_amdgcn_sched_barrier(0);
-  VA_CHUNK(a1, 1, false)
+  VA_CHUNK4(a1, 1, false)
   for (int kc = 2; kc < KC; kc += 2) {
     VA_LOADW(a1, kc + 1)
     __builtin_amdgcn_sched_barrier(0);
-    VA_CHUNK(a0, kc, false)
+    VA_CHUNK4(a0, kc, false)
     VA_LOADW(a0, kc + 2)
     __builtin_amdgcn_sched_barrier(0);
-    VA_CHUNK(a1, kc + 1, false)
+    VA_CHUNK4(a1, kc + 1, false)
   }
+#undef VA_CHUNK4
 #undef VA_LOADW
 #undef VA_READX
 #undef VA_MMA
-#undef VA_CHUNK
 }
 
 // COMP (the decoder's form): W_g1 is linear, so W_g1 (q_i - k_j + pos_ij) + b_g1 = qg_i - kg_j + (W_g1 W_d2) h_ij with
