@@ -94,6 +94,24 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
   VA_MMA(A, 1, x1, false) __builtin_amdgcn_sched_barrier(0); VA_READX(x1, (KCI) + 1, 1) __builtin_amdgcn_sched_barrier(0); \
   VA_MMA(A, 2, x2, false) __builtin_amdgcn_sched_barrier(0); VA_READX(x2, (KCI) + 1, 2) __builtin_amdgcn_sched_barrier(0); \
   VA_MMA(A, 3, x3, false) __builtin_amdgcn_sched_barrier(0); VA_READX(x3, (KCI) + 1, 3) __builtin_amdgcn_sched_barrier(0);
+  if constexpr (TPW <= 2) {
+  // weight fragments three chunks ahead (ring of four; 16 more VGPRs at TPW = 2 -- wider waves keep the ring of two)
+  static_assert(KC % 4 == 0, "C must be a multiple of 32");
+  float4 a2[TPW], a3[TPW];
+  VA_LOADW(a0, 0)
+  VA_READX(x0, 0, 0) VA_READX(x1, 0, 1) VA_READX(x2, 0, 2) VA_READX(x3, 0, 3)
+  VA_LOADW(a1, 1)
+  VA_LOADW(a2, 2)
+  __builtin_amdgcn_sched_barrier(0);
+#define VA_GROUP(KC0, INIT)                                                   \
+  VA_LOADW(a3, (KC0) + 3) __builtin_amdgcn_sched_barrier(0); VA_CHUNK4(a0, (KC0), INIT)      \
+  VA_LOADW(a0, (KC0) + 4) __builtin_amdgcn_sched_barrier(0); VA_CHUNK4(a1, (KC0) + 1, false) \
+  VA_LOADW(a1, (KC0) + 5) __builtin_amdgcn_sched_barrier(0); VA_CHUNK4(a2, (KC0) + 2, false) \
+  VA_LOADW(a2, (KC0) + 6) __builtin_amdgcn_sched_barrier(0); VA_CHUNK4(a3, (KC0) + 3, false)
+  VA_GROUP(0, INIT0)
+  for (int kc = 4; kc < KC; kc += 4) { VA_GROUP(kc, false) }
+#undef VA_GROUP
+  } else {
   VA_LOADW(a0, 0)
   VA_READX(x0, 0, 0) VA_READX(x1, 0, 1) VA_READX(x2, 0, 2) VA_READX(x3, 0, 3)
   VA_LOADW(a1, 1)
@@ -109,6 +127,7 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
     VA_LOADW(a0, kc + 2)
     __builtin_amdgcn_sched_barrier(0);
     VA_CHUNK4(a1, kc + 1, false)
+  }
   }
 #undef VA_CHUNK4
 #undef VA_LOADW
