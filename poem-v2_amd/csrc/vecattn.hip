@@ -472,20 +472,29 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   float* scr = X + wv * (32 * 33);
   const float k2 = inv_sqrt_c * 1.44269504088896340736f;
   const __amdgpu_buffer_rsrc_t vrs = frag_rsrc(A.v, 0xffffffffu);
+  // The v_j gathers of tile q + 1 are issued before tile q's softmax: issued and consumed inside one tile, the L2 / HBM round
+  // trip of every tile's sixteen 4-byte gathers stood in front of its weighted sum (vmcnt(14) ... vmcnt(0) in the ISA).
+  float vgb[2][16];
+#define VA_GATHER(Q)                                                                                          \
+  {                                                                                                           \
+    const int tp_ = (Q) / P, p_ = (Q) % P, cch_ = (wv * TPW + tp_) * 32 + j;                                  \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                            \
+      vgb[(Q) & 1][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrs, voffs[p_ * 32 + mfma_row(i, h)] + cch_ * 4, 0, 0)); \
+  }
+  VA_GATHER(0)
 #pragma unroll
-  for (int tp = 0; tp < TPW; ++tp) {
+  for (int q = 0; q < TPW * P; ++q) {
+    const int tp = q / P, p = q % P;
     const int cch = (wv * TPW + tp) * 32 + j;   // this lane's output channel
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
+    {
       // pos tile [c'][j] (lane = neighbour) -> [j][c'] (lane = channel) through the wave-private scratch
       if (!COMP) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) scr[j * 33 + mfma_row(i, h)] = pos[tp][p][i];
       }
-      float vg[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        vg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrs, voffs[p * 32 + mfma_row(i, h)] + cch * 4, 0, 0));
+      if (q + 1 < TPW * P) VA_GATHER(q + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      const float (&vg)[16] = vgb[q & 1];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       float pt[16];
 #pragma unroll
@@ -513,6 +522,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
       if (h == 0 && i0 + p < A.Q) A.out[((size_t)b * A.Q + i0 + p) * C + cch] = res * __builtin_amdgcn_rcpf(sum);
     }
   }
+#undef VA_GATHER
   VA_STAMP(7);
   }   // item loop
 }
