@@ -51,6 +51,25 @@ __device__ __forceinline__ void lds_gemm(const __amdgpu_buffer_rsrc_t wrs, int w
     CH_MMA(A, 1, x1, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x1, (KCI) + 1, 1) __builtin_amdgcn_sched_barrier(0); \
     CH_MMA(A, 2, x2, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x2, (KCI) + 1, 2) __builtin_amdgcn_sched_barrier(0); \
     CH_MMA(A, 3, x3, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x3, (KCI) + 1, 3) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TPW * P == 1 && KCH % 4 == 0) {
+      // one MFMA per k-step: a chunk is 256 cycles of MFMAs, less than an L2 round trip -- weight fragments three chunks
+      // ahead (ring of four) instead of one
+      float4 a2[TPW], a3[TPW];
+      CH_LOADW(a0, 0)
+      CH_READX(x0, 0, 0) CH_READX(x1, 0, 1) CH_READX(x2, 0, 2) CH_READX(x3, 0, 3)
+      CH_LOADW(a1, 1)
+      CH_LOADW(a2, 2)
+      __builtin_amdgcn_sched_barrier(0);
+#define CH_GROUP(KC0, INIT)                                                                     \
+      CH_LOADW(a3, (KC0) + 3) __builtin_amdgcn_sched_barrier(0); CH_CHUNK4(a0, (KC0), INIT)      \
+      CH_LOADW(a0, (KC0) + 4) __builtin_amdgcn_sched_barrier(0); CH_CHUNK4(a1, (KC0) + 1, false) \
+      CH_LOADW(a1, (KC0) + 5) __builtin_amdgcn_sched_barrier(0); CH_CHUNK4(a2, (KC0) + 2, false) \
+      CH_LOADW(a2, (KC0) + 6) __builtin_amdgcn_sched_barrier(0); CH_CHUNK4(a3, (KC0) + 3, false)
+      CH_GROUP(0, INIT0)
+      for (int kc = 4; kc < KCH; kc += 4) { CH_GROUP(kc, false) }
+#undef CH_GROUP
+      return;
+    }
     CH_LOADW(a0, 0)
     CH_READX(x0, 0, 0) CH_READX(x1, 0, 1) CH_READX(x2, 0, 2) CH_READX(x3, 0, 3)
     CH_LOADW(a1, 1)
