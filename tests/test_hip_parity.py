@@ -494,6 +494,37 @@ def test_fused_sampling_vs_operator_sequence(name):
     assert mp(out[1], out[0]) < (1e-6 if "hot" in name else 2e-7)
 
 
+@pytest.mark.parametrize("embed,chains", [(128, 1), (256, 1), (256, 0), (512, 1)])
+def test_decoder_entry_with_caller_queries_vs_oracle(embed, chains):
+    """PtEmbedTRv4.forward / poem_decoder_forward (ptEmb_transformer.py:371-376): the decoder on the CALLER's query coordinates
+    and features -- per-sample, nothing like the head's shared template, so block 0 takes the per-sample form, the chains read
+    their residual rows per sample and no anchor table is used -- against the oracle's three decoder blocks on the same inputs."""
+    spec = dict(embed=embed, nsample=4096, views=[2, 2, 2], seed=5, parametric=False)
+    cfg, w, consts, _ = case_setup(spec)
+    head = build_hip_head(spec, DEV)
+    head.set_chains(bool(chains))
+    g = torch.Generator().manual_seed(embed)
+    B = 3
+    qxyz = torch.randn(B, 799, 3, generator=g) * 0.4
+    pxyz = torch.rand(B, 4096, 3, generator=g) * 2 - 1
+    qf, pf = torch.randn(B, 799, embed, generator=g), torch.randn(B, 4096, embed, generator=g)
+    with torch.no_grad():
+        got, pose, shape = head.transformer(qxyz.to(DEV), qf.to(DEV), pxyz.to(DEV), pf.to(DEV))
+        feats, xyz, ref = qf, qxyz, []
+        for i in range(cfg.nblocks):
+            feats, xyz, _, _ = po.decoder_block(w, cfg, i, xyz, feats, pxyz, pf, consts)
+            ref.append(xyz)
+    assert pose is None and shape is None
+    ref = torch.stack(ref)
+    got = got.cpu()
+    assert got.shape == ref.shape == (3, B, 799, 3)
+    for layer in range(3):
+        d = torch.norm(got[layer] - ref[layer], dim=-1)                 # normalised units (x 0.1 m)
+        # a query whose 32nd / 33rd neighbour distances tie at fp32 round-off may pick the other set in blocks 1, 2
+        df = d.flatten()
+        assert float(df.mean()) < 2e-5 and float(df.kthvalue(int(0.995 * df.numel())).values) < 1e-4, (layer, float(df.mean()), float(df.max()))
+
+
 def test_last_block_feed_forward_is_computed_only_when_read():
     """PtEmbedTRv4.forward returns the coordinate stack only (ptEmb_transformer.py:115-121,371-376): the last block's
     feed-forward output feeds nothing unless the parametric tail or a debug tap reads it, and the path does not compute
