@@ -51,9 +51,9 @@ __device__ __forceinline__ void lds_gemm(const __amdgpu_buffer_rsrc_t wrs, int w
     CH_MMA(A, 1, x1, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x1, (KCI) + 1, 1) __builtin_amdgcn_sched_barrier(0); \
     CH_MMA(A, 2, x2, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x2, (KCI) + 1, 2) __builtin_amdgcn_sched_barrier(0); \
     CH_MMA(A, 3, x3, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x3, (KCI) + 1, 3) __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TPW * P == 1 && KCH % 4 == 0) {
-      // one MFMA per k-step: a chunk is 256 cycles of MFMAs, less than an L2 round trip -- weight fragments three chunks
-      // ahead (ring of four) instead of one
+    if constexpr (KCH % 4 == 0) {
+      // one or two MFMAs per k-step: a chunk is 256 / 512 cycles of MFMAs, less than an L2 round trip -- weight fragments
+      // three chunks ahead (ring of four) instead of one; no extra registers at the kernels' peaks
       float4 a2[TPW], a3[TPW];
       CH_LOADW(a0, 0)
       CH_READX(x0, 0, 0) CH_READX(x1, 0, 1) CH_READX(x2, 0, 2) CH_READX(x3, 0, 3)
