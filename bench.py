@@ -55,8 +55,23 @@ def executed_flops(C, views, Q=799, S=4096, K=32, in_ch=160, hw=256, nblocks=3, 
         f += B * Q * 2.0 * C * (C if dead else 5 * C) + B * Q * 2.0 * C * 3                              # F4 + reg_branch.2
         if not dead:
             f += B * Q * 2.0 * 4 * C * C                                                                 # feed-forward output
-    if tables:
-        f += 2 * Q * K * 4.0 * C * C                                                                     # table build
+    # (the block-0 anchor tables are folded once at poem_create, like the positional table: not part of a step)
+    return f
+
+
+def as_written_flops(C, views, Q=799, S=4096, K=32, in_ch=160, hw=256, nblocks=3):
+    """FLOPs of the path AS THE REFERENCE WRITES IT (SURVEY.md section 8d's per-sample formula + input_proj): un-hoisted
+    vector cross attention (fc1 / w_k / w_v on the gathered (Q, 32, C) rows), un-composed Linears, per-sample block 0, the
+    last block's feed-forward.  c2 (medium, 8 views): 132.5 GFLOP per sample.  The step's rate on THIS count divided by
+    the rate on the executed count is the algebra's gain (hoist, anchor tables, composed Linears), held to parity."""
+    f = 0.0
+    for n in views:
+        f += n * 2.0 * C * in_ch * hw + S * n * 3.0 * C * C + 1.5 * S * C * C
+        blk = (2.0 * C * C * (Q + S) + 2 * (4.0 * C * C * Q + 4.0 * C * C * S + 4.0 * Q * S * C)
+               + (10.0 * C * C * Q + Q * K * (6.0 * C + 2.0 * C * C) + 4.0 * Q * K * C * C)
+               + (4.0 * C * C * Q + 6.0 * C * C * Q * K + Q * K * (6.0 * C + 2.0 * C * C) + 4.0 * Q * K * C * C)
+               + 2.0 * C * C * Q + 16.0 * C * C * Q)
+        f += nblocks * blk
     return f
 
 
@@ -200,7 +215,8 @@ def cpu_baseline(model_embed, batch, n_samples):
     t0 = time.perf_counter()
     out = run(0, n_samples)
     dt = time.perf_counter() - t0
-    return {"value": n_samples / dt, "unit": "samples/s", "cores": best_t, "kind": "port", "one_thread_value": one_thread,
+    return {"value": n_samples / dt, "unit": "samples/s", "cores": best_t, "threads": best_t, "host_physical_cores": phys,
+            "kind": "port", "one_thread_value": one_thread,
             "sample": f"first {n_samples} samples of the GPU's own batch (POEM-medium, {views[0]} views), one pass in "
                       f"{dt:.1f} s, torch CPU fp32, {best_t} threads (fastest of 16/32/64/{phys} on this host, "
                       f"{phys} physical cores)"}, out
@@ -347,9 +363,31 @@ def main():
         torch.cuda.synchronize()
         pdist.barrier()
         dt = time.perf_counter() - t0
+    dt_rank = dt
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     pdist.all_reduce_max_(tmax)
     dt = float(tmax.item())
+    scale_diag = None
+    if world > 1:
+        # what a reader of the scaling curve needs beside `value`: every rank's own step time (min / max / spread) and the
+        # latency of the path's only collective (the 16-byte all-reduce of the metric sums), measured alone
+        per = torch.zeros(world, dtype=torch.float64, device=dev)
+        per[rank] = dt_rank / args.steps * 1e3
+        pdist.all_reduce_sum_(per)
+        probe = torch.zeros(2, dtype=torch.float64, device=dev)
+        for _ in range(5):
+            pdist.all_reduce_sum_(probe)
+        torch.cuda.synchronize()
+        pdist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            pdist.all_reduce_sum_(probe)
+        torch.cuda.synchronize()
+        ar_us = (time.perf_counter() - t0) / 50 * 1e6
+        scale_diag = {"ms_per_step_by_rank": [round(float(v), 4) for v in per.tolist()], "ms_per_step_min": float(per.min()),
+                      "ms_per_step_max": float(per.max()), "allreduce_16B_latency_us": ar_us,
+                      "note": "per-rank wall time of the timed region / steps (rank-local clocks, same barrier-bracketed region); "
+                              "the all-reduce is timed alone, back to back, 50 calls"}
     n_fe, fe_ms = eng.profile_read_stage(2)            # the sampling front end (input_proj .. merge finalize), per forward
     n_anch, anch_ms = eng.profile_read_anchored()      # block 0's table form (one C x C GEMM per neighbour column)
     n_launch, va_ms = eng.profile_read()               # the full fused kernel (blocks 1, 2)
@@ -375,9 +413,16 @@ def main():
     }
     # whole step against the fp32 matrix pipe: FLOPs the launch list executes (not the as-written count) / step time
     ex = executed_flops(C, views, tables=bool(args.anchor_tables) and args.precision == "fp32", parametric=parametric)
+    aw = as_written_flops(C, views)
     res["whole_step"] = {"executed_TFLOP_per_step": ex / 1e12, "executed_TFLOPs": ex / (dt / args.steps) / 1e12,
                          "frac_of_fp32_matrix_peak": ex / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                         "note": "per GPU; 2 FLOP per multiply-add of every GEMM-shaped launch of csrc/api.cpp's sequence"}
+                         "as_written_TFLOP_per_step": aw / 1e12, "as_written_TFLOPs": aw / (dt / args.steps) / 1e12,
+                         "algorithmic_efficiency": aw / ex,
+                         "as_written_frac_of_fp32_matrix_peak": aw / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "note": "per GPU; executed = 2 FLOP per multiply-add of every GEMM-shaped launch of csrc/api.cpp's "
+                                 "sequence; as_written = SURVEY 8d's count of the reference's own arithmetic (un-hoisted cross "
+                                 "attention, per-sample block 0, un-composed Linears): a rate above the pipe's peak on that count is "
+                                 "algebra held to parity, not skipped work"}
     if n_fe > 0:
         fe_s = fe_ms / n_fe * 1e-3
         sb = sampling_stage_bytes(C, views)
@@ -422,6 +467,8 @@ def main():
                 "as_written_TFLOPs": vecattn_flops_per_launch(args.batch, C) / (anch_ms / n_anch * 1e-3) / 1e12,
                 "executed_TFLOPs": vecattn_flops_per_launch(args.batch, C) / 3.0 / (anch_ms / n_anch * 1e-3) / 1e12,
                 "note": "not part of `achieved`: a third of the as-written products are executed per sample"}
+    if scale_diag is not None:
+        res["scaling_diagnostics"] = scale_diag
     res["mpvpe_synthetic_gt_mm"] = meter.result() * 1e3
     if args.precision != "fp32":
         res["dtype"] = "f32 (vector-attention C x C products as hi/lo f16 splits on the f16 matrix cores, fp32 accumulation)"
@@ -498,6 +545,33 @@ def main():
             res["per_sample_block0_scope"] = {"error": repr(e)[:200]}
     if (rank == 0 and world == 1 and not args.no_extra_configs and args.precision == "fp32" and args.anchor_tables and args.overlap
             and (args.model, args.views, args.views_range, args.batch, parametric) == ("medium", 8, None, 32, False)):
+        # SMALL-PER-GPU-BATCH regime: the reference's evaluation runs --val_batch_size 2 (lib/opt.py:27-30 upstream), and
+        # BASELINE configs[4] read as a GLOBAL batch of 64 is 8 samples per GPU.  Same head, same code path; only the batch.
+        small = {}
+        try:
+            legs = [(f"B{b}", [8] * b) for b in (1, 2, 4, 8, 16)]
+            legs.append(("B8_ragged_2to10views", np.random.RandomState(5).randint(2, 11, size=8).tolist()))
+            for name, vws in legs:
+                _, b2, _ = make_leg(C, vws, False, dev, rank, rotate=4, seed0=3000)       # (weights are seeded: the same head)
+                n = len(vws)
+                sec = time_leg(head, b2, steps=max(20, 160 // n), warmup=5)
+                with torch.no_grad():
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(10):
+                        head(*b2[i % len(b2)][:3])
+                        torch.cuda.synchronize()
+                    lat = (time.perf_counter() - t0) / 10
+                small[name] = {"samples_per_s": n / sec, "ms_per_forward": sec * 1e3, "ms_per_forward_synced": lat * 1e3,
+                               "views_total": int(sum(vws)), "frac_of_headline_per_sample_rate": (n / sec) / value}
+                del b2
+            small["note"] = ("POEM-medium head, 8 views (or ragged), batch B per forward, back-to-back forwards on resident inputs "
+                             "(`ms_per_forward`; `_synced`: a device sync after every forward = latency incl. host enqueue); "
+                             "`frac_of_headline_per_sample_rate` = this batch's samples/s over the batch-32 headline's")
+        except Exception as e:   # informational: never fail the bench line on it
+            small["error"] = repr(e)[:200]
+        res["small_batch_scope"] = small
+        torch.cuda.empty_cache()
         # the per-GPU loads of the other BASELINE configs, same code path, short legs (reported beside the headline)
         extras = {}
         legs = {"c3_medium_MANO_8views_batch32": ("medium_MANO", [8] * 32, True),
@@ -662,6 +736,39 @@ def main():
             res["speedup_vs_eager"] = value / res["eager_baseline"]["value"]
         except Exception as e:   # the eager leg is informational: never fail the bench line on it
             res["eager_baseline"] = {"error": repr(e)[:200]}
+    if world > 1 and args.precision == "fp32" and not args.headline_only and not args.views_range and not parametric:
+        # BASELINE configs[4] as ONE global batch: 64 samples with 2..10 views each (seed 5), split over the ranks by
+        # dist.shard_by_views (contiguous sample ranges balanced by their view counts) -- strong scaling of that batch, next
+        # to the weak-scaling headline above.  No data-path collective: each rank runs its shard, the time is the slowest rank's.
+        try:
+            views_g = np.random.RandomState(5).randint(2, 11, size=64)
+            lo, hi = pdist.shard_by_views(views_g, rank, world)
+            mine = views_g[lo:hi].tolist()
+            counts = torch.zeros(2 * world, dtype=torch.float64, device=dev)
+            counts[rank], counts[world + rank] = hi - lo, float(sum(mine))
+            pdist.all_reduce_sum_(counts)
+            _, b2, _ = make_leg(C, mine, False, dev, rank, rotate=3, seed0=5000)
+            ksteps = max(5, args.steps)
+            with torch.no_grad():
+                for i in range(3):
+                    head(*b2[i % len(b2)][:3])
+                pdist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(ksteps):
+                    head(*b2[i % len(b2)][:3])
+                torch.cuda.synchronize()
+                pdist.barrier()
+                gdt = time.perf_counter() - t0
+            tg = torch.tensor([gdt], dtype=torch.float64, device=dev)
+            pdist.all_reduce_max_(tg)
+            res["c5_global_ragged_batch64"] = {
+                "value": 64 * ksteps / float(tg.item()), "unit": "samples/s", "ms_per_step": float(tg.item()) / ksteps * 1e3,
+                "scaling": "strong", "samples_by_rank": [int(v) for v in counts[:world].tolist()],
+                "views_by_rank": [int(v) for v in counts[world:].tolist()],
+                "note": "one global batch of 64 ragged samples per step, dist.shard_by_views; max over ranks"}
+        except Exception as e:
+            res["c5_global_ragged_batch64"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -274,6 +274,15 @@ struct poem_handle_s {
   bool tables_first = true;    // the fused sampling kernel starts behind the anchor-table build (see poem_head_forward)
   bool chain_combine = true;   // chain kind A combines the cross attention's split-key partials itself (no attn_combine launch)
   bool knn_early = true;     // chain mode: issue block i+1's neighbour searches right behind block i's coordinate update
+  int chain_tile = 0;        // chain row-tile height: 0 = per launch (chain.hip chain_tile_p), 1 = 32 rows, 2 = 64 rows (A/B)
+  // The block-0 anchor tables are functions of the handle's constants only (template, anchors, weights): like the folded
+  // positional table they are built ONCE, at poem_create, into handle-owned memory ("block-0
+  // fc_delta outputs ... a fixed (799,32,C) table per attention").  tables_cached = false rebuilds them on every forward
+  // in the workspace (the round-1/2 behaviour; same kernel, same inputs: bit-identical, tested).
+  bool tables_cached = true;
+  bool tables_pending = false;       // this forward built the tables on the side stream: consumers wait for ev_tab
+  float* tab_mem = nullptr;
+  float *c_canon_xyz = nullptr, *c_tab_g[2] = {}, *c_tab_p[2] = {};
   hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {};
   bool overlap = true;
   // Per-view index arrays (view_offsets | view_sample | pe_index) live in handle-owned device memory and are re-uploaded
@@ -409,10 +418,10 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
 // the very top of poem_head_forward -- they depend on the handle's constants only, so they overlap the HBM-bound sampling
 // front end instead of competing with the first basis-point GEMM the query side waits for (0.07 ms each when they get
 // the chip; 0.7 ms and a later start of block 0 when issued next to that GEMM).
-static int build_anchor_tables(poem_handle_t h, Plan& p, hipStream_t s) {
+static int build_anchor_tables(poem_handle_t h, Plan& p, hipStream_t s, bool at_create = false) {
   const poem_config_t& c = h->cfg;
   const int C = c.embed, Q = c.nquery;
-  const bool ov = h->overlap && h->bps_stream && h->knn_stream;
+  const bool ov = !at_create && h->overlap && h->bps_stream && h->knn_stream;
   hipStream_t sk = ov ? h->knn_stream : s;
   if (ov) {
     HIPCHK(hipEventRecord(h->ev_fork0, s));      // the previous forward's readers of the tables are behind this point
@@ -427,6 +436,7 @@ static int build_anchor_tables(poem_handle_t h, Plan& p, hipStream_t s) {
                                                Q, C, sk));
   }
   if (ov) HIPCHK(hipEventRecord(h->ev_tab, sk));
+  h->tables_pending = ov;
   return POEM_OK;
 }
 
@@ -555,6 +565,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       HIPCHK(poem_launch_cross_attention_imgq(q0, 2 * C, q_batch, p.y1[i], p.y1[i] + (size_t)BS * C, comb ? nullptr : p.ctx, B, Q, S,
                                               C, c.heads, p.attn_scratch, s));
       ChainArgs ca{};
+      ca.tile_p = h->chain_tile;
       ca.kind = 0; ca.M = BQ; ca.x = p.ctx; ca.ldx = C;
       from_partials(ca);
       ca.w1 = (const float4*)h->P(a1 + 6); ca.b1 = h->R(a1 + 7); ca.res = hidden; ca.ldres = ldh; ca.res_mod = hidden_mod;
@@ -564,6 +575,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       HIPCHK(poem_launch_cross_attention_imgq(p.qp, C, Q, p.y1[i] + (size_t)2 * BS * C, p.y1[i] + (size_t)3 * BS * C,
                                               comb ? nullptr : p.ctx, B, Q, S, C, c.heads, p.attn_scratch, s));
       ChainArgs cb{};
+      cb.tile_p = h->chain_tile;
       cb.kind = 0; cb.M = BQ; cb.x = p.ctx; cb.ldx = C;
       from_partials(cb);
       cb.w1 = (const float4*)h->P(a2 + 6); cb.b1 = h->R(a2 + 7); cb.res = p.h_attn; cb.ldres = C; cb.res_mod = 0;
@@ -621,7 +633,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
                                                 h->R(vsb + 4), h->R(vsb + 5), sw.w[0], h->R(vsb + 7), sw.w[1], sw.w[2],
                                                 sw.scales, p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, s));
     } else if (tables && i == 0) {
-      if (ov) HIPCHK(hipStreamWaitEvent(s, h->ev_tab, 0));
+      if (ov && h->tables_pending) HIPCHK(hipStreamWaitEvent(s, h->ev_tab, 0));
       HIPCHK(poem_launch_vector_attention_anchored(p.ident, p.y3, p.anch_kv[0], p.anch_kv[0] + C, 32, h->P(vsb + 10),
                                                    p.tab_g[0], p.tab_p[0], p.rs, B, Q, C, 3 * C, 2 * C, 2 * C, s));
     } else
@@ -634,6 +646,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     const int vcb = bb + B_VC;
     if (chain) {       // f_self = fc2(r) + h_cross ; qc = (W_g1 w_qs) f_self + (W_g1 b_d2 + b_g1)
       ChainArgs cc{};
+      cc.tile_p = h->chain_tile;
       cc.kind = 1; cc.M = BQ; cc.x = p.rs; cc.ldx = C;
       cc.w1 = (const float4*)h->P(vsb + 2); cc.b1 = h->R(vsb + 3); cc.res = hidden; cc.ldres = C; cc.res_mod = 0;
       cc.y1 = p.f_self[i]; cc.ldy1 = C;
@@ -669,6 +682,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
     if (chain) {
       // f_cross = fc2(r) + f_self ; reg_branch -> xyz_{i+1} ; feed forward + LayerNorm -> feats ; next block's F2
       ChainArgs cd{};
+      cd.tile_p = h->chain_tile;
       cd.kind = 2; cd.M = BQ; cd.x = p.rc; cd.ldx = C;
       cd.w1 = (const float4*)h->P(vcb + 2); cd.b1 = h->R(vcb + 3); cd.res = p.f_self[i]; cd.ldres = C; cd.res_mod = 0;
       cd.y1 = p.f_cross[i]; cd.ldy1 = C; cd.eps = c.ln_eps;
@@ -685,6 +699,7 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
         knn_issued[i + 1] = true;
       }
       ChainArgs ce{};
+      ce.tile_p = h->chain_tile;
       ce.kind = 3; ce.M = BQ; ce.x = p.f_cross[i]; ce.ldx = C; ce.eps = c.ln_eps;
       ce.wf4 = (const float4*)h->fused[i].w[3]; ce.bf4 = h->fused[i].b[3];
       ce.wout = (const float4*)h->P(bb + B_OUT_W); ce.bout = h->R(bb + B_OUT_B);
@@ -987,6 +1002,22 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
     for (int i = 0; i < 8; ++i) { mk(&h->ev_bps[i]); mk(&h->ev_xyz[i]); mk(&h->ev_knn[i]); }
     if (!ok) { poem_destroy(h); return POEM_E_LAUNCH; }
   }
+  {   // block-0 anchor tables (see poem_handle_s::tables_cached): handle-owned, built here once
+    const size_t tf = poem_vector_attention_table_floats(cfg->nquery, C);
+    const size_t cx = align_up((size_t)cfg->nquery * 3, 64);
+    if (hipMalloc((void**)&h->tab_mem, (cx + 4 * tf) * sizeof(float)) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
+    }
+    h->c_canon_xyz = h->tab_mem;
+    Plan tp{};
+    tp.canon_xyz = h->c_canon_xyz;
+    for (int k = 0; k < 2; ++k) {
+      tp.tab_g[k] = h->c_tab_g[k] = h->tab_mem + cx + (size_t)(2 * k) * tf;
+      tp.tab_p[k] = h->c_tab_p[k] = h->tab_mem + cx + (size_t)(2 * k + 1) * tf;
+    }
+    rc = build_anchor_tables(h, tp, s, true);
+    if (rc != POEM_OK) { poem_destroy(h); return rc; }
+  }
   *out = h;
   return POEM_OK;
 }
@@ -997,6 +1028,7 @@ void poem_destroy(poem_handle_t h) {
   auto de = [](hipEvent_t e) { if (e) (void)hipEventDestroy(e); };
   de(h->ev_fork); de(h->ev_join_bps); de(h->ev_join_knn); de(h->ev_tab); de(h->ev_fork0);
   for (int i = 0; i < 8; ++i) { de(h->ev_bps[i]); de(h->ev_xyz[i]); de(h->ev_knn[i]); }
+  if (h->tab_mem) (void)hipFree(h->tab_mem);
   if (h->split_mem) (void)hipFree(h->split_mem);
   if (h->gemm_split) (void)hipFree(h->gemm_split);
   if (h->gemm_scales) (void)hipFree(h->gemm_scales);
@@ -1027,6 +1059,8 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "fused_sampling") h->fused_sampling = value != 0;
   else if (k == "chain_combine") h->chain_combine = value != 0;
   else if (k == "tables_first") h->tables_first = value != 0;
+  else if (k == "tables_cached") h->tables_cached = value != 0;
+  else if (k == "chain_tile") { if (value < 0 || value > 2) return POEM_E_ARG; h->chain_tile = value; }
   else return POEM_E_ARG;
   return POEM_OK;
 }
@@ -1425,9 +1459,15 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
 #define GEMM(X, LDX, WI, BI, RES, LDR, Y, LDY, M, N, K, ACT) \
   HIPCHK(poem_launch_gemm(X, LDX, h->P(WI), (BI) >= 0 ? h->R(BI) : nullptr, RES, LDR, Y, LDY, M, N, K, ACT, s))
 
+  h->tables_pending = false;
   if (h->anchor_tables && h->precision == POEM_PRECISION_FP32) {
-    const int rc = build_anchor_tables(h, p, s);
-    if (rc != POEM_OK) return rc;
+    if (h->tables_cached && h->tab_mem) {
+      p.canon_xyz = h->c_canon_xyz;
+      for (int k = 0; k < 2; ++k) { p.tab_g[k] = h->c_tab_g[k]; p.tab_p[k] = h->c_tab_p[k]; }
+    } else {
+      const int rc = build_anchor_tables(h, p, s);
+      if (rc != POEM_OK) return rc;
+    }
   }
   // ---- sampling stage ------------------------------------------------------------------------------------------
   const bool prof_fe = h->prof_on && (size_t)(2 * h->prof_used + 1) < h->prof_ev.size();
@@ -1450,8 +1490,7 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
     // sample_merge waves its blocks linger: a CU that hosts one takes a single sample_merge block (2 x 66.5 KB no longer
     // fit) and the persistent grid runs in two rounds -- 2.55 instead of 1.69 ms in a third of the forwards.  The build
     // overlaps input_proj / the projection; sample_merge waits for it (+0.06 ms on the critical path, always).
-    if (h->tables_first && h->anchor_tables && h->precision == POEM_PRECISION_FP32 && h->overlap && h->bps_stream && h->knn_stream)
-      HIPCHK(hipStreamWaitEvent(s, h->ev_tab, 0));
+    if (h->tables_first && h->tables_pending) HIPCHK(hipStreamWaitEvent(s, h->ev_tab, 0));
     HIPCHK(poem_launch_sample_merge(&sm, C, s));
     MergeTailArgs mt{};
     mt.h2 = p.h2; mt.q1 = p.q1; mt.offs = p.offs;

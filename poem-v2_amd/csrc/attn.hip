@@ -616,16 +616,7 @@ extern "C" size_t poem_cross_attention_scratch_floats(int B, int NQ, int NK, int
   return n;
 }
 
-static int poem_attn_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
-  return cus;
-}
+static int poem_attn_cus() { return poem_device_cus(); }
 
 // opt-in split precision for the calls enqueued while it is set (api.cpp: around poem_head_forward in SPLIT_F16X3_ALL mode,
 // and by the operator-level entry point); head dims 32 and 64 only, the others keep the exact kernels
@@ -692,7 +683,7 @@ extern "C" hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, 
 #define POEM_XSPLIT(D, WV, PREV)                                                                                         \
   hipLaunchKernelGGL((xattn_split_kernel<D, WV, PREV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, qbr, (const float4*)kimg, \
                      (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw);                \
-  hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
+  if (ctx) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
   if (g_xattn_split && (dh == 32 || dh == 64)) {
 #ifdef POEM_LAB

@@ -319,35 +319,25 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain_ke
 }
 
 template <int C, int P, int NW, int KIND>
-static hipError_t launch_chain_k(const ChainArgs& a, hipStream_t s) {
+static hipError_t launch_chain_k(const ChainArgs& a, int cus, hipStream_t s) {
   constexpr int XS = 32 * P, XSP = XS + 1;
   const size_t lds = ((size_t)(KIND == 3 ? 2 : 1) * C * XSP + (size_t)NW * XS) * sizeof(float);
   auto kern = chain_kernel<C, P, NW, KIND>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin); e != hipSuccess) return e;
   const int items = (a.M + XS - 1) / XS;
-  const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
+  const int per_cu = std::max(1, std::min(32 / NW, (int)(160 * 1024 / lds)));
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min(items, cus * per_cu)), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
 }
 
 template <int C, int P, int NW>
-static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t s) {
+static hipError_t launch_chain_t(const ChainArgs& a, int cus, hipStream_t s) {
   switch (a.kind) {
-    case 0: return launch_chain_k<C, P, NW, 0>(a, s);
-    case 1: return launch_chain_k<C, P, NW, 1>(a, s);
-    case 2: return launch_chain_k<C, P, NW, 2>(a, s);
-    case 3: return launch_chain_k<C, P, NW, 3>(a, s);
+    case 0: return launch_chain_k<C, P, NW, 0>(a, cus, s);
+    case 1: return launch_chain_k<C, P, NW, 1>(a, cus, s);
+    case 2: return launch_chain_k<C, P, NW, 2>(a, cus, s);
+    case 3: return launch_chain_k<C, P, NW, 3>(a, cus, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -358,11 +348,25 @@ extern "C" int poem_chain_supported(int C) { return C == 128 || C == 256 || C ==
 // kind A can take the cross attention's split-key partials as its input (ChainArgs::part_o) for 4 heads and <= 4 key chunks
 extern "C" int poem_chain_combines(int C, int heads, int chunks) { return poem_chain_supported(C) && heads == 4 && chunks >= 1 && chunks <= 4; }
 
+// Row-tile height.  Every tile height runs the same arithmetic per row (a row's fma chains, its LayerNorm sums and its
+// residuals never see the other rows of the tile), so the choice is free per launch -- results stay bit-identical in any
+// batch.  A CU's co-resident blocks share its matrix pipe, so a launch takes as long as the CU with the most rows:
+// ceil(tiles / CUs) * rows per tile.  64-row tiles stream every weight fragment once per 64 rows (best when M is large);
+// 32-row tiles put a small batch on twice as many CUs (M = 1598 at the reference's evaluation batch of 2: 50 CUs instead
+// of 25) and quantise better for 16 < B < 32 (B = 24: 3 x 32 rows per CU instead of 2 x 64).
+static int chain_tile_p(int M, int cus, int force) {
+  if (force == 1 || force == 2) return force;
+  const long r2 = ((long)(M + 63) / 64 + cus - 1) / cus * 64, r1 = ((long)(M + 31) / 32 + cus - 1) / cus * 32;
+  return r1 < r2 ? 1 : 2;
+}
+
 extern "C" hipError_t poem_launch_chain(const ChainArgs* a, int C, hipStream_t s) {
+  const int cus = poem_device_cus();
+  const int p = chain_tile_p(a->M, cus, a->tile_p);
   switch (C) {
-    case 128: return launch_chain_t<128, 2, 4>(*a, s);
-    case 256: return launch_chain_t<256, 2, 8>(*a, s);
-    case 512: return launch_chain_t<512, 1, 8>(*a, s);
+    case 128: return p == 1 ? launch_chain_t<128, 1, 4>(*a, cus, s) : launch_chain_t<128, 2, 4>(*a, cus, s);
+    case 256: return p == 1 ? launch_chain_t<256, 1, 8>(*a, cus, s) : launch_chain_t<256, 2, 8>(*a, cus, s);
+    case 512: return launch_chain_t<512, 1, 8>(*a, cus, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -3,6 +3,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
+// ---- per-device launch state -------------------------------------------------------------------------------------------
+// include/poem_hip.h lets handles on different host threads drive different GPUs of one process, so nothing a launcher
+// caches may be process-wide: the CU count and the "> 64 KB of dynamic LDS" opt-in of a kernel are kept per device id.
+static inline int poem_device_cus() {
+  static std::atomic<int> cache[64];
+  int dev = 0, c = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if ((c = cache[dev].load(std::memory_order_relaxed)) > 0) return c;
+  if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+  cache[dev].store(c, std::memory_order_relaxed);
+  return c;
+}
+// `done`: one function-local static bit mask per kernel instantiation (bit = device id)
+static inline hipError_t poem_optin_lds(const void* kern, size_t bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  const bool idx = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+  if (idx && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess && idx) done.fetch_or(1ull << dev, std::memory_order_release);
+  return e;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -591,16 +591,7 @@ __global__ __launch_bounds__((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512, 2) voi
                                        blocks_in_panel, tile_scales, scale_stride);
 }
 
-static int poem_num_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
-  return cus;
-}
+static int poem_num_cus() { return poem_device_cus(); }
 
 template <int NT, int MT, bool GELU, bool SPLIT = false>
 static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
@@ -609,13 +600,8 @@ static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const 
                                  int scale_stride = 0) {
   const size_t lds = (size_t)NT * (K / 8) * 64 * 16;
   auto kern = gemm_panel_kernel<NT, MT, GELU, SPLIT>;
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(128 * 1024));
-    if (e != hipSuccess) return e;
-    lds_set = 128 * 1024;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), 128 * 1024, optin); e != hipSuccess) return e;
   const int panels = N / (32 * NT);
   const int grid = std::max(poem_num_cus(), panels);
   hipLaunchKernelGGL(kern, dim3(grid), dim3((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512), lds, s, X, ldx, (const float4*)Wp, bias, R,

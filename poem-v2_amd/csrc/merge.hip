@@ -353,27 +353,15 @@ __global__ void project_table_kernel(const float* __restrict__ bps, const float*
                      __uint_as_float((unsigned)(cy1 * fw + cx0) | ((unsigned)(cy1 * fw + cx1) << 16)), 0.f, 0.f);
 }
 
-static int g_cus = 0;
-static int cu_count() {
-  if (!g_cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_cus <= 0)
-      g_cus = 256;
-  }
-  return g_cus;
-}
+static int cu_count() { return poem_device_cus(); }
 
 template <int C, int P, int NW>
 static hipError_t launch_sample_merge_t(const SampleMergeArgs& a, hipStream_t s) {
   constexpr int XS = 32 * P, XSP = XS + 1;
   const size_t lds = (size_t)C * XSP * sizeof(float);
   auto kern = sample_merge_kernel<C, P, NW>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin); e != hipSuccess) return e;
   const int tpv = (C / XS) * (a.S / C);
   const long items = (long)a.views * tpv;
   const long grid = std::min<long>(items, (long)cu_count() * 2);
@@ -385,12 +373,8 @@ template <int C, int NW>
 static hipError_t launch_merge_tail_t(const MergeTailArgs& a, hipStream_t s) {
   const size_t lds = (size_t)(C / 2) * 65 * sizeof(float);
   auto kern = merge_tail_kernel<C, NW>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin); e != hipSuccess) return e;
   const long items = (long)a.B * a.S / 64;
   hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long>(items, (long)cu_count() * 2)), dim3(NW * 64), lds, s, a);
   return hipGetLastError();

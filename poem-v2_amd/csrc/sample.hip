@@ -172,12 +172,8 @@ extern "C" hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, con
     const size_t lds = (size_t)K * 512;
     const int nw = ctiles >= 8 ? 8 : 4;
     auto kern = nw == 8 ? conv1x1_lds_kernel<8> : conv1x1_lds_kernel<4>;
-    static bool attr_done[2] = {false, false};
-    if (!attr_done[nw == 8]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (e != hipSuccess) return e;
-      attr_done[nw == 8] = true;
-    }
+    static std::atomic<unsigned long long> optin[2];
+    if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), 96 * 1024, optin[nw == 8]); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)(views * (hw / 128))), dim3(nw * 64), lds, s, feat, (const float4*)Wp, bias, table,
                        pe_index, x, xt, views, K, C, hw);
     return hipGetLastError();

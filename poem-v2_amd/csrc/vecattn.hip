@@ -535,22 +535,11 @@ static hipError_t launch_va_t(const VecAttnArgs& a, hipStream_t s) {
   if (const char* e = getenv("POEM_VA_LDSPAD")) lds += atoi(e);
 #endif
   auto kern = vecattn_kernel<C, P, NW, MINW, COMP, MODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin); e != hipSuccess) return e;
   unsigned grid = (unsigned)(a.B * groups);
   if (a.stagger > 0) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        cus = 256;
-    }
-    grid = std::min(grid, (unsigned)(2 * cus));
+    grid = std::min(grid, (unsigned)(2 * poem_device_cus()));
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, a);
   return hipGetLastError();

@@ -413,20 +413,14 @@ static hipError_t launch_vs(const VecAttnSplitArgs& a, hipStream_t s) {
   const int groups = (a.Q + P - 1) / P;
   const size_t lds = (size_t)32 * P * (C * 4 + 16) + P * 32 * 3 * 4 + 2 * P * 32 * 4 + (size_t)P * C * 4;
   auto kern = vecattn_split_kernel<C, P, NW, MINW>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin); e != hipSuccess) return e;
   // Persistent: as many blocks as the chip holds, items dealt round-robin (they all cost the same).  The compiler hoists
   // ~20 per-lane address values out of the item loop and spills them; with one item per block that was 280 MB of scratch
   // writes per launch (PMC WRITE_SIZE 308 MB against 26 MB of results).
-  static int slots = 0;
-  if (!slots) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots = cus * ((size_t)2 * lds <= 160 * 1024 ? 2 : 1);
+  int slots = 0;
+  {
+    slots = poem_device_cus() * ((size_t)2 * lds <= 160 * 1024 ? 2 : 1);
 #ifdef POEM_LAB
     if (const char* e = getenv("POEM_VS_PERSIST")) if (atoi(e) == 0) slots = 1 << 30;
 #endif

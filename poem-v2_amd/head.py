@@ -148,6 +148,13 @@ class POEM_Generalized_Head(nn.Module):
 
     # ---- forward -----------------------------------------------------------------------------------------------
     def forward(self, mlvl_feat, img_metas, reference_joints, **kwargs):
+        # Inference only.  The reference trains through this head (scripts/train_ddp.py:84, lib/models/POEM.py:363-466
+        # upstream: losses on all_coords_preds / pred_pose / pred_shape back-propagate into the head and HRNet); the HIP
+        # path has no backward and returns tensors without a graph, so a training step would silently receive no gradient.
+        # Refuse instead: train mode with grad enabled, or any input that asks for a gradient.
+        if torch.is_grad_enabled() and (self.training or mlvl_feat.requires_grad or reference_joints.requires_grad):
+            raise RuntimeError("POEM_Generalized_Head (HIP) is inference-only: no backward is built.  Call model.eval() and run under "
+                               "torch.no_grad() (as scripts/eval.py does); for training keep the reference's PyTorch head")
         if not mlvl_feat.is_cuda:
             raise RuntimeError("POEM_Generalized_Head runs on the MI355X HIP path only (no CPU fallback)")
         assert self.merge_mode == "attn"                                                   # ptEmb_head.py:903

@@ -698,10 +698,13 @@ def test_projections_outside_the_image_and_behind_the_camera(fused):
 
 
 def test_errors_are_loud():
-    head = pk.build_head(__import__("util").head_cfg(128), data_preset=pk.CN({}))
+    head = pk.build_head(__import__("util").head_cfg(128), data_preset=pk.CN({})).eval()
     b = pk.inputs.synthetic_batch([2], seed=0)
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         head(b["mlvl_feat"], b["img_metas"], b["reference_joints"])      # CPU tensors: no fallback
+    head.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        head(b["mlvl_feat"].to(DEV), b["img_metas"], b["reference_joints"].to(DEV))   # training through the HIP head: refused
     with pytest.raises(RuntimeError):
         hip.gemm(torch.zeros(4, 8), torch.zeros(8, dtype=torch.uint8), 4)
 
@@ -732,6 +735,19 @@ def test_full_size_batch_properties():
     assert torch.equal(one[:, 0], full[:, 17])
     perm = [5, 30, 0, 11]
     assert torch.equal(sub(perm), full[:, perm])
+    # the small-per-GPU-batch regime (the reference evaluates at batch 2, lib/opt.py:27-30 upstream): B = 2 and B = 8 take
+    # other row-tile heights / grids than B = 32 (chain.hip chain_tile_p) -- same arithmetic per row, bit for bit
+    assert torch.equal(sub([9, 20]), full[:, [9, 20]])
+    eight = list(range(8, 16))
+    assert torch.equal(sub(eight), full[:, eight])
+    # A/B switches that must not change a bit: forced 32- / 64-row chain tiles, the block-0 anchor tables rebuilt per forward
+    # (the round-2 behaviour) instead of read from the handle, where poem_create folded them
+    eng = head._engine
+    for name, val in (("chain_tile", 1), ("chain_tile", 2), ("chain_tile", 0), ("tables_cached", 0), ("tables_cached", 1)):
+        eng.set_option(name, val)
+        with torch.no_grad():
+            again = head(feat, metas, rj)["all_coords_preds"]
+        assert torch.equal(again, full), (name, val)
     # oracle on 2 samples of the big batch
     b2 = dict(mlvl_feat=batch["mlvl_feat"][:16], reference_joints=batch["reference_joints"][:2],
               img_metas=dict(batch["img_metas"], cam_intr=batch["img_metas"]["cam_intr"][:16],
@@ -787,6 +803,44 @@ def test_full_size_config_c5_ragged_2_to_10_views_batch_64():
     views = np.random.RandomState(5).randint(2, 11, size=64).tolist()
     assert min(views) == 2 and max(views) == 10
     _full_size_properties(dict(embed=256, nsample=4096, views=views, seed=51, parametric=False), n_oracle=2)
+
+
+def test_full_size_config_c3_medium_mano_8_views_batch_32():
+    """BASELINE configs[2]'s per-GPU load: POEM-medium_MANO, 8 views, batch 32, the parametric tail on the device (Q3 flatten,
+    Linears, rot6d -> axis-angle, MANO linear blend skinning through the HIP ManoLayer on a synthetic asset set of MANO's
+    shapes -- the real assets are licence-gated).  Properties: finite; a sample of the big batch equals its own
+    single-sample run bit for bit (coordinates, pose, shape); the first two decoder layers equal the non-parametric head's
+    (the tail only replaces the last layer); the last layer equals MANO(pred_pose, pred_shape) + centre re-evaluated by
+    the oracle's LBS restatement."""
+    import mano_oracle as mo
+    spec = dict(embed=256, nsample=4096, views=[8] * 32, seed=61, parametric=True)
+    cfg, w, consts, batch = case_setup(spec)
+    head = build_hip_head(spec, DEV)
+    assets = pk.mano.synthetic_mano_assets(0)
+    head.set_mano_layer(pk.ManoLayer(assets, center_idx=9, device=DEV))
+    feat, metas, rj = batch_to(batch, DEV)
+    with torch.no_grad():
+        out = head(feat, metas, rj)
+    full, pose, shape = out["all_coords_preds"], out["pred_pose"], out["pred_shape"]
+    assert full.shape == (3, 32, 799, 3) and pose.shape == (32, 16, 3) and shape.shape == (32, 10)
+    assert torch.isfinite(full).all() and torch.isfinite(pose).all() and torch.isfinite(shape).all()
+    rows = torch.arange(8 * 21, 8 * 22).to(DEV)
+    m = dict(metas)
+    m["cam_intr"], m["cam_extr"] = metas["cam_intr"][rows].contiguous(), metas["cam_extr"][rows].contiguous()
+    m["cam_view_num"], m["master_id"] = np.asarray([8]), [0]
+    with torch.no_grad():
+        one = head(feat[rows].contiguous(), m, rj[21:22].contiguous())
+    assert torch.equal(one["all_coords_preds"][:, 0], full[:, 21])
+    assert torch.equal(one["pred_pose"][0], pose[21]) and torch.equal(one["pred_shape"][0], shape[21])
+    # layers 0, 1 are untouched by the tail
+    plain = build_hip_head(dict(spec, parametric=False), DEV)        # (seeded weights are keyed by tensor name: same common tensors)
+    with torch.no_grad():
+        base = plain(feat, metas, rj)["all_coords_preds"]
+    assert torch.equal(base[:2], full[:2])
+    # last layer = MANO(pose, shape) centred at joint 9, + the sample's centre (ptEmb_head.py:944-958 upstream: no radius scale)
+    verts, joints = mo.mano_lbs(assets, pose.reshape(32, 48).cpu(), shape.cpu(), center_idx=9)
+    want = torch.cat([joints, verts], dim=1) + batch["reference_joints"][:, 9:10].double()
+    assert float((full[-1].cpu().double() - want).abs().max()) < 5e-6
 
 
 def test_bench_gpus_2_launches_two_ranks_or_refuses():

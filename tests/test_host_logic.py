@@ -82,12 +82,30 @@ def test_parametric_head_has_mano_tail_keys():
 
 
 def test_no_cpu_fallback():
-    head = pk.build_head(pk.configs.model_head_cfg("small"), data_preset=pk.CN({}))
+    head = pk.build_head(pk.configs.model_head_cfg("small"), data_preset=pk.CN({})).eval()
     b = pk.inputs.synthetic_batch([2], seed=0)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"), torch.no_grad():
         head(b["mlvl_feat"], b["img_metas"], b["reference_joints"])
     with pytest.raises(RuntimeError):
         hip.ptr(torch.zeros(3))
+
+
+def test_head_refuses_training():
+    """The HIP head has no backward: the reference's training loop (scripts/train_ddp.py:84, losses at lib/models/POEM.py:363-466
+    upstream) must get an error, not a head that silently returns graph-less tensors."""
+    head = pk.build_head(pk.configs.model_head_cfg("small"), data_preset=pk.CN({}))
+    b = pk.inputs.synthetic_batch([2], seed=0)
+    assert head.training
+    with pytest.raises(RuntimeError, match="inference-only"):
+        head(b["mlvl_feat"], b["img_metas"], b["reference_joints"])                  # train mode, autograd on
+    head.eval()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        head(b["mlvl_feat"].clone().requires_grad_(True), b["img_metas"], b["reference_joints"])   # eval mode, but a gradient is asked for
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        head(b["mlvl_feat"], b["img_metas"], b["reference_joints"])                  # eval mode, nothing asks for a gradient: past the guard
+    head.train()
+    with pytest.raises(RuntimeError, match="no CPU fallback"), torch.no_grad():
+        head(b["mlvl_feat"], b["img_metas"], b["reference_joints"])                  # train mode under no_grad (validation inside a training script)
 
 
 # ---- C ABI ------------------------------------------------------------------------------------------------------
@@ -225,6 +243,49 @@ def test_dp_metric_allreduce_gloo_world2(tmp_path):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "DP_OK" in out.stdout
+
+
+_WORKER8 = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from poem_v2_amd import dist as pdist
+from poem_v2_amd.metrics import MeanEPE
+rank, local, world = pdist.init_from_env(backend="gloo")
+assert world == 8
+# config c5 as one global batch: 64 ragged samples split by shard_by_views; config c3: 256 samples split by shard_range
+views = np.random.RandomState(5).randint(2, 11, size=64)
+lo, hi = pdist.shard_by_views(views, rank, world)
+spans = [None] * world; dist.all_gather_object(spans, (lo, hi))
+assert spans[0][0] == 0 and spans[-1][1] == 64 and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1)), spans
+loads = [int(views[a:b].sum()) for a, b in spans]
+assert max(hi_ - lo_ for lo_, hi_ in spans) <= 9 and max(loads) <= 1.25 * sum(loads) / world, (spans, loads)
+l3, h3 = pdist.shard_range(256, rank, world)
+assert (l3, h3) == (32 * rank, 32 * rank + 32)
+# the path's only collective: metric sums over the shards == the single-process metric, and reduce() twice changes nothing
+g = torch.Generator().manual_seed(0)
+pred = torch.randn(64, 778, 3, generator=g); gt = torch.randn(64, 778, 3, generator=g)
+m = MeanEPE("v"); m.feed(pred[lo:hi], gt[lo:hi]); m.reduce(); m.reduce()
+full = MeanEPE("v"); full.feed(pred, gt)
+assert abs(m.result() - full.result()) < 1e-6, (m.result(), full.result())
+t = torch.tensor([float(rank)], dtype=torch.float64); pdist.all_reduce_max_(t); assert t.item() == 7.0
+pdist.barrier()
+if rank == 0: print("DP8_OK", spans)
+dist.destroy_process_group()
+'''
+
+
+def test_dp_sharding_and_metric_allreduce_gloo_world8(tmp_path):
+    """The N = 8 layout of BASELINE configs[2] / [4] on CPU (gloo): shard_range / shard_by_views cover the batch with balanced,
+    contiguous ranges, and the sharded metric equals the single-process one (the world-2 test covers the other metrics)."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29641", str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "DP8_OK" in out.stdout
 
 
 def test_eval_single_cfg_edits_match_reference():
