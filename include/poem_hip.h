@@ -340,6 +340,13 @@ int poem_vector_attention_split(const float* query_xyz, const float* src_xyz, co
                                 void* stream);
 /* idx (B,Q,32) int32: 32 nearest src points per query, ascending squared L2, ties -> lower index. */
 int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream);
+/* The same with a choice of the distance's rounding.  fma_contract = 0: ((dx*dx + dy*dy) + dz*dz), every operation rounded --
+ * pytorch3d's CPU kernel (knn_cpu.cpp, built without FMA), the path BASELINE's parity bar is stated against, and what
+ * poem_knn / poem_head_forward use.  fma_contract = 1: fma(dz, dz, fma(dy, dy, dx*dx)) -- pytorch3d's CUDA kernel
+ * (knn.cu `dist += diff * diff` under nvcc's default -fmad=true), for comparing with results produced on a CUDA box;
+ * whole path: poem_set_option(h, "knn_fma", 1).  The two differ by <= 1 ulp per distance and only reorder near-ties. */
+int poem_knn_ex(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, int fma_contract,
+                void* stream);
 /* Vector attention core.  q (B,Q,C); k,v (B,NS,C) gathered by idx; idx (B,Q,32) or (32) when shared_idx!=0;
  * neighbour coordinates: anchor_xyz (32,3) when non-NULL, else src_xyz[b, idx];
  * wd1 (C,3)+bd1 raw; wd2, wg1, wg2 packed (C,C) + biases.  out r (B,Q,C) = sum_j softmax_j(a/sqrt(C)) * (v_j + pos_j). */

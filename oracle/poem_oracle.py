@@ -37,6 +37,7 @@ class PathConfig:
     parametric: bool = False  # TRANSFORMER.PARAMETRIC_OUTPUT
     center_idx: int = 9       # TRANSFORMER_CENTER_IDX
     ln_eps: float = 1e-12     # BertConfig.layer_norm_eps default
+    knn_fma: bool = False     # neighbour distances with the fma contraction of pytorch3d's CUDA kernel (see knn_distances)
 
 
 def linear(x, w, b=None):
@@ -175,13 +176,30 @@ def bert_cross_attention(w, pre, hidden, enc, heads, eps):
     return layer_norm(out + hidden, w[pre + "output.LayerNorm.weight"], w[pre + "output.LayerNorm.bias"], eps)
 
 
-def knn_indices(query_xyz, src_xyz, K):
-    """pytorch3d.ops.knn_points semantics (call sites point_transformers.py:83,134): squared L2
-    ((dx*dx + dy*dy) + dz*dz, fp32, no matmul expansion), K smallest sorted ascending.  Ties: lower index
-    first (upstream: implementation-defined -> unpinned)."""
+def knn_distances(query_xyz, src_xyz, fma=False):
+    """Squared L2 of every (query, source) pair in fp32, the way pytorch3d's kernels accumulate it (third-party source,
+    absent from /root/reference; pinned version 0.7.2, docs/installation.md:28-39; call sites point_transformers.py:83,134):
+    ``dist = 0; for d in x, y, z: diff = p1[d] - p2[d]; dist += diff * diff``.
+      fma=False  every product and sum rounded: ((dx*dx + dy*dy) + dz*dz) -- knn_cpu.cpp as the wheels build it (x86-64
+                 baseline has no FMA), i.e. the reference CPU path;
+      fma=True   nvcc contracts the loop body to fma(diff, diff, dist) (-fmad=true is its default): dx*dx rounded, then
+                 two fused steps -- knn.cu on a CUDA box.  Emulated in fp64: the product of two fp32 values is exact in
+                 fp64, the sum is rounded once to fp64 and once to fp32 (double rounding differs from a true fma only on
+                 exact half-way cases of the 29 guard bits)."""
     d = query_xyz[:, :, None, :] - src_xyz[:, None, :, :]
-    d = d * d
-    dist = (d[..., 0] + d[..., 1]) + d[..., 2]
+    if not fma:
+        d = d * d
+        return (d[..., 0] + d[..., 1]) + d[..., 2]
+    dd = d.double()
+    acc = (d[..., 0] * d[..., 0])                                       # fp32 product, rounded
+    acc = (dd[..., 1] * dd[..., 1] + acc.double()).float()              # fma(dy, dy, acc)
+    return (dd[..., 2] * dd[..., 2] + acc.double()).float()             # fma(dz, dz, acc)
+
+
+def knn_indices(query_xyz, src_xyz, K, fma=False):
+    """pytorch3d.ops.knn_points semantics (call sites point_transformers.py:83,134): squared L2 (knn_distances), K smallest
+    sorted ascending.  Ties: lower index first (upstream: implementation-defined -> unpinned)."""
+    dist = knn_distances(query_xyz, src_xyz, fma)
     # stable sort => lower index first among equal distances
     order = torch.sort(dist, dim=-1, stable=True).indices[..., :K]
     return order
@@ -314,9 +332,9 @@ def decoder_block(w, cfg, i, query_xyz, query_feats, pt_xyz, pt_feats, consts, h
         nxyz_s = consts["anchor"].view(1, 1, -1, 3).expand(B, Q, -1, -1)
         idx_c, nxyz_c = idx_s, nxyz_s
     else:
-        idx_s = knn_indices(query_xyz, query_xyz, cfg.knn)
+        idx_s = knn_indices(query_xyz, query_xyz, cfg.knn, cfg.knn_fma)
         nxyz_s = gather_xyz(query_xyz, idx_s)
-        idx_c = knn_indices(query_xyz, pt_xyz, cfg.knn)
+        idx_c = knn_indices(query_xyz, pt_xyz, cfg.knn, cfg.knn_fma)
         nxyz_c = gather_xyz(pt_xyz, idx_c)
     vp = p + "encoder.vec_attn."
     va_xyz = query_xyz if (anchor_xyz is None or i != 0) else anchor_xyz[None].expand_as(query_xyz)

@@ -56,7 +56,7 @@ int poem_chain_combines(int C, int heads, int chunks);
 void poem_cross_attention_partials(int B, int NQ, int NK, int C, int heads, float* scratch, const void** part_o,
                                    const void** part_ml, int* chunks, float* kc2);
 hipError_t poem_launch_chain(const ChainArgs* a, int C, hipStream_t s);
-hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS, hipStream_t s);
+hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS, int fma, hipStream_t s);
 hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                         const int* idx, int shared_idx, const float* q, const float* k, const float* v,
                                         int nsrc, const float* wd1, const float* bd1, const void* wd2, const float* bd2,
@@ -274,6 +274,7 @@ struct poem_handle_s {
   bool tables_first = true;    // the fused sampling kernel starts behind the anchor-table build (see poem_head_forward)
   bool chain_combine = true;   // chain kind A combines the cross attention's split-key partials itself (no attn_combine launch)
   bool knn_early = true;     // chain mode: issue block i+1's neighbour searches right behind block i's coordinate update
+  int knn_fma = 0;           // neighbour distances with the fma contraction of pytorch3d's CUDA kernel (knn.hip); default: the CPU path's rounding
   int chain_tile = 0;        // chain row-tile height: 0 = per launch (chain.hip chain_tile_p), 1 = 32 rows, 2 = 64 rows (A/B)
   // The block-0 anchor tables are functions of the handle's constants only (template, anchors, weights): like the folded
   // positional table they are built ONCE, at poem_create, into handle-owned memory ("block-0
@@ -516,8 +517,8 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       }
       // the large search first: it gets its CUs before the persistent attention kernel of this block takes them all
       // (+0.8 %; both searches at once on two streams, or both right behind the xyz update of the previous block, lose)
-      HIPCHK(poem_launch_knn(xyz, pt_xyz, p.idx_cross[i], B, Q, S, sk));
-      HIPCHK(poem_launch_knn(xyz, xyz, p.idx_self[i], B, Q, Q, sk));
+      HIPCHK(poem_launch_knn(xyz, pt_xyz, p.idx_cross[i], B, Q, S, h->knn_fma, sk));
+      HIPCHK(poem_launch_knn(xyz, xyz, p.idx_self[i], B, Q, Q, h->knn_fma, sk));
       if (ov) HIPCHK(hipEventRecord(h->ev_knn[i], sk));
       }
       idx_s = p.idx_self[i];
@@ -693,8 +694,8 @@ static int run_decoder(poem_handle_t h, Plan& p, const float* feats_in, const fl
       if (ov && h->knn_early && i + 1 < c.nblocks) {
         HIPCHK(hipEventRecord(h->ev_xyz[i + 1], s));
         HIPCHK(hipStreamWaitEvent(sk, h->ev_xyz[i + 1], 0));
-        HIPCHK(poem_launch_knn(p.xyz[i + 1], pt_xyz, p.idx_cross[i + 1], B, Q, S, sk));
-        HIPCHK(poem_launch_knn(p.xyz[i + 1], p.xyz[i + 1], p.idx_self[i + 1], B, Q, Q, sk));
+        HIPCHK(poem_launch_knn(p.xyz[i + 1], pt_xyz, p.idx_cross[i + 1], B, Q, S, h->knn_fma, sk));
+        HIPCHK(poem_launch_knn(p.xyz[i + 1], p.xyz[i + 1], p.idx_self[i + 1], B, Q, Q, h->knn_fma, sk));
         HIPCHK(hipEventRecord(h->ev_knn[i + 1], sk));
         knn_issued[i + 1] = true;
       }
@@ -1060,6 +1061,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "chain_combine") h->chain_combine = value != 0;
   else if (k == "tables_first") h->tables_first = value != 0;
   else if (k == "tables_cached") h->tables_cached = value != 0;
+  else if (k == "knn_fma") h->knn_fma = value != 0;
   else if (k == "chain_tile") { if (value < 0 || value > 2) return POEM_E_ARG; h->chain_tile = value; }
   else return POEM_E_ARG;
   return POEM_OK;
@@ -1241,7 +1243,14 @@ int poem_cross_attention_split_f16x3(const float* q, const float* k, const float
 
 int poem_knn(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, void* stream) {
   if (!query_xyz || !src_xyz || !idx || batch <= 0 || nq <= 0 || nsrc < 32 || nsrc > 4096) return POEM_E_ARG;
-  HIPCHK(poem_launch_knn(query_xyz, src_xyz, idx, batch, nq, nsrc, (hipStream_t)stream));
+  HIPCHK(poem_launch_knn(query_xyz, src_xyz, idx, batch, nq, nsrc, 0, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_knn_ex(const float* query_xyz, const float* src_xyz, int32_t* idx, int batch, int nq, int nsrc, int fma_contract,
+                void* stream) {
+  if (!query_xyz || !src_xyz || !idx || batch <= 0 || nq <= 0 || nsrc < 32 || nsrc > 4096 || (fma_contract & ~1)) return POEM_E_ARG;
+  HIPCHK(poem_launch_knn(query_xyz, src_xyz, idx, batch, nq, nsrc, fma_contract, (hipStream_t)stream));
   return POEM_OK;
 }
 

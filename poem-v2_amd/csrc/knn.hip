@@ -1,6 +1,7 @@
 // K = 32 nearest source points per query (pytorch3d.ops.knn_points semantics at the reference's call sites):
 // squared L2 evaluated as ((dx*dx + dy*dy) + dz*dz) in fp32 with every operation individually rounded (no fma
-// contraction -- near-ties must order the way the CPU evaluation orders them), ascending, ties -> lower index.
+// contraction -- near-ties must order the way the CPU evaluation orders them; `fma` selects the CUDA kernel's contracted
+// rounding instead), ascending, ties -> lower index.
 // One wave per query; each lane keeps ceil(NS/64) candidate distances in registers (strided so that the source
 // coordinates are read coalesced) and the wave extracts the minimum 32 times.
 //
@@ -24,7 +25,7 @@
 #define POEM_KNN_SURV_CAP 128
 template <int PER, int QPB>
 __global__ __launch_bounds__(QPB * 64) void knn_kernel(const float* __restrict__ qxyz, const float* __restrict__ sxyz,
-                                                       int* __restrict__ idx, int B, int NQ, int NS) {
+                                                       int* __restrict__ idx, int B, int NQ, int NS, int fma) {
   constexpr int NG = PER / 8;                 // groups of 8 registers
   extern __shared__ float sp[];               // NS * 3 floats, then QPB survivor lists of SURV_CAP (distance, index) pairs
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -51,7 +52,10 @@ __global__ __launch_bounds__(QPB * 64) void knn_kernel(const float* __restrict__
 #pragma clang fp contract(off)
       const float dx = qx - sp[c * 3 + 0], dy = qy - sp[c * 3 + 1], dz = qz - sp[c * 3 + 2];
       const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-      d[i] = (xx + yy) + zz;
+      // fma != 0: the rounding of pytorch3d's CUDA kernel instead (knn.cu: `dist += diff * diff` under nvcc's default
+      // -fmad=true is fma(dz, dz, fma(dy, dy, dx * dx))) -- for evaluating against results produced on that path; the
+      // default is the CPU path's (knn_cpu.cpp built without FMA), which BASELINE's parity bar is stated against
+      d[i] = fma ? __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, xx)) : (xx + yy) + zz;
     } else {
       d[i] = INFINITY;
     }
@@ -180,13 +184,13 @@ __global__ __launch_bounds__(QPB * 64) void knn_kernel(const float* __restrict__
   }
 }
 
-extern "C" hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS,
+extern "C" hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS, int fma,
                                       hipStream_t s) {
   constexpr int QPB = 16;
   dim3 grid((unsigned)(B * ((NQ + QPB - 1) / QPB))), block(QPB * 64);
   const size_t lds = (size_t)((NS * 3 + 1) & ~1) * sizeof(float) + (size_t)QPB * POEM_KNN_SURV_CAP * sizeof(float2);
-  if (NS <= 64 * 16) hipLaunchKernelGGL((knn_kernel<16, QPB>), grid, block, lds, s, qxyz, sxyz, idx, B, NQ, NS);
-  else if (NS <= 64 * 64) hipLaunchKernelGGL((knn_kernel<64, QPB>), grid, block, lds, s, qxyz, sxyz, idx, B, NQ, NS);
+  if (NS <= 64 * 16) hipLaunchKernelGGL((knn_kernel<16, QPB>), grid, block, lds, s, qxyz, sxyz, idx, B, NQ, NS, fma);
+  else if (NS <= 64 * 64) hipLaunchKernelGGL((knn_kernel<64, QPB>), grid, block, lds, s, qxyz, sxyz, idx, B, NQ, NS, fma);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

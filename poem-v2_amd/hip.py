@@ -89,6 +89,7 @@ SIGNATURES = {
     "poem_warp_affine": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "poem_pck_accumulate": (_i, [_vp, _vp, _i, _i, ctypes.c_double, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp]),
     "poem_knn": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "poem_knn_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "poem_vector_attention": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _i, _i, _i, _vp]),
     "poem_reg_update": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -381,10 +382,14 @@ def cross_attention(q, k, v, heads, split=False):
     return ctx
 
 
-def knn(query_xyz, src_xyz):
+def knn(query_xyz, src_xyz, fma=False):
+    """fma=True: distances with the fma contraction of pytorch3d's CUDA kernel (include/poem_hip.h poem_knn_ex)."""
     B, NQ, _ = query_xyz.shape
     idx = torch.empty(B, NQ, 32, dtype=torch.int32, device=query_xyz.device)
-    check(lib().poem_knn(ptr(query_xyz), ptr(src_xyz), idx.data_ptr(), B, NQ, src_xyz.shape[1], stream()), "poem_knn")
+    if fma:
+        check(lib().poem_knn_ex(ptr(query_xyz), ptr(src_xyz), idx.data_ptr(), B, NQ, src_xyz.shape[1], 1, stream()), "poem_knn_ex")
+    else:
+        check(lib().poem_knn(ptr(query_xyz), ptr(src_xyz), idx.data_ptr(), B, NQ, src_xyz.shape[1], stream()), "poem_knn")
     return idx
 
 

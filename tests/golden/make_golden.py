@@ -49,6 +49,22 @@ CASES = {
                       ln_spread=0.3),
     "medium_hot": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False,
                        gain=2.5, ln_spread=0.3),
+    # round 3.  (i) the same hot cases with the reference's neighbour search rounding its distances the way pytorch3d's
+    # CUDA kernel does (fma-contracted accumulation, ref_harness.KNN_FMA): what a near-tie at rank 32 costs when the third
+    # party rounds differently from the CPU path; (ii) a conditioning sweep of the medium case (gain 1 / 2.5 / 4 / 6, same
+    # seed and views: "medium_hot" is its gain-2.5 point)
+    "small_hot_fma": dict(model="small", embed=128, nsample=4096, views=[3, 2], seed=21, parametric=False, full=False, gain=2.5,
+                          ln_spread=0.3, knn_fma=True),
+    "medium_hot_fma": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False,
+                           gain=2.5, ln_spread=0.3, knn_fma=True),
+    "medium_g1": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False, gain=1.0,
+                      ln_spread=0.3),
+    "medium_g4": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False, gain=4.0,
+                      ln_spread=0.3),
+    "medium_g6": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False, gain=6.0,
+                      ln_spread=0.3),
+    "medium_g4_fma": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False, gain=4.0,
+                          ln_spread=0.3, knn_fma=True),
 }
 
 
@@ -79,6 +95,7 @@ def run_case(name, spec):
     cfg["POSITIONAL_ENCODING"]["NUM_FEATS"] = C // 2
     cwd = make_cwd(spec["nsample"])
     os.chdir(cwd)
+    rh.KNN_FMA = bool(spec.get("knn_fma", False))
     try:
         head = build_head(cfg, data_preset=CN(y["DATA_PRESET"]))
         head.eval()
@@ -144,6 +161,7 @@ def run_case(name, spec):
         for h in hooks:
             h.remove()
     finally:
+        rh.KNN_FMA = False
         os.chdir(ROOT)
         shutil.rmtree(cwd, ignore_errors=True)
 

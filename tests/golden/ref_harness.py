@@ -112,11 +112,15 @@ class _CfgNode(dict):
         return yaml.safe_dump(dict(self))
 
 
+KNN_FMA = False      # make_golden.py sets it per case ("*_fma": the distance rounding of pytorch3d's CUDA kernel)
+
+
 def knn_points_direct(p1, p2, K, return_nn=False, **kw):
-    """pytorch3d.ops.knn_points stand-in: d = ((dx*dx + dy*dy) + dz*dz) in fp32, K smallest, ascending."""
-    d = p1[:, :, None, :] - p2[:, None, :, :]
-    d = d * d
-    dist = (d[..., 0] + d[..., 1]) + d[..., 2]
+    """pytorch3d.ops.knn_points stand-in: the accumulation loop of pytorch3d's kernels (poem_oracle.knn_distances --
+    ((dx*dx + dy*dy) + dz*dz) as knn_cpu.cpp rounds it, or with KNN_FMA the fma-contracted form nvcc makes of knn.cu),
+    K smallest, ascending."""
+    import poem_oracle as po
+    dist = po.knn_distances(p1, p2, fma=KNN_FMA)
     val, idx = torch.topk(dist, K, dim=-1, largest=False, sorted=True)
     nn = None
     if return_nn:
