@@ -17,6 +17,7 @@ Restates, in numpy:
     copies, and ``to_tensor`` / ``normalize`` against torch on all 256 byte values.
 """
 import pickle
+import math
 import random
 
 import numpy as np
@@ -131,9 +132,31 @@ def transform_coords(pts, A):                                                # :
     return A.dot(hom.transpose()).transpose()[:, :2]
 
 
+def random_occlusion(image, center, scale, prob):
+    """RandomOcclusion.__call__ on the jittered bbox (transform.py:21-66 called from :111-116; box = center_scale_to_box,
+    :1083-1101): one np.random coin; if taken, four ``random.random()`` draws (patch area <= 20 % of the box, aspect in
+    [0.5, 2], position) and -- when the patch lies inside the image -- an (h, w, 3) block of uniform noise * 255 written INTO
+    the caller's uint8 array (numpy truncates on assignment)."""
+    if np.random.rand() > prob:
+        return image
+    xmin, ymin = center[0] - scale * 0.5, center[1] - scale * 0.5
+    bw, bh = (xmin + scale) - xmin, (ymin + scale) - ymin
+    H, W = image.shape[0], image.shape[1]
+    area = (random.random() * 0.2) * bw * bh
+    ratio = random.random() * (1 / 0.5 - 0.5) + 0.5
+    h, w = math.sqrt(area * ratio), math.sqrt(area / ratio)
+    px = random.random() * (bw - w - 1) + xmin
+    py = random.random() * (bh - h - 1) + ymin
+    if px >= 0 and py >= 0 and px + w < W and py + h < H:
+        px, py, w, h = int(px), int(py), int(w), int(h)
+        image[py:py + h, px:px + w, :] = np.random.rand(h, w, 3) * 255
+    return image
+
+
 def simple_transform_3d_multiview(image, label, out_size=(256, 256), is_train=False, aug=None, no_rot=False):
-    """One view.  aug = None (evaluation: AUG false) or dict(center_jit, scale_jit, rot_jit, rot_prob, color_jit) --
-    draws from np.random / random exactly where upstream does (occlusion off, as in every released config)."""
+    """One view.  aug = None (evaluation: AUG false) or dict(center_jit, scale_jit, rot_jit, rot_prob, color_jit
+    [, occlusion_prob]) -- draws from np.random / random exactly where upstream does; ``occlusion_prob`` absent = OCCLUSION
+    False as in every released config (upstream's default when the key is missing is True / 0.1, transform.py:83-84)."""
     if aug is not None:
         c_factor = np.random.normal(loc=0, scale=aug["center_jit"], size=2)
         center = label["bbox_center"] + c_factor * label["bbox_scale"]
@@ -141,6 +164,8 @@ def simple_transform_3d_multiview(image, label, out_size=(256, 256), is_train=Fa
         scale = label["bbox_scale"] * s_factor
         r_factor = np.random.normal(loc=0, scale=aug["rot_jit"])
         rot = np.deg2rad(r_factor) if (not no_rot and np.random.rand() <= aug["rot_prob"]) else 0.0
+        if aug.get("occlusion_prob") is not None:
+            image = random_occlusion(image, center, scale, aug["occlusion_prob"])
     else:
         scale, center, rot = label["bbox_scale"], label["bbox_center"], 0.0
     R3 = rotation_matrix(rot)

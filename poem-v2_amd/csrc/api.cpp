@@ -274,6 +274,18 @@ struct poem_handle_s {
   bool tables_first = true;    // the fused sampling kernel starts behind the anchor-table build (see poem_head_forward)
   bool chain_combine = true;   // chain kind A combines the cross attention's split-key partials itself (no attn_combine launch)
   bool knn_early = true;     // chain mode: issue block i+1's neighbour searches right behind block i's coordinate update
+  // hipGraph replay of the step's launch list (everything between the four kernels that read the caller's inputs and the
+  // one that writes the caller's output touches workspace / handle memory only): captured once per (batch, view layout,
+  // workspace, option set) on an internal stream -- side-stream forks and joins become graph edges -- and replayed with one
+  // hipGraphLaunch per forward instead of ~45 launches + ~25 event calls (host enqueue 0.35 -> ~0.1 ms per forward, which is
+  // what a small batch's latency sees).  Not used while the HIP-event profile or the per-forward table build is on.
+  bool graphs = true;
+  bool graph_broken = false;         // a capture failed once on this handle: stay on plain launches
+  hipStream_t cap_stream = nullptr;
+  struct GraphEntry { std::vector<int64_t> key; hipGraphExec_t exec; uint64_t stamp; };
+  std::vector<GraphEntry> graph_cache;
+  uint64_t graph_clock = 0;
+  static constexpr size_t GRAPH_CAP = 12;
   int knn_fma = 0;           // neighbour distances with the fma contraction of pytorch3d's CUDA kernel (knn.hip); default: the CPU path's rounding
   int chain_tile = 0;        // chain row-tile height: 0 = per launch (chain.hip chain_tile_p), 1 = 32 rows, 2 = 64 rows (A/B)
   // The block-0 anchor tables are functions of the handle's constants only (template, anchors, weights): like the folded
@@ -343,7 +355,7 @@ struct Plan {
   float *qeqp;     // (BQ, 2C): [qe | first attention's query projection]
   // per block kept tensors (taps)
   float *h_cross[8], *f_self[8], *f_cross[8], *feats[8];
-  float *q3t, *par, *attn_scratch;
+  float *q3t, *par, *attn_scratch, *g_pose, *g_betas;
   float *canon_xyz, *tab_g[2], *tab_p[2];   // block-0 anchor tables (self, cross) of the head path
   float *anch_x[2], *anch_kv[2], *qeqp0;    // block 0: anchor rows of the key/value sources, their (k | v) rows; F2 on Q rows
   int32_t* ident;
@@ -398,6 +410,8 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   }
   p.q3t = a.take<float>((size_t)B * C);
   p.par = a.take<float>((size_t)B * 106);
+  p.g_pose = a.take<float>((size_t)B * 48);
+  p.g_betas = a.take<float>((size_t)B * 10);
   p.attn_scratch = a.take<float>(poem_cross_attention_scratch_floats(B, (int)Q, (int)S, (int)C, c.heads, 0) + 4);
   p.canon_xyz = a.take<float>(Q * 3);
   for (int k = 0; k < 2; ++k) {
@@ -997,7 +1011,8 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   if (rc != POEM_OK) { poem_destroy(h); return rc; }
   {
     bool ok = hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess;
+              hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
     auto mk = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
     mk(&h->ev_fork); mk(&h->ev_join_bps); mk(&h->ev_join_knn); mk(&h->ev_tab); mk(&h->ev_fork0);
     for (int i = 0; i < 8; ++i) { mk(&h->ev_bps[i]); mk(&h->ev_xyz[i]); mk(&h->ev_knn[i]); }
@@ -1033,6 +1048,8 @@ void poem_destroy(poem_handle_t h) {
   if (h->split_mem) (void)hipFree(h->split_mem);
   if (h->gemm_split) (void)hipFree(h->gemm_split);
   if (h->gemm_scales) (void)hipFree(h->gemm_scales);
+  for (auto& g : h->graph_cache) (void)hipGraphExecDestroy(g.exec);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
   if (h->bps_stream) (void)hipStreamDestroy(h->bps_stream);
   if (h->knn_stream) (void)hipStreamDestroy(h->knn_stream);
   delete h;
@@ -1062,6 +1079,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "tables_first") h->tables_first = value != 0;
   else if (k == "tables_cached") h->tables_cached = value != 0;
   else if (k == "knn_fma") h->knn_fma = value != 0;
+  else if (k == "graphs") h->graphs = value != 0;
   else if (k == "chain_tile") { if (value < 0 || value > 2) return POEM_E_ARG; h->chain_tile = value; }
   else return POEM_E_ARG;
   return POEM_OK;
@@ -1465,9 +1483,6 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
     // the host vectors die at return: pageable H2D copies complete (are staged) before hipMemcpyAsync returns.
   }
 
-#define GEMM(X, LDX, WI, BI, RES, LDR, Y, LDY, M, N, K, ACT) \
-  HIPCHK(poem_launch_gemm(X, LDX, h->P(WI), (BI) >= 0 ? h->R(BI) : nullptr, RES, LDR, Y, LDY, M, N, K, ACT, s))
-
   h->tables_pending = false;
   if (h->anchor_tables && h->precision == POEM_PRECISION_FP32) {
     if (h->tables_cached && h->tab_mem) {
@@ -1491,39 +1506,94 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
     HIPCHK(poem_launch_invert_extr(cam_extr, inv, BN, s));
     HIPCHK(poem_launch_project_table(h->bps, p.centre, p.view_sample, cam_intr, inv, p.ptab, nullptr, BN, C, c.feat_h, c.feat_w,
                                      S, img_w, img_h, s));
-    SampleMergeArgs sm{};
-    sm.xt = p.xt; sm.tab = (const float4*)p.ptab; sm.view_sample = p.view_sample; sm.offs = p.offs;
-    sm.w0 = (const float4*)h->P(T_M00_W); sm.b0 = h->R(T_M00_B); sm.w1 = (const float4*)h->P(T_M02_W); sm.b1 = h->R(T_M02_B);
-    sm.h2 = p.h2; sm.q1 = p.q1; sm.views = BN; sm.S = S; sm.hw = HW; sm.h2_tiled = 1;
-    // The anchor-table build on the neighbour-search stream holds 68 KB of LDS per block, and next to the MFMA-dense
-    // sample_merge waves its blocks linger: a CU that hosts one takes a single sample_merge block (2 x 66.5 KB no longer
-    // fit) and the persistent grid runs in two rounds -- 2.55 instead of 1.69 ms in a third of the forwards.  The build
-    // overlaps input_proj / the projection; sample_merge waits for it (+0.06 ms on the critical path, always).
-    if (h->tables_first && h->tables_pending) HIPCHK(hipStreamWaitEvent(s, h->ev_tab, 0));
-    HIPCHK(poem_launch_sample_merge(&sm, C, s));
-    MergeTailArgs mt{};
-    mt.h2 = p.h2; mt.q1 = p.q1; mt.offs = p.offs;
-    mt.w0 = (const float4*)h->P(T_M10_W); mt.b0 = h->R(T_M10_B); mt.w1 = (const float4*)h->P(T_M12_W); mt.b1 = h->R(T_M12_B);
-    mt.out = p.bps_feat; mt.B = B; mt.S = S; mt.h2_tiled = 1;
-    HIPCHK(poem_launch_merge_tail(&mt, C, s));
-  } else {
-  HIPCHK(poem_launch_project_sample(p.x, h->bps, p.centre, p.view_sample, cam_intr, cam_extr, p.uv + (size_t)BN * S * 2,
-                                    p.uv, p.g, BN, C, c.feat_h, c.feat_w, S, img_w, img_h, s));
-  // merge MLP 0 on the Q1 rows == the (BN*S, C) row-major view of g's memory
-  GEMM(p.g, C, T_M00_W, T_M00_B, nullptr, 0, p.h1, C, BN * S, C, C, POEM_ACT_RELU);
-  GEMM(p.h1, C, T_M02_W, T_M02_B, nullptr, 0, p.h2, C / 2, BN * S, C / 2, C, POEM_ACT_NONE);
-  HIPCHK(poem_launch_merge_reduce(p.h2, p.offs, p.mm, B, S, C / 2, s));
-  GEMM(p.mm, C / 2, T_M10_W, T_M10_B, nullptr, 0, p.mh, C / 2, BS, C / 2, C / 2, POEM_ACT_RELU);
-  GEMM(p.mh, C / 2, T_M12_W, T_M12_B, nullptr, 0, p.y, C, BS, C, C / 2, POEM_ACT_NONE);
-  HIPCHK(poem_launch_merge_finalize(p.g, p.y, p.offs, p.bps_feat, B, S, C, s));
   }
-  if (prof_fe) HIPCHK(hipEventRecord(h->prof_ev[2 * prof_fe_slot + 1], s));
-
-  // ---- decoder ---------------------------------------------------------------------------------------------------
-  HIPCHK(poem_launch_broadcast(h->R(T_QEMB), p.feats0, (long)Q * C, B, s));
+  // Everything from here to the de-normalisation reads and writes workspace / handle memory only.
+  auto body = [&](hipStream_t st, float* pose_dst, float* betas_dst) -> int {
+#define GEMM(X, LDX, WI, BI, RES, LDR, Y, LDY, M, N, K, ACT) \
+  HIPCHK(poem_launch_gemm(X, LDX, h->P(WI), (BI) >= 0 ? h->R(BI) : nullptr, RES, LDR, Y, LDY, M, N, K, ACT, st))
+    if (fused_fe) {
+      SampleMergeArgs sm{};
+      sm.xt = p.xt; sm.tab = (const float4*)p.ptab; sm.view_sample = p.view_sample; sm.offs = p.offs;
+      sm.w0 = (const float4*)h->P(T_M00_W); sm.b0 = h->R(T_M00_B); sm.w1 = (const float4*)h->P(T_M02_W); sm.b1 = h->R(T_M02_B);
+      sm.h2 = p.h2; sm.q1 = p.q1; sm.views = BN; sm.S = S; sm.hw = HW; sm.h2_tiled = 1;
+      // (per-forward table build only) The build on the neighbour-search stream holds 68 KB of LDS per block, and next to the
+      // MFMA-dense sample_merge waves its blocks linger: a CU that hosts one takes a single sample_merge block (2 x 66.5 KB no
+      // longer fit) and the persistent grid runs in two rounds -- 2.55 instead of 1.69 ms in a third of the forwards.  The
+      // build overlaps input_proj / the projection; sample_merge waits for it (+0.06 ms on the critical path).
+      if (h->tables_first && h->tables_pending) HIPCHK(hipStreamWaitEvent(st, h->ev_tab, 0));
+      HIPCHK(poem_launch_sample_merge(&sm, C, st));
+      MergeTailArgs mt{};
+      mt.h2 = p.h2; mt.q1 = p.q1; mt.offs = p.offs;
+      mt.w0 = (const float4*)h->P(T_M10_W); mt.b0 = h->R(T_M10_B); mt.w1 = (const float4*)h->P(T_M12_W); mt.b1 = h->R(T_M12_B);
+      mt.out = p.bps_feat; mt.B = B; mt.S = S; mt.h2_tiled = 1;
+      HIPCHK(poem_launch_merge_tail(&mt, C, st));
+    } else {
+      HIPCHK(poem_launch_project_sample(p.x, h->bps, p.centre, p.view_sample, cam_intr, cam_extr, p.uv + (size_t)BN * S * 2,
+                                        p.uv, p.g, BN, C, c.feat_h, c.feat_w, S, img_w, img_h, st));
+      // merge MLP 0 on the Q1 rows == the (BN*S, C) row-major view of g's memory
+      GEMM(p.g, C, T_M00_W, T_M00_B, nullptr, 0, p.h1, C, BN * S, C, C, POEM_ACT_RELU);
+      GEMM(p.h1, C, T_M02_W, T_M02_B, nullptr, 0, p.h2, C / 2, BN * S, C / 2, C, POEM_ACT_NONE);
+      HIPCHK(poem_launch_merge_reduce(p.h2, p.offs, p.mm, B, S, C / 2, st));
+      GEMM(p.mm, C / 2, T_M10_W, T_M10_B, nullptr, 0, p.mh, C / 2, BS, C / 2, C / 2, POEM_ACT_RELU);
+      GEMM(p.mh, C / 2, T_M12_W, T_M12_B, nullptr, 0, p.y, C, BS, C, C / 2, POEM_ACT_NONE);
+      HIPCHK(poem_launch_merge_finalize(p.g, p.y, p.offs, p.bps_feat, B, S, C, st));
+    }
 #undef GEMM
-  {
-    const int rc = run_decoder(h, p, p.feats0, p.pt_xyz, p.bps_feat, B, pose_aa, betas, s, true);
+    if (prof_fe) HIPCHK(hipEventRecord(h->prof_ev[2 * prof_fe_slot + 1], st));
+    // ---- decoder -------------------------------------------------------------------------------------------------
+    HIPCHK(poem_launch_broadcast(h->R(T_QEMB), p.feats0, (long)Q * C, B, st));
+    return run_decoder(h, p, p.feats0, p.pt_xyz, p.bps_feat, B, pose_dst, betas_dst, st, true);
+  };
+  // ---- graph replay or plain launches ----------------------------------------------------------------------------------
+  bool replayed = false;
+  if (h->graphs && !h->graph_broken && fused_fe && !h->prof_on && !h->tables_pending && h->cap_stream) {
+    std::vector<int64_t> key = {B, BN, img_w, img_h, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
+                                h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
+                                h->tables_cached, h->knn_fma, h->taps, c.parametric};
+    key.insert(key.end(), view_offsets_host, view_offsets_host + B + 1);
+    poem_handle_s::GraphEntry* hit = nullptr;
+    for (auto& g : h->graph_cache)
+      if (g.key == key) { hit = &g; break; }
+    if (!hit) {
+      // capture the body on the internal stream (the caller's may be the legacy default stream, which cannot be captured);
+      // the side-stream forks / joins inside run_decoder become edges of the same graph
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      bool ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+      if (ok) {
+        const int rc = body(h->cap_stream, p.g_pose, p.g_betas);
+        const hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
+        ok = rc == POEM_OK && e == hipSuccess && graph != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (!ok) {
+        (void)hipGetLastError();
+        h->graph_broken = true;               // plain launches from now on (results are the same either way)
+      } else {
+        if (h->graph_cache.size() >= poem_handle_s::GRAPH_CAP) {      // evict the least recently used
+          size_t lru = 0;
+          for (size_t i = 1; i < h->graph_cache.size(); ++i)
+            if (h->graph_cache[i].stamp < h->graph_cache[lru].stamp) lru = i;
+          (void)hipGraphExecDestroy(h->graph_cache[lru].exec);
+          h->graph_cache.erase(h->graph_cache.begin() + lru);
+        }
+        h->graph_cache.push_back({key, exec, 0});
+        hit = &h->graph_cache.back();
+      }
+    }
+    if (hit) {
+      hit->stamp = ++h->graph_clock;
+      HIPCHK(hipGraphLaunch(hit->exec, s));
+      if (c.parametric) {
+        HIPCHK(hipMemcpyAsync(pose_aa, p.g_pose, (size_t)B * 48 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(betas, p.g_betas, (size_t)B * 10 * sizeof(float), hipMemcpyDeviceToDevice, s));
+      }
+      replayed = true;
+    }
+  }
+  if (!replayed) {
+    const int rc = body(s, pose_aa, betas);
     if (rc != POEM_OK) return rc;
   }
   HIPCHK(poem_launch_finalize(p.xyz[1], p.centre, out_xyz, c.nblocks, B, Q, c.radius, s));

@@ -92,8 +92,18 @@ class POEM_Generalized_Head(nn.Module):
                                  self.parametric_output)
         return {k: sd[k].reshape(s) for k, s in shapes.items()}
 
+    def _apply(self, fn, *a, **k):
+        self._plist = None                     # .to() / .cuda() / .float(): the parameters move
+        return super()._apply(fn, *a, **k)
+
     def _engine_for(self, device):
-        sig = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        # The engine packs the weights once; it is rebuilt when any parameter's storage or version counter changes
+        # (load_state_dict, .to(), in-place edits).  The Parameter objects are cached: walking the module tree for its 199
+        # parameters costs ~0.3 ms of host time per forward -- more than enqueueing the whole step (a hipGraph replay).
+        self._pcheck = getattr(self, "_pcheck", 0) + 1
+        if getattr(self, "_plist", None) is None or self._pcheck % 256 == 0:
+            self._plist = list(self.parameters())
+        sig = (str(device),) + tuple((p.data_ptr(), p._version) for p in self._plist)
         if self._engine is None or self._engine_sig != sig:
             t = self.transformer
             cfg = hip.make_config(self.embed_dims, in_channels=self.in_channels, nsample=self.nsample, nquery=799,

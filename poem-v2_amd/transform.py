@@ -11,6 +11,7 @@ frame: closed-form crop matrices for all views at once (:func:`crop_geometry`) i
 No CPU fallback: without the HIP library / a GPU the image side raises (``hip.lib()``); the label side
 (:meth:`SimpleTransform3DMultiView.labels`) is pure numpy and runs anywhere.
 """
+import math
 import random
 
 import numpy as np
@@ -86,10 +87,11 @@ def crop_geometry(center, scale, rot, principal, out_size):
 
 
 def _rows_times(mat, pts):
-    """mat (3,3), pts (n,3) -> rows  m[r,0]*x + m[r,1]*y + m[r,2]*z  summed left to right, in the promoted dtype."""
-    dt = np.result_type(mat.dtype, pts.dtype)
-    m, p = mat.astype(dt), np.asarray(pts).astype(dt)
-    return (m[None, :, 0] * p[:, 0:1] + m[None, :, 1] * p[:, 1:2]) + m[None, :, 2] * p[:, 2:3]
+    """mat (3,3), pts (n,3) -> (n,3) rows ``mat @ p`` in the promoted dtype, as ONE matrix product ``mat.dot(pts.T).T`` -- the
+    form upstream uses (transform.py:311-312), so that the host BLAS rounds both sides alike (its k-loop is fma-accumulated:
+    a hand-written ``(m0 x + m1 y) + m2 z`` differs from it in the last bit on ~1 % of the coordinates)."""
+    dt = np.result_type(mat.dtype, np.asarray(pts).dtype)
+    return mat.astype(dt).dot(np.asarray(pts).astype(dt).transpose(1, 0)).transpose()
 
 
 # ---- the device stage -------------------------------------------------------------------------------------------------
@@ -178,11 +180,34 @@ def warp_views(images, affines, out_size, gains=None, device="cuda:0", out="f32"
 
 # ---- the transform ------------------------------------------------------------------------------------------------------
 class ViewDraw:
-    """The random part of one view's augmentation: bbox centre / scale jitter, in-plane rotation, colour gains."""
-    __slots__ = ("center", "scale", "rot", "gain")
+    """The random part of one view's augmentation: bbox centre / scale jitter, in-plane rotation, colour gains and the
+    occlusion patch (x, y, w, h, noise (h, w, 3)) or None."""
+    __slots__ = ("center", "scale", "rot", "gain", "patch")
 
-    def __init__(self, center, scale, rot=0.0, gain=None):
-        self.center, self.scale, self.rot, self.gain = center, scale, rot, gain
+    def __init__(self, center, scale, rot=0.0, gain=None, patch=None):
+        self.center, self.scale, self.rot, self.gain, self.patch = center, scale, rot, gain, patch
+
+
+def draw_occlusion_patch(center, scale, width, height, prob):
+    """The random-occlusion draw of one view (upstream ``RandomOcclusion``, transform.py:21-66, applied to the jittered box at
+    :111-116): consumes one ``np.random.rand()`` and, when the coin falls at or below ``prob``, four ``random.random()``
+    values -- relative area (up to a fifth of the box), aspect ratio (0.5 .. 2), left edge, top edge -- and, if the patch lies
+    inside the (width, height) image, ``np.random.rand(h, w, 3)``.  -> (x, y, w, h, noise * 255) or None.  Every expression
+    keeps upstream's operand order: the fixture pins the patched pixels through their CRC."""
+    if np.random.rand() > prob:
+        return None
+    left, top = center[0] - scale * 0.5, center[1] - scale * 0.5
+    box_w, box_h = (left + scale) - left, (top + scale) - top           # (xmax - xmin as upstream forms it)
+    rel_area, rel_aspect, rel_x, rel_y = random.random(), random.random(), random.random(), random.random()
+    area = (rel_area * 0.2) * box_w * box_h
+    aspect = rel_aspect * (2.0 - 0.5) + 0.5
+    ph, pw = math.sqrt(area * aspect), math.sqrt(area / aspect)
+    x = rel_x * (box_w - pw - 1) + left
+    y = rel_y * (box_h - ph - 1) + top
+    if not (x >= 0 and y >= 0 and x + pw < width and y + ph < height):
+        return None
+    x, y, pw, ph = int(x), int(y), int(pw), int(ph)
+    return x, y, pw, ph, np.random.rand(ph, pw, 3) * 255
 
 
 @TRANSFORM.register_module()
@@ -194,9 +219,10 @@ class SimpleTransform3DMultiView:
       :meth:`frame_labels`  the label arithmetic of all views of a frame in one vectorised pass (:func:`crop_geometry`)
       :meth:`images`        the pixels of any number of views in ONE ``poem_warp_affine`` launch
 
-    ``__call__(image, label, no_rot=False)`` is the per-view form with the reference's signature.  Heat-map / mask targets
-    and the random-occlusion patch belong to the training losses / training augmentation and are not built (the released
-    configs switch the occlusion off: config/release/train_*.yaml ``OCCLUSION: False``)."""
+    ``__call__(image, label, no_rot=False)`` is the per-view form with the reference's signature.  The random-occlusion patch
+    (upstream default when the TRANSFORM node carries no OCCLUSION key; the released configs switch it off) is drawn with the
+    view's other random numbers and written into a copy of the raw image before the upload.  Heat-map / mask targets belong to
+    the training losses and are not built."""
 
     def __init__(self, cfg):
         self._output_size, self._train, self._aug = cfg.DATA_PRESET.IMAGE_SIZE, cfg.IS_TRAIN, cfg.AUG
@@ -204,17 +230,19 @@ class SimpleTransform3DMultiView:
         self._jitter = {"center": cfg.get("CENTER_JIT", 0), "scale": cfg.get("SCALE_JIT", 0.04 if on else 0),
                         "rot_deg": cfg.get("ROT_JIT", 10 if on else 0), "color": cfg.get("COLOR_JIT", 0.3 if on else 0)}
         self._rot_prob = cfg.get("ROT_PROB", 1.0 if on else 0)
-        if cfg.get("OCCLUSION", on) and cfg.get("OCCLUSION_PROB", 0.1 if on else 0) > 0:
-            raise NotImplementedError("OCCLUSION is a training-time augmentation outside the built path; set OCCLUSION: False")
+        # upstream's defaults when the keys are absent: on with probability 0.1 under AUG (transform.py:83-84); the released
+        # configs say OCCLUSION: False.  The patch is host-side work on the raw uint8 image, before the upload.
+        self._occlusion_prob = cfg.get("OCCLUSION_PROB", 0.1 if on else 0) if cfg.get("OCCLUSION", on) else None
         if cfg.DATA_PRESET.get("WITH_HEATMAP", False) or cfg.DATA_PRESET.get("WITH_MASK", False):
             raise NotImplementedError("heat-map / mask targets are training-side and outside the built path")
         self.device = cfg.get("DEVICE", "cuda:0")
 
     # -- random numbers ---------------------------------------------------------------------------------------------------
-    def draw(self, label, no_rot=False):
+    def draw(self, label, no_rot=False, image_shape=None):
         """Consumes the generators exactly as one upstream ``__call__`` does: four normal deviates from ``np.random``
-        (centre x/y, scale, angle), one uniform unless ``no_rot`` (the master view keeps its orientation), and -- from the
-        ``random`` module, an independent stream -- three colour gains."""
+        (centre x/y, scale, angle), one uniform unless ``no_rot`` (the master view keeps its orientation), the occlusion
+        draw when OCCLUSION is on (:func:`draw_occlusion_patch`; needs the raw image's (H, W)) and -- from the ``random``
+        module, an independent stream -- three colour gains."""
         if not self._aug:
             return ViewDraw(label["bbox_center"], label["bbox_scale"])
         j = self._jitter
@@ -223,8 +251,13 @@ class SimpleTransform3DMultiView:
         scale = label["bbox_scale"] * (1 + j["scale"] * z[2])
         turn = (not no_rot) and np.random.rand() <= self._rot_prob
         rot = np.deg2rad(0 + j["rot_deg"] * z[3]) if turn else 0.0
+        patch = None
+        if self._occlusion_prob is not None:
+            if image_shape is None:
+                raise ValueError("OCCLUSION is on: draw() needs image_shape=(H, W) of the raw view")
+            patch = draw_occlusion_patch(center, scale, image_shape[1], image_shape[0], self._occlusion_prob)
         lo, hi = 1 - j["color"], 1 + j["color"]
-        return ViewDraw(center, scale, rot, [random.uniform(lo, hi) for _ in range(3)])
+        return ViewDraw(center, scale, rot, [random.uniform(lo, hi) for _ in range(3)], patch)
 
     # -- labels -----------------------------------------------------------------------------------------------------------
     def frame_labels(self, images, labels, draws):
@@ -253,9 +286,14 @@ class SimpleTransform3DMultiView:
             dt = np.result_type(p.dtype, k.dtype)
             intr = np.stack([p[0, 0].astype(dt) * k[0].astype(dt) + p[0, 2].astype(dt) * k[2].astype(dt),
                              p[1, 1].astype(dt) * k[1].astype(dt) + p[1, 2].astype(dt) * k[2].astype(dt), k[2].astype(dt)])
+            raw = images[v]
+            if d.patch is not None:                     # (upstream writes into the caller's array; a copy is patched here)
+                x, y, pw, ph, noise = d.patch
+                raw = np.array(raw, copy=True)
+                raw[y:y + ph, x:x + pw, :] = noise      # float -> uint8 truncation on assignment, as upstream
             out.append({"rot_rad": d.rot, "rot_mat3d": R[v], "affine": A[v], "target_bbox_center": d.center,
                         "target_bbox_scale": d.scale, "target_joints_2d": uv, "target_joints_vis": vis,
-                        "image_path": lab["image_path"], "color_gain": d.gain, "raw_image": images[v],
+                        "image_path": lab["image_path"], "color_gain": d.gain, "raw_image": raw,
                         "affine_postrot": p, "extr_prerot": R[v], "target_cam_intr": intr,
                         "target_joints_3d": _rows_times(R[v], lab["joints_3d"]),
                         "target_verts_3d": _rows_times(R[v], lab["verts_3d"]),
@@ -264,7 +302,7 @@ class SimpleTransform3DMultiView:
 
     def labels(self, image, label, **kwargs):
         """One view: draw, then the label arithmetic (pure numpy, runs anywhere)."""
-        return self.frame_labels([image], [label], [self.draw(label, kwargs.get("no_rot", False))])[0]
+        return self.frame_labels([image], [label], [self.draw(label, kwargs.get("no_rot", False), np.shape(image)[:2])])[0]
 
     # -- pixels -----------------------------------------------------------------------------------------------------------
     def images(self, results_list):

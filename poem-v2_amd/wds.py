@@ -244,7 +244,7 @@ class MultiviewWebDataset:
         pixels = [cams[c] for c in keep]
         if labels.get("request_flip", False):
             pixels = self._mirrored(pixels, [lab["cam_intr"] for lab in view_labels], [lab["raw_size"] for lab in view_labels])
-        draws = [self.transform.draw(lab, no_rot=(c == master)) for lab, c in zip(view_labels, keep)]
+        draws = [self.transform.draw(lab, no_rot=(c == master), image_shape=np.shape(px)[:2]) for lab, c, px in zip(view_labels, keep, pixels)]
         views = self.transform.frame_labels(pixels, view_labels, draws)
         extr = self.remaster_extrinsics([lab["cam_extr"] for lab in view_labels], [v["extr_prerot"] for v in views])
         for v, lab, e in zip(views, view_labels, extr):

@@ -12,6 +12,7 @@ definitions, ``webdataset`` / ``braceexpand`` by mocks (only the record-processi
 import os
 import random
 import sys
+import zlib
 from unittest.mock import MagicMock
 
 import numpy as np
@@ -32,6 +33,9 @@ CASES = {
     "eval_random_views": ("Interhand", [(3, 8), (4, 6)], True, [2, 5], False, False, np.float32, 7),
     "train_aug": ("DexYCB", [(5, 4), (6, 2)], True, [1, 8], True, False, np.float64, 11),
     "flip": ("Oakink", [(7, 3)], False, None, False, True, np.float32, 13),
+    # round 3: the reference's DEFAULT augmentation keys -- OCCLUSION absent from the TRANSFORM node means on, probability 0.1
+    # (lib/utils/transform.py:83-84); a high probability here so that patches are actually drawn ("occl")
+    "train_occlusion": ("DexYCB", [(8, 4), (9, 3)], True, [2, 6], "occl", False, np.float64, 17),
 }
 AUG = {"AUG": True, "CENTER_JIT": 0.05, "SCALE_JIT": 0.06, "ROT_JIT": 5, "COLOR_JIT": 0.3, "ROT_PROB": 0.5,
        "OCCLUSION": False, "OCCLUSION_PROB": 0.2}                      # config/release/train_medium.yaml:31-40
@@ -50,7 +54,7 @@ def main():
     calls = []
 
     def fake_warp(img, M, dsize, **kw):
-        calls.append((np.array(M, dtype=np.float64), tuple(int(v) for v in dsize)))
+        calls.append((np.array(M, dtype=np.float64), tuple(int(v) for v in dsize), zlib.crc32(np.ascontiguousarray(img).tobytes())))
         return np.zeros((int(dsize[1]), int(dsize[0]), 3), dtype=np.uint8)
 
     T.cv2 = MagicMock()
@@ -64,9 +68,10 @@ def main():
     for name, (ds, frames, rnd, vr, aug, flip, dt, seed) in CASES.items():
         cfg = CN({"URLS": f"data/dataset_tars/{ds}_mv/{ds}_mv_test-{{000000..000003}}.tar", "DATA_SPLIT": "test",
                   "RANDOM_N_VIEWS": rnd, "VIEW_RANGE": vr,
-                  "TRANSFORM": dict({"TYPE": "SimpleTransform3DMultiView"}, **(AUG if aug else {"AUG": False})),
+                  "TRANSFORM": dict({"TYPE": "SimpleTransform3DMultiView"},
+                                    **(dict(AUG, OCCLUSION=True, OCCLUSION_PROB=0.7) if aug == "occl" else AUG if aug else {"AUG": False})),
                   "DATA_PRESET": {"IMAGE_SIZE": [256, 256], "CENTER_IDX": 9}})
-        dset = MW.MultiviewWebDataset(cfg, data_preset=cfg.DATA_PRESET, is_train=aug)
+        dset = MW.MultiviewWebDataset(cfg, data_preset=cfg.DATA_PRESET, is_train=bool(aug))
         random.seed(seed)
         np.random.seed(seed)
         outs = []
@@ -82,6 +87,7 @@ def main():
             rec[f"{name}.{fi}.target_verts_3d_s16"] = np.asarray(out["target_verts_3d"])[:, ::16]
             rec[f"{name}.{fi}.warp_M"] = np.stack([c[0] for c in calls])
             rec[f"{name}.{fi}.warp_size"] = np.asarray([c[1] for c in calls])
+            rec[f"{name}.{fi}.warp_src_crc"] = np.asarray([c[2] for c in calls], dtype=np.int64)   # the pixels handed to the warp (occlusion patches included)
             rec[f"{name}.{fi}.master_serial"] = np.asarray(out["master_serial"])
             rec[f"{name}.{fi}.image_shape"] = np.asarray(out["image"].shape)
         col = collation_random_n_views(outs)

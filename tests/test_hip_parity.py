@@ -806,7 +806,9 @@ def test_full_size_batch_properties():
     # A/B switches that must not change a bit: forced 32- / 64-row chain tiles, the block-0 anchor tables rebuilt per forward
     # (the round-2 behaviour) instead of read from the handle, where poem_create folded them
     eng = head._engine
-    for name, val in (("chain_tile", 1), ("chain_tile", 2), ("chain_tile", 0), ("tables_cached", 0), ("tables_cached", 1)):
+    # ... and the hipGraph replay of the launch list against plain launches (first call of a layout captures, later calls replay)
+    for name, val in (("chain_tile", 1), ("chain_tile", 2), ("chain_tile", 0), ("tables_cached", 0), ("tables_cached", 1),
+                      ("graphs", 0), ("graphs", 1), ("graphs", 1)):
         eng.set_option(name, val)
         with torch.no_grad():
             again = head(feat, metas, rj)["all_coords_preds"]

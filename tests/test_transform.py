@@ -21,6 +21,8 @@ CASES = {   # mirrors tests/golden/make_golden_transform.py::CASES
     "eval_random_views": ("Interhand", [(3, 8), (4, 6)], True, [2, 5], False, False, np.float32, 7),
     "train_aug": ("DexYCB", [(5, 4), (6, 2)], True, [1, 8], True, False, np.float64, 11),
     "flip": ("Oakink", [(7, 3)], False, None, False, True, np.float32, 13),
+    # upstream's default augmentation keys include the random occlusion patch (OCCLUSION absent = on, lib/utils/transform.py:83-84)
+    "train_occlusion": ("DexYCB", [(8, 4), (9, 3)], True, [2, 6], "occl", False, np.float64, 17),
 }
 KEYS = ("affine", "affine_postrot", "rot_mat3d", "extr_prerot", "target_cam_intr", "target_cam_extr", "target_joints_2d",
         "target_joints_vis", "target_joints_3d", "target_joints_3d_no_rot", "target_bbox_center", "target_bbox_scale",
@@ -40,6 +42,20 @@ def _frames(case):
         yield item
 
 
+def _oracle_aug(aug):
+    if not aug:
+        return None
+    d = dict(center_jit=0.05, scale_jit=0.06, rot_jit=5, rot_prob=0.5, color_jit=0.3)
+    if aug == "occl":
+        d["occlusion_prob"] = 0.7
+    return d
+
+
+def _crc(img):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(img).tobytes())
+
+
 def _same(a, b, what):
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
@@ -47,15 +63,20 @@ def _same(a, b, what):
 
 
 @pytest.mark.parametrize("case", list(CASES))
-def test_oracle_labels_match_reference(case):
+def test_oracle_labels_match_reference(case, monkeypatch):
     z = _golden()
     ds, frames, rnd, vr, aug, flip, dt, seed = CASES[case]
     random.seed(seed)
     np.random.seed(seed)
-    tf = dict(is_train=aug, aug=dict(center_jit=0.05, scale_jit=0.06, rot_jit=5, rot_prob=0.5, color_jit=0.3) if aug else None)
+    tf = dict(is_train=bool(aug), aug=_oracle_aug(aug))
+    warped_src, real_warp = [], to.warp_affine_u8
+    monkeypatch.setattr(to, "warp_affine_u8", lambda img, M, size: (warped_src.append(_crc(img)), real_warp(img, M, size))[1])
     for fi, item in enumerate(_frames(case)):
+        del warped_src[:]
         out = to.process_data_item(item, inv_extr=ds in ("Interhand", "Arctic", "Oakink", "Oakink2"), random_n_views=rnd,
                                    view_range=vr, **tf)
+        if not flip:            # the pixels handed to the warp (occlusion patches included) are the reference's, byte for byte
+            assert warped_src == z[f"{case}.{fi}.warp_src_crc"].tolist(), (case, fi)
         for k in KEYS:
             _same(out[k], z[f"{case}.{fi}.{k}"], f"{case}.{fi}.{k}")
         _same(np.asarray(out["target_verts_3d"])[:, ::16], z[f"{case}.{fi}.target_verts_3d_s16"], "verts")
@@ -66,13 +87,15 @@ def test_oracle_labels_match_reference(case):
 def _dataset(case, defer, device=DEV):
     import poem_v2_amd as pk
     ds, frames, rnd, vr, aug, flip, dt, seed = CASES[case]
-    cfg = pk.wds.dataset_cfg(f"data/dataset_tars/{ds}_mv/{ds}_mv_test-{{000000..000003}}.tar", view_range=vr, device=device,
-                             **({k: v for k, v in AUG.items() if k != "AUG"} if aug else {}))
-    cfg.TRANSFORM.AUG = aug
-    return pk.MultiviewWebDataset(cfg, data_preset=cfg.DATA_PRESET, is_train=aug, defer_images=defer)
+    keys = {k: v for k, v in AUG.items() if k != "AUG"} if aug else {}
+    if aug == "occl":
+        keys.update(OCCLUSION=True, OCCLUSION_PROB=0.7)
+    cfg = pk.wds.dataset_cfg(f"data/dataset_tars/{ds}_mv/{ds}_mv_test-{{000000..000003}}.tar", view_range=vr, device=device, **keys)
+    cfg.TRANSFORM.AUG = bool(aug)
+    return pk.MultiviewWebDataset(cfg, data_preset=cfg.DATA_PRESET, is_train=bool(aug), defer_images=defer)
 
 
-@pytest.mark.parametrize("case", ["eval", "eval_random_views", "train_aug"])
+@pytest.mark.parametrize("case", ["eval", "eval_random_views", "train_aug", "train_occlusion"])
 def test_product_labels_match_reference(case):
     """The host side of the product (no GPU needed with deferred pixels) against the reference's outputs, and the
     matrices it will hand to the warp against the ones the reference handed to cv2.warpAffine."""
@@ -92,7 +115,8 @@ def test_product_labels_match_reference(case):
         _same(np.asarray(out["target_verts_3d"])[:, ::16], z[f"{case}.{fi}.target_verts_3d_s16"], "verts")
         M = np.stack([np.asarray(a, np.float64)[:2] for a in out["affine"]])
         _same(M, z[f"{case}.{fi}.warp_M"], "warp matrices")
-        assert len(out["raw_image"]) == len(M) and (out["color_gain"][0] is not None) == aug
+        assert len(out["raw_image"]) == len(M) and (out["color_gain"][0] is not None) == bool(aug)
+        assert [_crc(im) for im in out["raw_image"]] == z[f"{case}.{fi}.warp_src_crc"].tolist()      # incl. the occlusion patches
     with pytest.raises(ValueError):
         pk.collation_random_n_views(outs)                       # deferred pixels need the transform
     for o in outs:                                              # label-only collation
@@ -269,7 +293,7 @@ def test_warp_kernel_bit_exact_against_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["eval", "eval_random_views", "train_aug", "flip"])
+@pytest.mark.parametrize("case", ["eval", "eval_random_views", "train_aug", "flip", "train_occlusion"])
 def test_pipeline_matches_oracle(case, tmp_path):
     """shard on disk -> MultiviewWebDataset -> collation, per-frame launches and the single-launch batch form, against the
     oracle's process_data_item on the same records (pixels bit-exact, labels exact)."""
@@ -277,7 +301,7 @@ def test_pipeline_matches_oracle(case, tmp_path):
     ds, frames, rnd, vr, aug, flip, dt, seed = CASES[case]
     path = str(tmp_path / f"{ds}_mv_test-000000.tar")
     pk.wds.write_shard(path, list(_frames(case)))
-    tf = dict(is_train=aug, aug=dict(center_jit=0.05, scale_jit=0.06, rot_jit=5, rot_prob=0.5, color_jit=0.3) if aug else None)
+    tf = dict(is_train=bool(aug), aug=_oracle_aug(aug))
     random.seed(seed)
     np.random.seed(seed)
     want = [to.process_data_item(pk.wds.decode_record(r), inv_extr=ds in pk.wds.INV_EXTR_DATASETS, random_n_views=rnd,
