@@ -149,6 +149,8 @@ def random_occlusion(image, center, scale, prob):
     py = random.random() * (bh - h - 1) + ymin
     if px >= 0 and py >= 0 and px + w < W and py + h < H:
         px, py, w, h = int(px), int(py), int(w), int(h)
+        if not image.flags.writeable:          # (decoded records hand out read-only buffers; upstream's arrays are writable)
+            image = image.copy()
         image[py:py + h, px:px + w, :] = np.random.rand(h, w, 3) * 255
     return image
 

@@ -1080,7 +1080,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "tables_cached") h->tables_cached = value != 0;
   else if (k == "knn_fma") h->knn_fma = value != 0;
   else if (k == "graphs") h->graphs = value != 0;
-  else if (k == "chain_tile") { if (value < 0 || value > 2) return POEM_E_ARG; h->chain_tile = value; }
+  else if (k == "chain_tile") { if (value < 0 || value > 3) return POEM_E_ARG; h->chain_tile = value; }
   else return POEM_E_ARG;
   return POEM_OK;
 }

@@ -5,7 +5,7 @@
 struct ChainArgs {
   int kind;                  // 0 = A, 1 = C, 2 = D1, 3 = D2
   int M;                     // rows
-  int tile_p;                // row-tile height: 0 = chosen per launch (chain.hip chain_tile_p), 1 = 32 rows, 2 = 64 rows
+  int tile_p;                // row tiles: 0 = chosen per launch (chain.hip), 1 = 32 rows, 2 = 64 rows, 3 = 16-row units (chain16.hip)
   const float* x; int ldx;   // chain input (M, C)
   // kind A, x == nullptr: the chain input is the cross attention's context, combined here from the attention kernel's
   // split-key partials (attn.hip: part_o fragment images + (m, l) per row) instead of by a separate attn_combine launch

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain_ke
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const float d = pass == 0 ? acc[tp][p][i] : acc[tp][p][i] - mean[p];
-            t += pass == 0 ? d : d * d;
+            t = pass == 0 ? t + d : __builtin_fmaf(d, d, t);       // (explicit: chain16.hip must round the same way)
           }
         s[p] = half_sum(t);
       }
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain_ke
         for (int p = 0; p < P; ++p)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            acc[tp][p][4 * g + e] = (acc[tp][p][4 * g + e] - mean[p]) * rstd[p] * (&gg.x)[e] + (&bb.x)[e];
+            acc[tp][p][4 * g + e] = __builtin_fmaf((acc[tp][p][4 * g + e] - mean[p]) * rstd[p], (&gg.x)[e], (&bb.x)[e]);
       }
     }
   };
@@ -360,8 +360,23 @@ static int chain_tile_p(int M, int cus, int force) {
   return r1 < r2 ? 1 : 2;
 }
 
+extern "C" hipError_t poem_launch_chain16(const ChainArgs* a, int C, hipStream_t s);      // chain16.hip
+
+// Which kernel takes a launch (tile_p = 0; measured per kind and batch, tools/run/gpu_chain_sweep.sh):
+//   * kinds A / C / D1 (two co-resident blocks per CU): from 3 units of 16 rows per CU on, the 16x16x4 kernel with its
+//     16-row granularity and a CU's share split over two co-resident blocks (chain16.hip); below that a tile would be 1-2
+//     units, where every MFMA needs a fresh weight fragment from L2 -- the 32-row tiles of this file spread a small batch
+//     almost as widely and stream half the weight bytes per row;
+//   * kind D2 (two activation tiles: one block per CU at 64 rows): chain16 while a CU's share is one tile of <= 3 units,
+//     the 32- / 64-row kernel with chain_tile_p's height above (its second tile of a CU starts without a new block).
+// Any choice gives the same bits.
 extern "C" hipError_t poem_launch_chain(const ChainArgs* a, int C, hipStream_t s) {
   const int cus = poem_device_cus();
+  if (a->tile_p == 3) return poem_launch_chain16(a, C, s);
+  if (a->tile_p == 0) {
+    const int U = (a->M + 15) / 16, per_cu = (U + std::min(cus, U) - 1) / std::min(cus, U);
+    if (a->kind == 3 ? per_cu <= 3 : per_cu >= 3) return poem_launch_chain16(a, C, s);
+  }
   const int p = chain_tile_p(a->M, cus, a->tile_p);
   switch (C) {
     case 128: return p == 1 ? launch_chain_t<128, 1, 4>(*a, cus, s) : launch_chain_t<128, 2, 4>(*a, cus, s);

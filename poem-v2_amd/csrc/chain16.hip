@@ -1,0 +1,434 @@
+// Row-tile chains on v_mfma_f32_16x16x4_f32: the kinds, arguments and arithmetic of chain.hip (see there for what a chain
+// is) with row tiles of 1..4 units of 16 rows instead of 32 / 64 rows -- so that
+//   * a CU's share of the M = B * 799 rows quantises in 16-row steps: at the headline batch (25568 rows = 1598 units over 256
+//     CUs = 6.24 units per CU) the busiest CU runs 7 units = 112 rows instead of two 64-row tiles = 128;
+//   * a small batch spreads over more CUs (M = 1598 at the reference's evaluation batch of 2: 100 units).
+// Every result element is the SAME fma chain as in chain.hip: the 16x16x4 instruction sums its four k-slots in order, and
+// the slots are given the channels (8kc, 8kc+4, 8kc+1, 8kc+5) then (8kc+2, 8kc+6, 8kc+3, 8kc+7) -- the order in which two
+// 32x32x2 steps of chain.hip's chunk visit them (half-wave 0 holds k, half-wave 1 holds k+4 of the fragment image).  The
+// LayerNorm sums are taken in chain.hip's order too (a running sum that alternates between the half-waves), so a row's result
+// does not depend on which kernel or which tile height processed it: bit-identical, tested.
+//
+// Layout.  X[channel][row] in LDS, row stride 16 MAXRU + 4 = 68 (== 4 mod 8: the two channels a 32-lane group reads in one ds_read_b32 are
+// 4 apart -> 16 banks apart, conflict-free; same for the write-back).  Weight fragments: the 32-row fragment images of
+// common.h; lane (i = lane & 15, g = lane >> 4) of 16-channel tile t loads the float4 of image lane 16 (t & 1) + i + 32 (g & 1)
+// and takes components (x, z) for g < 2, (y, w) for g >= 2.  MFMA result: lane (g, j) holds channels 4g..4g+3 of the tile for
+// row j -- float4 stores / residual loads per lane.
+//
+// Schedule (static).  Workgroups are dispatched breadth-first (tools/lab/census_lab: blocks b and b + 256 share a CU), so
+// block (layer, c) = layer * ncu + c runs on CU c: CU c is given n_c = U / ncu (+1) consecutive units, cut into
+// ceil(n_c / 4) nearly equal tiles, one per block (layer) -- co-resident where the LDS holds two tiles, else one after the other.
+#include "common.h"
+#include <algorithm>
+#include <type_traits>
+
+#include "chain.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// value of the lower / upper half-wave's lanes in both halves (one v_permlane32_swap)
+__device__ __forceinline__ float from_lower(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]);
+}
+__device__ __forceinline__ float from_upper(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[1]);
+}
+
+// D[c'][row] (+)= sum_k W[c'][k0 + k] X[k][row] for this wave's T16 channel tiles and RU row units.  wbase: byte offset of
+// the wave's first 32-row tile at the contraction's start; tile_stride: bytes between consecutive 32-row tiles.
+template <int KCH, int XSP16, int RU, int T16, bool INIT0>
+__device__ __forceinline__ void gemm16(const __amdgpu_buffer_rsrc_t wrs, int wbase, int tile_stride, const float* __restrict__ X,
+                                       f32x4 (&acc)[T16][RU], int lane) {
+  static_assert(KCH % 4 == 0 && T16 % 2 == 0, "shape");
+  const int j = lane & 15, g = lane >> 4;
+  const bool hi = g >= 2;
+  const int loff0 = (j + 32 * (g & 1)) * 16, loff1 = loff0 + 256;
+  const float* xc = X + (4 * (g & 1) + (g >> 1)) * XSP16 + j;
+  if (INIT0) {
+#pragma unroll
+    for (int t = 0; t < T16; ++t)
+#pragma unroll
+      for (int u = 0; u < RU; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float4 a0[T16], a1[T16], a2[T16], a3[T16];
+  float xa[2][RU], xb[2][RU];
+#define C16_LOADW(A, KCI)                                                                                     \
+  {                                                                                                           \
+    const int kq_ = min((KCI), KCH - 1);                                                                      \
+    _Pragma("unroll") for (int t = 0; t < T16; ++t)                                                           \
+        A[t] = frag_load(wrs, (t & 1) ? loff1 : loff0, wbase + (t >> 1) * tile_stride + kq_ * 1024);          \
+  }
+#define C16_READX(XR, KCI)                                                                                    \
+  {                                                                                                           \
+    const int kq_ = min((KCI), KCH - 1);                                                                      \
+    _Pragma("unroll") for (int u = 0; u < RU; ++u) {                                                          \
+      XR[0][u] = xc[(kq_ * 8) * XSP16 + 16 * u];                                                              \
+      XR[1][u] = xc[(kq_ * 8 + 2) * XSP16 + 16 * u];                                                          \
+    }                                                                                                         \
+  }
+#define C16_MMA(A, XR)                                                                                        \
+  {                                                                                                           \
+    float w1_[T16], w2_[T16];                                                                                 \
+    _Pragma("unroll") for (int t = 0; t < T16; ++t) { w1_[t] = hi ? A[t].y : A[t].x; w2_[t] = hi ? A[t].w : A[t].z; } \
+    _Pragma("unroll") for (int u = 0; u < RU; ++u)                                                            \
+      _Pragma("unroll") for (int t = 0; t < T16; ++t) acc[t][u] = mfma16(w1_[t], XR[0][u], acc[t][u]);        \
+    _Pragma("unroll") for (int u = 0; u < RU; ++u)                                                            \
+      _Pragma("unroll") for (int t = 0; t < T16; ++t) acc[t][u] = mfma16(w2_[t], XR[1][u], acc[t][u]);        \
+  }
+  C16_LOADW(a0, 0)
+  C16_READX(xa, 0)
+  C16_LOADW(a1, 1)
+  C16_LOADW(a2, 2)
+#pragma unroll 1
+  for (int kc = 0; kc < KCH; kc += 4) {
+    C16_LOADW(a3, kc + 3) C16_READX(xb, kc + 1) C16_MMA(a0, xa)
+    C16_LOADW(a0, kc + 4) C16_READX(xa, kc + 2) C16_MMA(a1, xb)
+    C16_LOADW(a1, kc + 5) C16_READX(xb, kc + 3) C16_MMA(a2, xa)
+    C16_LOADW(a2, kc + 6) C16_READX(xa, kc + 4) C16_MMA(a3, xb)
+  }
+#undef C16_LOADW
+#undef C16_READX
+#undef C16_MMA
+}
+
+}  // namespace
+
+// MAXRU: largest tile in units (4 = 64 rows; 2 at C = 512, where two activation tiles of kind D2 must fit 160 KB of LDS)
+template <int C, int NW, int KIND, int MAXRU>
+__global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_kernel(ChainArgs A, int ncu, int layers) {
+  constexpr int XSP = 16 * MAXRU + 4, XROWS = 16 * MAXRU, T16 = C / 16 / NW, KCH = C / 8, NT = NW * 64, NTILE = C / 32;
+  static_assert((C / 16) % NW == 0 && T16 % 2 == 0, "waves must divide the 32-channel tiles");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* X0 = smem;                       // C * XSP
+  float* X1 = X0 + C * XSP;               // C * XSP (kind D2 only)
+  float* red = KIND == 3 ? X1 + C * XSP : X0 + C * XSP;   // NW * XROWS partial row sums
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int cw0 = wv * T16 * 16;          // this wave's first channel within a C-wide pass
+  const int tile0 = wv * (T16 / 2);       // ... its first 32-row tile of a packed image
+  const unsigned CC4 = (unsigned)(C * C * 4);
+
+  // ---- this block's tile: CU c's share of the units, cut into `layers` nearly equal tiles (one per block: a tile loop around
+  // the four tile-height variants makes the compiler keep every variant's loop invariants live at once -- 200+ spilled VGPRs)
+  const int U = (A.M + 15) >> 4;
+  const int c = blockIdx.x % ncu, layer = blockIdx.x / ncu;
+  const int ubase = U / ncu, urem = U % ncu;
+  const int cu_lo = c * ubase + min(c, urem), cu_n = ubase + (c < urem ? 1 : 0);
+  const int tb = cu_n / layers, te = cu_n % layers;
+  const int ru = tb + (layer < te ? 1 : 0);
+  if (ru <= 0) return;
+  const int tile_row0 = (cu_lo + layer * tb + min(layer, te)) * 16;
+
+  auto run_tile = [&](auto ru_tag, const int row0) {
+    constexpr int RU = decltype(ru_tag)::value;
+    constexpr int XS = 16 * RU;
+    // channel of acc[t][u][r]: cw0 + 16 t + 4 g + r (+ pass * C); row: row0 + 16 u + j
+    auto add_bias = [&](f32x4 (&acc)[T16][RU], const float* bias, int act) {
+#pragma unroll
+      for (int t = 0; t < T16; ++t) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias + cw0 + 16 * t + 4 * g);
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[t][u][e] + (&bb.x)[e];
+            if (act == 1) v = fmaxf(v, 0.f);
+            if (act == 2) v = gelu_erf(v);
+            acc[t][u][e] = v;
+          }
+      }
+    };
+    auto add_rows = [&](f32x4 (&acc)[T16][RU], const float* R, int ld, int mod) {
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        int row = min(row0 + 16 * u + j, A.M - 1);
+        if (mod > 0) row %= mod;
+        const float* rp = R + (size_t)row * ld + cw0 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < T16; ++t) {
+          const float4 rr = *reinterpret_cast<const float4*>(rp + 16 * t);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][u][e] += (&rr.x)[e];
+        }
+      }
+    };
+    auto to_lds = [&](const f32x4 (&acc)[T16][RU], float* X) {
+#pragma unroll
+      for (int t = 0; t < T16; ++t)
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) X[(cw0 + 16 * t + 4 * g + e) * XSP + 16 * u + j] = acc[t][u][e];
+    };
+    auto to_global = [&](const f32x4 (&acc)[T16][RU], float* Y, int ld, int col0) {
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int row = row0 + 16 * u + j;
+        if (row >= A.M) continue;
+        float* yp = Y + (size_t)row * ld + col0 + cw0 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < T16; ++t)
+          *reinterpret_cast<float4*>(yp + 16 * t) = make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]);
+      }
+    };
+    // LayerNorm over the C channels of every row, in place.  chain.hip sums, per wave and half-wave h, the 16 registers of
+    // each 32-channel tile in order -- channels 4h.., 8+4h.., 16+4h.., 24+4h.. -- then adds the two halves, then the waves
+    // in order.  Here those channel groups sit in lane groups (tile 2m, g = h), (2m, g = 2 + h), (2m+1, h), (2m+1, 2 + h):
+    // the running sum hops between the half-waves (lanes l and l + 32 share row and h) and ends in the upper one.
+    auto layer_norm = [&](f32x4 (&acc)[T16][RU], const float* gamma, const float* beta, float eps) {
+      float mean[RU], rstd[RU];
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        float s[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          float p = 0.f;
+#pragma unroll
+          for (int t = 0; t < T16; ++t) {
+#pragma unroll
+            for (int stage = 0; stage < 2; ++stage) {       // 0: lanes g < 2 hold the running sum, 1: lanes g >= 2
+              if (t > 0 || stage > 0) p = stage == 0 ? from_upper(p) : from_lower(p);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float d = pass == 0 ? acc[t][u][e] : acc[t][u][e] - mean[u];
+                p = pass == 0 ? p + d : __builtin_fmaf(d, d, p);
+              }
+            }
+          }
+          s[u] = p + __shfl_xor(p, 16, 64);                // lanes g = 2, 3: (half-wave 0's sum) + (half-wave 1's)
+        }
+        __syncthreads();                                    // previous readers of `red` are done
+        if (g == 2)
+#pragma unroll
+          for (int u = 0; u < RU; ++u) red[wv * XROWS + 16 * u + j] = s[u];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) t += red[w * XROWS + 16 * u + j];
+          if (pass == 0) mean[u] = t / (float)C;
+          else rstd[u] = 1.0f / sqrtf(t / (float)C + eps);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T16; ++t) {
+        const float4 gg = *reinterpret_cast<const float4*>(gamma + cw0 + 16 * t + 4 * g);
+        const float4 bb = *reinterpret_cast<const float4*>(beta + cw0 + 16 * t + 4 * g);
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][u][e] = __builtin_fmaf((acc[t][u][e] - mean[u]) * rstd[u], (&gg.x)[e], (&bb.x)[e]);
+      }
+    };
+    // trailing wide Linear: n C-wide passes over X, results straight to global
+    auto wide_linear = [&](const float4* W, const float* bias, int n, const float* X, float* Y, int ld) {
+      const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(W, (unsigned)n * CC4);
+      for (int pass = 0; pass < n; ++pass) {
+        f32x4 acc[T16][RU];
+        gemm16<KCH, XSP, RU, T16, true>(wrs, __builtin_amdgcn_readfirstlane((pass * NTILE + tile0) * KCH * 1024), KCH * 1024, X, acc, lane);
+        add_bias(acc, bias + pass * C, 0);
+        to_global(acc, Y, ld, pass * C);
+      }
+    };
+
+    if (KIND == 0 && A.x == nullptr) {
+      // ---- fill X0 with the cross attention's context, combined from the split-key partials (chain.hip; per (row, channel)
+      // the arithmetic of attn_combine_kernel, in its order).  Threads are laid out over XM >= XS rows so that a thread owns
+      // one row and G float4 groups per head.
+      constexpr int DH4 = C / 4, HEADS = 4, XM = XS <= 32 ? (NT / 32 <= DH4 / HEADS ? 32 : 64) : 64;
+      constexpr int RS = NT / XM, G = DH4 / (HEADS * RS), DT = C / HEADS / 32;
+      static_assert(NT % XM == 0 && G >= 1 && DH4 % (HEADS * RS) == 0 && DT >= 1, "shape");
+      const int rr = tid % XM, cgw = tid / XM;
+      if (rr < XS) {
+        const int i = min(row0 + rr, A.M - 1);
+        const int b = i / A.pc_nq, q = i % A.pc_nq, qt = q >> 5, r = q & 31;
+        const int nqt = (A.pc_nq + 31) >> 5, nch = A.pc_chunks;
+        float2 ml[HEADS][4];
+#pragma unroll
+        for (int hd = 0; hd < HEADS; ++hd)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            ml[hd][s] = A.part_ml[(((size_t)(b * HEADS + hd) * nch + min(s, nch - 1)) * nqt + qt) * 32 + r];
+        float w[HEADS][4], rden[HEADS];
+#pragma unroll
+        for (int hd = 0; hd < HEADS; ++hd) {
+          float mx = ml[hd][0].x;
+#pragma unroll
+          for (int s = 1; s < 4; ++s) mx = fmaxf(mx, ml[hd][s].x);
+          float den = 0.f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            w[hd][s] = s < nch ? ((ml[hd][s].x == mx) ? 1.0f : __builtin_amdgcn_exp2f((ml[hd][s].x - mx) * A.pc_kc2)) : 0.f;
+            den = s < nch ? fmaf(w[hd][s], ml[hd][s].y, den) : den;
+          }
+          rden[hd] = den;
+        }
+#pragma unroll
+        for (int hd = 0; hd < HEADS; ++hd) {
+          float4 p[G][4];
+#pragma unroll
+          for (int gi = 0; gi < G; ++gi) {
+            const int cg4 = hd * (DH4 / HEADS) + cgw + RS * gi;
+            const int d = (cg4 >> 3) % DT, gq = (cg4 & 7) >> 1, hh = cg4 & 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              p[gi][s] = A.part_o[((((size_t)(b * HEADS + hd) * nch + min(s, nch - 1)) * nqt + qt) * (DT * 4) + d * 4 + gq) * 64 + r + 32 * hh];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int gi = 0; gi < G; ++gi) {
+            const int cg4 = hd * (DH4 / HEADS) + cgw + RS * gi;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              acc.x = fmaf(w[hd][s], p[gi][s].x, acc.x); acc.y = fmaf(w[hd][s], p[gi][s].y, acc.y);
+              acc.z = fmaf(w[hd][s], p[gi][s].z, acc.z); acc.w = fmaf(w[hd][s], p[gi][s].w, acc.w);
+            }
+            float* xo = X0 + (4 * cg4) * XSP + rr;
+            xo[0] = acc.x / rden[hd]; xo[XSP] = acc.y / rden[hd]; xo[2 * XSP] = acc.z / rden[hd]; xo[3 * XSP] = acc.w / rden[hd];
+          }
+        }
+      }
+    } else {
+      // ---- fill X0 with the input tile, transposed: consecutive threads read consecutive channels of one row
+      static_assert(NT % C == 0 || C % NT == 0, "threads and channels must nest");
+      constexpr int RSTEP = NT >= C ? NT / C : 1, CSTEP = NT >= C ? C : NT;
+      const int c0 = tid % CSTEP, r0 = tid / CSTEP;
+#pragma unroll 4
+      for (int r = r0; r < XS; r += RSTEP) {
+        const float* xr = A.x + (size_t)min(row0 + r, A.M - 1) * A.ldx;
+#pragma unroll
+        for (int cc = c0; cc < C; cc += CSTEP) X0[cc * XSP + r] = xr[cc];
+      }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t f4rs = frag_rsrc(A.wf4, 5u * CC4);
+    if (KIND != 3) {
+      // ---- stage 1: first Linear + bias + residual [+ LayerNorm] -> y1 and back into X0
+      f32x4 acc[T16][RU];
+      gemm16<KCH, XSP, RU, T16, true>(frag_rsrc(A.w1, CC4), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, acc, lane);
+      add_bias(acc, A.b1, 0);
+      add_rows(acc, A.res, A.ldres, A.res_mod);
+      if (KIND == 0) layer_norm(acc, A.ln_g, A.ln_b, A.eps);
+      to_global(acc, A.y1, A.ldy1, 0);
+      __syncthreads();                          // every wave is done reading the input tile
+      to_lds(acc, X0);
+      __syncthreads();
+      if (KIND != 2) {
+        if (A.n2 > 0) wide_linear(A.w2, A.b2, A.n2, X0, A.y2, A.ldy2);
+        return;
+      }
+      // ---- kind D1.  reg_branch: u = relu(f Wreg0^T + b), xyz' = xyz + u Wreg2^T + b
+      {
+        f32x4 uu[T16][RU];
+        gemm16<KCH, XSP, RU, T16, true>(f4rs, __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, uu, lane);
+        add_bias(uu, A.bf4, 1);
+        __syncthreads();                        // every wave is done reading f
+        to_lds(uu, X0);
+      }
+      __syncthreads();
+      // one wave per row, lanes stride the channels: the fma chain and the reduction order of narrow_linear_kernel
+      for (int r = wv; r < XS; r += NW) {
+        const int row = row0 + r;
+        float s3[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          float s = 0.f;
+          for (int cc = lane; cc < C; cc += 64) s = fmaf(X0[cc * XSP + r], A.wreg2[n * C + cc], s);
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+          s3[n] = s;
+        }
+        if (lane < 3 && row < A.M) {
+          const float s = lane == 0 ? s3[0] : (lane == 1 ? s3[1] : s3[2]);
+          A.xyz_out[(size_t)row * 3 + lane] = A.xyz_in[(size_t)row * 3 + lane] + (s + A.breg2[lane]);
+        }
+      }
+      return;
+    }
+    // ---- kind D2 (X0 = f): o = sum_s gelu(f Wint_s^T + b_s) Wout[:, sC:(s+1)C]^T, slab by slab in k order
+    f32x4 o[T16][RU];
+    const __amdgpu_buffer_rsrc_t wors = frag_rsrc(A.wout, 4u * CC4);
+#pragma unroll 1
+    for (int sl = 0; sl < 4; ++sl) {
+      f32x4 t[T16][RU];
+      gemm16<KCH, XSP, RU, T16, true>(f4rs, __builtin_amdgcn_readfirstlane(((1 + sl) * NTILE + tile0) * KCH * 1024), KCH * 1024, X0, t, lane);
+      add_bias(t, A.bf4 + (1 + sl) * C, 2);
+      __syncthreads();                        // readers of X1 (the previous slab's contraction)
+      to_lds(t, X1);
+      __syncthreads();
+      const int wb = __builtin_amdgcn_readfirstlane(tile0 * 4 * KCH * 1024 + sl * KCH * 1024);
+      if (sl == 0) gemm16<KCH, XSP, RU, T16, true>(wors, wb, 4 * KCH * 1024, X1, o, lane);
+      else gemm16<KCH, XSP, RU, T16, false>(wors, wb, 4 * KCH * 1024, X1, o, lane);
+    }
+    add_bias(o, A.bout, 0);
+#pragma unroll
+    for (int t = 0; t < T16; ++t)
+#pragma unroll
+      for (int u = 0; u < RU; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[t][u][e] += X0[(cw0 + 16 * t + 4 * g + e) * XSP + 16 * u + j];
+    layer_norm(o, A.ln2_g, A.ln2_b, A.eps);
+    to_global(o, A.y3, A.ldy3, 0);
+    if (A.n2 > 0) {
+      __syncthreads();                        // every wave has read its residual from X0
+      to_lds(o, X0);
+      __syncthreads();
+      wide_linear(A.w2, A.b2, A.n2, X0, A.y2, A.ldy2);
+    }
+  };
+
+  if constexpr (MAXRU == 4) {
+    switch (ru) {
+      case 1: run_tile(std::integral_constant<int, 1>{}, tile_row0); break;
+      case 2: run_tile(std::integral_constant<int, 2>{}, tile_row0); break;
+      case 3: run_tile(std::integral_constant<int, 3>{}, tile_row0); break;
+      default: run_tile(std::integral_constant<int, 4>{}, tile_row0); break;
+    }
+  } else {
+    if (ru == 1) run_tile(std::integral_constant<int, 1>{}, tile_row0);
+    else run_tile(std::integral_constant<int, 2>{}, tile_row0);
+  }
+}
+
+template <int C, int NW, int KIND, int MAXRU>
+static hipError_t launch_chain16_k(const ChainArgs& a, int cus, hipStream_t s) {
+  const size_t lds = ((size_t)(KIND == 3 ? 2 : 1) * C * (16 * MAXRU + 4) + (size_t)NW * 16 * MAXRU) * sizeof(float);
+  auto kern = chain16_kernel<C, NW, KIND, MAXRU>;
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin); e != hipSuccess) return e;
+  const int U = (a.M + 15) / 16;
+  const int ncu = std::min(cus, U);
+  const int per_cu = (U + ncu - 1) / ncu;                         // units of the busiest CU
+  // tiles per CU: two co-resident ones from 3 units on where the LDS holds two (one block's fill / LayerNorm / stores then
+  // overlap the other's MFMAs: B = 16, 4 units per CU, 127 us as one tile vs 116 us as two), else as few as fit
+  const bool pair = 2 * lds <= 160 * 1024 && per_cu >= 3;
+  const int layers = std::max(pair ? 2 : 1, (per_cu + MAXRU - 1) / MAXRU);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(ncu * layers)), dim3(NW * 64), lds, s, a, ncu, layers);
+  return hipGetLastError();
+}
+
+template <int C, int NW, int MAXRU>
+static hipError_t launch_chain16_t(const ChainArgs& a, int cus, hipStream_t s) {
+  switch (a.kind) {
+    case 0: return launch_chain16_k<C, NW, 0, MAXRU>(a, cus, s);
+    case 1: return launch_chain16_k<C, NW, 1, MAXRU>(a, cus, s);
+    case 2: return launch_chain16_k<C, NW, 2, MAXRU>(a, cus, s);
+    case 3: return launch_chain16_k<C, NW, 3, MAXRU>(a, cus, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+extern "C" hipError_t poem_launch_chain16(const ChainArgs* a, int C, hipStream_t s) {
+  const int cus = poem_device_cus();
+  switch (C) {
+    case 128: return launch_chain16_t<128, 4, 4>(*a, cus, s);
+    case 256: return launch_chain16_t<256, 8, 4>(*a, cus, s);
+    case 512: return launch_chain16_t<512, 8, 2>(*a, cus, s);
+    default: return hipErrorInvalidValue;
+  }
+}

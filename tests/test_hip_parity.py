@@ -469,6 +469,35 @@ def test_anchor_tables_vs_per_sample_form(name):
 
 
 @pytest.mark.parametrize("name", ["small", "medium", "large", "ragged", "mediummano", "medium_hot"])
+def test_chain_kernels_on_both_matrix_shapes_are_bit_identical(name):
+    """csrc/chain16.hip (v_mfma_f32_16x16x4_f32, row tiles of 1..4 units of 16 rows) against csrc/chain.hip (32x32x2, 32- / 64-row
+    tiles): every output element is the same k-ordered fma chain and LayerNorm sums in the same order, so every stage tap and
+    the output agree BIT FOR BIT -- which is what lets the tile height follow the batch size."""
+    z, meta = load_golden(name)
+    spec = meta["spec"]
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(case_setup(spec)[3], DEV)
+    eng = head._engine_for(torch.device(DEV))
+    eng.enable_taps(True)
+    B, C, Q = len(spec["views"]), spec["embed"], 799
+    got = {}
+    for tile in (2, 3, 1):
+        eng.set_option("chain_tile", tile)
+        with torch.no_grad():
+            res = head(feat, metas, rj)
+        got[tile] = {"out": res["all_coords_preds"].cpu()}
+        got[tile].update({f"b{i}.{k}": eng.tap(f"b{i}.{k}", (B, Q, 3 if k == "xyz" else C)).cpu()
+                          for i in range(3) for k in ("h_cross", "f_self", "f_cross", "feats", "xyz")})
+        if spec["parametric"]:
+            got[tile]["pose"] = res["pred_pose"].cpu()
+    eng.set_option("chain_tile", 0)
+    eng.enable_taps(False)
+    for k in got[2]:
+        assert torch.equal(got[2][k], got[3][k]), (k, float((got[2][k] - got[3][k]).abs().max()))
+        assert torch.equal(got[2][k], got[1][k]), k
+
+
+@pytest.mark.parametrize("name", ["small", "medium", "large", "ragged", "mediummano", "medium_hot"])
 def test_row_tile_chains_vs_operator_launches(name):
     """csrc/chain.hip (default): the query-side Linears / residual adds / LayerNorms of a block as four LDS-resident chain
     launches; set_chains(False) = one launch per operator.  Same arithmetic per element except the summation order inside
@@ -807,7 +836,7 @@ def test_full_size_batch_properties():
     # (the round-2 behaviour) instead of read from the handle, where poem_create folded them
     eng = head._engine
     # ... and the hipGraph replay of the launch list against plain launches (first call of a layout captures, later calls replay)
-    for name, val in (("chain_tile", 1), ("chain_tile", 2), ("chain_tile", 0), ("tables_cached", 0), ("tables_cached", 1),
+    for name, val in (("chain_tile", 1), ("chain_tile", 2), ("chain_tile", 3), ("chain_tile", 0), ("tables_cached", 0), ("tables_cached", 1),
                       ("graphs", 0), ("graphs", 1), ("graphs", 1)):
         eng.set_option(name, val)
         with torch.no_grad():

@@ -7,9 +7,12 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 nth = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a forward starts with the anchor-table fork (canon_xyz_kernel) or, without it, with conv1x1_kernel
-first = "canon_xyz_kernel" if any(r["Kernel_Name"].startswith("canon_xyz_kernel") for r in rows) else "void conv1x1_kernel"
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(first)]
+# a forward starts with input_proj (conv1x1_lds_kernel; conv1x1_kernel for shapes it does not take) -- or, when the block-0
+# anchor tables are rebuilt per forward (poem_set_option tables_cached=0), with the table fork (canon_xyz_kernel)
+names = [r["Kernel_Name"].replace("void ", "") for r in rows]
+n_canon = sum(n.startswith("canon_xyz_kernel") for n in names)
+first = "canon_xyz_kernel" if n_canon > 4 else ("conv1x1_lds_kernel" if any(n.startswith("conv1x1_lds_kernel") for n in names) else "conv1x1_kernel")
+starts = [i for i, n in enumerate(names) if n.startswith(first)]
 step = rows[starts[nth]:starts[nth + 1]]
 last = max(j for j, r in enumerate(step) if r["Kernel_Name"].startswith("finalize_kernel"))
 step = step[:last + 1]
