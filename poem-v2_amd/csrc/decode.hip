@@ -21,6 +21,7 @@
 // A wave owns CT channel tiles x PT pixel tiles; waves are independent (no LDS, no barriers).
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Cout, int Cin, float4* __restrict__ out, int total) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,18 +40,47 @@ __global__ void pack_conv3x3_kernel(const float* __restrict__ w, int Cout, int C
   out[i] = v;
 }
 
-extern "C" size_t poem_conv3x3_packed_floats(int Cout, int Cin) { return (size_t)((Cout + 31) / 32) * 9 * (Cin / 8) * 64 * 4; }
+// The same weights for v_mfma_f32_16x16x4_f32 (16 output channels per tile: Cout = 40 pads to 48 instead of 64, Cout = 80
+// not at all instead of to 96): P16[((cot * 9 + tap) * Cin/8 + cc) * 64 + lane] = float2( W[16cot + (lane&15)][8cc + (lane>>4)][tap],
+// W[16cot + (lane&15)][8cc + 4 + (lane>>4)][tap] ) -- one 512-byte wave load = the A operands of a chunk's two k-steps.
+__global__ void pack_conv3x3_m16_kernel(const float* __restrict__ w, int Cout, int Cin, float2* __restrict__ out, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = i & 63;
+  int f = i >> 6;
+  const int cc = f % (Cin / 8);
+  f /= (Cin / 8);
+  const int tap = f % 9, cot = f / 9;
+  const int co = cot * 16 + (lane & 15), ci = 8 * cc + (lane >> 4);
+  float2 v = make_float2(0.f, 0.f);
+  if (co < Cout) {
+    const float* p = w + ((size_t)co * Cin + ci) * 9 + tap;
+    v = make_float2(p[0], p[36]);
+  }
+  out[i] = v;
+}
+
+// packed image = [32-row fragment image | 16-row fragment image]: which one a launch reads depends on the kernel that takes
+// its shape (conv3x3_m16: the 16-row one when it pads fewer output channels)
+static size_t conv3x3_floats32(int Cout, int Cin) { return (size_t)((Cout + 31) / 32) * 9 * (Cin / 8) * 64 * 4; }
+static size_t conv3x3_floats16(int Cout, int Cin) { return (size_t)((Cout + 15) / 16) * 9 * (Cin / 8) * 64 * 2; }
+extern "C" size_t poem_conv3x3_packed_floats(int Cout, int Cin) { return conv3x3_floats32(Cout, Cin) + conv3x3_floats16(Cout, Cin); }
+static bool conv3x3_m16(int Cout) { return (Cout + 15) / 16 * 16 < (Cout + 31) / 32 * 32 && (Cout + 15) / 16 <= 5; }
 
 extern "C" hipError_t poem_launch_pack_conv3x3(const float* w, int Cout, int Cin, void* out, hipStream_t s) {
   if (Cin % 8) return hipErrorInvalidValue;
   const int total = ((Cout + 31) / 32) * 9 * (Cin / 8) * 64;
   hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, Cout, Cin, (float4*)out, total);
+  const int total16 = ((Cout + 15) / 16) * 9 * (Cin / 8) * 64;
+  hipLaunchKernelGGL(pack_conv3x3_m16_kernel, dim3((total16 + 255) / 256), dim3(256), 0, s, w, Cout, Cin,
+                     (float2*)((float*)out + conv3x3_floats32(Cout, Cin)), total16);
   return hipGetLastError();
 }
 
 struct Conv3Args {
   const float* in;      // (views, Cin, H+2, W+2) zero-bordered
-  const float4* wp;     // packed weights
+  const float4* wp;     // packed weights (32-row fragment image)
+  const float2* wp16;   // ... the 16-row image behind it (pack_conv3x3_m16_kernel)
   const float* scale;   // (cot*32) per-channel multiplier   (BatchNorm folded; 1 without norm)
   const float* shift;   // (cot*32) per-channel offset       (conv bias + BatchNorm folded)
   const float* res;     // optional lateral input (views, Cout, Ho, Wo), added after the activation
@@ -155,6 +185,93 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args A) {
   }
 }
 
+// Staging of one 8-channel chunk of a convolution's input tile -- (TR + 2) x (W + 2) per channel, zero border included --
+// into LDS, shared by the LDS-staged kernels below.  Per staged float everything that does not depend on the chunk is
+// worked out once (init): its LDS slot, and for the plain input its byte offset; for the fused [bilinear x2 of up_a | skip_b]
+// input the four tap offsets and the four tap weights of F.interpolate(scale_factor=2, align_corners=False) -- the weights
+// of an out-of-image position are zero, so the border costs no select -- or the skip tensor's offset.  The chunk's part of
+// every address is a scalar offset of a per-view buffer descriptor: `load` is loads only (no VALU), `finish` one multiply and
+// three fmas per interpolated float.  (Round 2 unpacked bit fields and formed 64-bit addresses per float and chunk: a fifth of
+// the fused kernels' time went into staging arithmetic that the fp32 MFMAs do not overlap with.)
+template <bool UPCAT>
+struct Conv3Stager {
+  static constexpr int MAXLD = 7;          // staged floats per thread and chunk: 8 * 396 / 512
+  float st[MAXLD], r1[MAXLD], r2[MAXLD], r3[MAXLD];
+  float q0[MAXLD], q1[MAXLD], q2[MAXLD], q3[MAXLD];       // bilinear tap weights
+  int o0[MAXLD], o1[MAXLD], o2[MAXLD], o3[MAXLD], ob[MAXLD], sdst[MAXLD];
+  __amdgpu_buffer_rsrc_t rs_a, rs_b;
+  int Ca, up_plane4, sk_plane4, in_plane4, count, so;
+
+  __device__ __forceinline__ void init(const Conv3Args& A, int n, int y0, int tid, int tplane, int tstride) {
+    const int W = A.W, Wp = A.W + 2, h2 = A.H / 2, w2 = A.W / 2;
+    count = 8 * tplane;
+    Ca = A.Ca;
+    up_plane4 = h2 * w2 * 4; sk_plane4 = A.H * W * 4; in_plane4 = (A.H + 2) * Wp * 4;
+    if (UPCAT) {
+      rs_a = frag_rsrc(A.up_a + (size_t)n * A.Ca * (h2 * w2), (unsigned)((size_t)A.Ca * up_plane4));
+      rs_b = frag_rsrc(A.skip_b + (size_t)n * A.Cb * (A.H * W), (unsigned)((size_t)A.Cb * sk_plane4));
+    } else {
+      rs_a = frag_rsrc(A.in + (size_t)n * A.Cin * ((A.H + 2) * Wp) + (size_t)y0 * Wp, (unsigned)((size_t)A.Cin * in_plane4));
+      rs_b = rs_a;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXLD; ++u) {
+      const int i = min(tid + 512 * u, count - 1);
+      const int chl = i / tplane, o = i % tplane;
+      sdst[u] = chl * tstride + o;
+      if (!UPCAT) {
+        o0[u] = (chl * (A.H + 2) * Wp + o) * 4;
+        continue;
+      }
+      const int y = y0 + o / Wp - 1, x = o % Wp - 1;
+      const bool valid = y >= 0 && y < A.H && x >= 0 && x < W;
+      const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+      const int yy0 = (int)sy, xx0 = (int)sx;
+      const int yy1 = min(yy0 + 1, h2 - 1), xx1 = min(xx0 + 1, w2 - 1);
+      const float ly = sy - (float)yy0, lx = sx - (float)xx0, hy = 1.f - ly, hx = 1.f - lx;
+      q0[u] = valid ? hy * hx : 0.f; q1[u] = valid ? hy * lx : 0.f; q2[u] = valid ? ly * hx : 0.f; q3[u] = valid ? ly * lx : 0.f;
+      const int base = valid ? chl * up_plane4 : 0;
+      o0[u] = valid ? base + (yy0 * w2 + xx0) * 4 : 0; o1[u] = valid ? base + (yy0 * w2 + xx1) * 4 : 0;
+      o2[u] = valid ? base + (yy1 * w2 + xx0) * 4 : 0; o3[u] = valid ? base + (yy1 * w2 + xx1) * 4 : 0;
+      ob[u] = valid ? chl * sk_plane4 + (y * W + x) * 4 : -1;
+    }
+  }
+  __device__ __forceinline__ static float ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+  }
+  // The same per staged float, with the chunk's kind a compile-time constant (KIND 1: plain input or skip tensor, 2:
+  // interpolated part) for the kernels with a pinned tap pipeline.  They spread a chunk's requests over its taps: vmcnt
+  // retires in order, so a weight fragment requested BEHIND a burst of 28 staging gathers is not usable before all of them
+  // are back -- one float's loads per tap keeps the wait in front of every tap at "all but the youngest four"; and a run-time
+  // branch on the kind inside that pipeline made the compiler merge the two paths through scratch memory.
+  template <int KIND>
+  __device__ __forceinline__ void begin_k(int cc) {
+    so = __builtin_amdgcn_readfirstlane(!UPCAT ? 8 * cc * in_plane4 : (KIND == 2 ? 8 * cc * up_plane4 : (8 * cc - Ca) * sk_plane4));
+  }
+  template <int KIND, int u>
+  __device__ __forceinline__ void load_k() {
+    if (!UPCAT) st[u] = ld(rs_a, o0[u], so);
+    else if (KIND == 2) { st[u] = ld(rs_a, o0[u], so); r1[u] = ld(rs_a, o1[u], so); r2[u] = ld(rs_a, o2[u], so); r3[u] = ld(rs_a, o3[u], so); }
+    else st[u] = ld(rs_b, max(ob[u], 0), so);
+  }
+  template <int KIND>
+  __device__ __forceinline__ void load_all() {
+    load_k<KIND, 0>(); load_k<KIND, 1>(); load_k<KIND, 2>(); load_k<KIND, 3>(); load_k<KIND, 4>(); load_k<KIND, 5>(); load_k<KIND, 6>();
+  }
+  template <int KIND>
+  __device__ __forceinline__ void finish_k() {
+    if (!UPCAT) return;
+#pragma unroll
+    for (int u = 0; u < MAXLD; ++u)
+      st[u] = KIND == 2 ? fmaf(q3[u], r3[u], fmaf(q2[u], r2[u], fmaf(q1[u], r1[u], q0[u] * st[u]))) : (ob[u] >= 0 ? st[u] : 0.f);
+  }
+  __device__ __forceinline__ void store(float* buf, int tid) const {
+#pragma unroll
+    for (int u = 0; u < MAXLD; ++u)
+      if (tid + 512 * u < count) buf[sdst[u]] = st[u];
+  }
+};
+
 // Stride-1 variant with the input staged in LDS (the three uv_decode convolutions: 9 x Cin x Cout x H x W = 177 M
 // multiply-adds per view each).  The direct kernel above re-reads its input for every tap and every channel-tile group
 // through caches that do not hold it (PMC: 5.2 GB fetched for the 0.5 GB input of the 120 -> 40 layer).  Here a block of 8
@@ -168,81 +285,35 @@ template <int CT, bool UPCAT>
 __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
   extern __shared__ __attribute__((aligned(16))) float tile[];      // 2 x 8 x trows x Wp
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
-  const int W = A.W, Wp = A.W + 2, Hp = A.H + 2, plane = Hp * Wp, KC = A.Cin / 8;
+  const int W = A.W, Wp = A.W + 2, KC = A.Cin / 8;
   const int TR = 256 / W, rblocks = A.H / TR;
   const int rb = (int)(blockIdx.x % rblocks), n = (int)(blockIdx.x / rblocks);
   const int y0 = rb * TR, tplane = (TR + 2) * Wp, chunk_floats = 8 * tplane;
   const int pix = wv * 32 + j, py = pix / W, px = pix % W;
-  const float* src = UPCAT ? nullptr : A.in + (size_t)n * A.Cin * plane + (size_t)y0 * Wp;
   const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(A.wp, 0xffffffffu);
-  constexpr int MAXLD = 7;                 // staged floats per thread and chunk: 8 * 396 / 512
-  float st[MAXLD];
-  // per staged float of a chunk (the same for every chunk): plain input -> source offset; fused input -> the bilinear
-  // taps of F.interpolate(scale_factor=2, align_corners=False) (upcat_pad_kernel's arithmetic) and the skip tensor's offset
-  int soff[MAXLD], sob[MAXLD];
-  float sly[MAXLD], slx[MAXLD];
-  const int h2 = A.H / 2, w2 = A.W / 2;
-#pragma unroll
-  for (int u = 0; u < MAXLD; ++u) {
-    const int i = min(tid + 512 * u, chunk_floats - 1);
-    const int chl = i / tplane, o = i % tplane;
-    if (!UPCAT) {
-      soff[u] = chl * plane + o;
-      sob[u] = 0; sly[u] = 0.f; slx[u] = 0.f;
-    } else {
-      const int y = y0 + o / Wp - 1, x = o % Wp - 1;
-      const bool valid = y >= 0 && y < A.H && x >= 0 && x < W;
-      const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
-      const int yy0 = (int)sy, xx0 = (int)sx;
-      const int yy1 = min(yy0 + 1, h2 - 1), xx1 = min(xx0 + 1, w2 - 1);
-      sly[u] = sy - (float)yy0;
-      slx[u] = sx - (float)xx0;
-      soff[u] = valid ? ((yy0 * w2 + xx0) | (chl << 20) | ((xx1 - xx0) << 23) | ((yy1 - yy0) << 24) | (1 << 25)) : (chl << 20);
-      sob[u] = valid ? y * W + x : 0;
-    }
-  }
-  auto stage_load = [&](int cc) {
-    if (!UPCAT) {
-      const float* sc = src + (size_t)(8 * cc) * plane;
-#pragma unroll
-      for (int u = 0; u < MAXLD; ++u) st[u] = sc[soff[u]];
-    } else if (8 * cc < A.Ca) {
-      const float* pa = A.up_a + ((size_t)n * A.Ca + 8 * cc) * (h2 * w2);
-#pragma unroll
-      for (int u = 0; u < MAXLD; ++u) {
-        const int pk = soff[u];
-        const float* p = pa + ((pk >> 20) & 7) * (h2 * w2) + (pk & 0xfffff);
-        const int dx = (pk >> 23) & 1, dyw = ((pk >> 24) & 1) * w2;
-        const float ly = sly[u], lx = slx[u], hy = 1.f - ly, hx = 1.f - lx;
-        const float v = hy * (hx * p[0] + lx * p[dx]) + ly * (hx * p[dyw] + lx * p[dyw + dx]);      // upcat_pad_kernel's expression
-        st[u] = (pk >> 25) & 1 ? v : 0.f;
-      }
-    } else {
-      const float* pb = A.skip_b + ((size_t)n * A.Cb + (8 * cc - A.Ca)) * (A.H * W);
-#pragma unroll
-      for (int u = 0; u < MAXLD; ++u) {
-        const int pk = soff[u];
-        const float v = pb[((pk >> 20) & 7) * (A.H * W) + sob[u]];
-        st[u] = (pk >> 25) & 1 ? v : 0.f;
-      }
-    }
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < MAXLD; ++u) {
-      const int i = tid + 512 * u;
-      if (i < chunk_floats) tile[buf * chunk_floats + i] = st[u];
-    }
-  };
+  Conv3Stager<UPCAT> sg;
+  sg.init(A, n, y0, tid, tplane, tplane);
   f32x16 acc[CT];
 #pragma unroll
   for (int c = 0; c < CT; ++c) acc[c] = zero16();
-  stage_load(0);
-  stage_store(0);
+  // chunk 0 (each kind stages and stores inside its own branch: no register merges behind it)
+  if (UPCAT && A.Ca > 0) {
+    sg.template begin_k<2>(0);
+    sg.template load_all<2>();
+    sg.template finish_k<2>();
+    sg.store(tile, tid);
+  } else {
+    sg.template begin_k<1>(0);
+    sg.template load_all<1>();
+    sg.template finish_k<1>();
+    sg.store(tile, tid);
+  }
   __syncthreads();
   const int boff = (4 * h) * tplane + py * Wp + px;
-  for (int cc = 0; cc < KC; ++cc) {
-    if (cc + 1 < KC) stage_load(cc + 1);
+  // one chunk; NEXT = kind of the chunk staged meanwhile (0: none, 1: plain input / skip tensor, 2: interpolated part)
+  auto chunk = [&](auto next_tag, const int cc) {
+    constexpr int NEXT = decltype(next_tag)::value;
+    if constexpr (NEXT != 0) { sg.template begin_k<NEXT>(cc + 1); sg.template load_all<NEXT>(); }
     const float* tb = tile + (cc & 1) * chunk_floats + boff;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -257,8 +328,15 @@ __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
         for (int c = 0; c < CT; ++c) acc[c] = mfma32((&a[c].x)[t], b, acc[c]);
       }
     }
-    if (cc + 1 < KC) stage_store((cc + 1) & 1);
+    if constexpr (NEXT != 0) { sg.template finish_k<NEXT>(); sg.store(tile + ((cc + 1) & 1) * chunk_floats, tid); }
     __syncthreads();
+  };
+  {
+    const int n_up = UPCAT ? A.Ca / 8 : 0;         // chunks [0, n_up) are interpolated, [n_up, KC) plain / skip tensor
+    int cc = 0;
+    for (; cc + 1 < n_up; ++cc) chunk(std::integral_constant<int, 2>{}, cc);
+    for (; cc + 1 < KC; ++cc) chunk(std::integral_constant<int, 1>{}, cc);
+    chunk(std::integral_constant<int, 0>{}, cc);
   }
   // epilogue: affine (conv bias + BatchNorm), ReLU, lateral add; lane = pixel, register e = channel 8(e>>2) + 4h + (e&3)
   const int Ho = A.H, Wo = A.W, oy = y0 + py;
@@ -282,6 +360,130 @@ __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
   }
 }
 
+// The LDS-staged kernel above on v_mfma_f32_16x16x4_f32, for output widths that are not multiples of 32: Cout = 40 (the last
+// uv_decode convolution, 40 % of the stage's FLOPs) multiplied 37 % zeros as two 32-channel tiles, Cout = 80 17 % as three.
+// A wave still owns 32 raster-consecutive pixels -- two units of 16 -- and all CT16 channel tiles; lane (j = lane & 15,
+// g = lane >> 4) feeds pixel j of a unit with channel 8cc + g (then 8cc + 4 + g) of the chunk.  The staged planes are padded
+// to a stride == 16 mod 32 floats so that the two channel planes a 32-lane group reads fall on disjoint banks.
+// Result layout: lane (g, j) holds output channels 16c + 4g .. + 3 of pixel j.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+template <int CT16, bool UPCAT>
+__global__ __launch_bounds__(512) void conv3x3_lds16_kernel(Conv3Args A) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];      // 2 x 8 x tstride
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int W = A.W, Wp = A.W + 2, KC = A.Cin / 8;
+  const int TR = 256 / W, rblocks = A.H / TR;
+  const int rb = (int)(blockIdx.x % rblocks), n = (int)(blockIdx.x / rblocks);
+  const int y0 = rb * TR, tplane = (TR + 2) * Wp, tstride = ((tplane + 15) & ~31) + 16;
+  const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(A.wp16, 0xffffffffu);
+  Conv3Stager<UPCAT> sg;
+  sg.init(A, n, y0, tid, tplane, tstride);
+  f32x4 acc[CT16][2];
+#pragma unroll
+  for (int c = 0; c < CT16; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[c][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // chunk 0 (each kind stages and stores inside its own branch: no register merges behind it)
+  if (UPCAT && A.Ca > 0) {
+    sg.template begin_k<2>(0);
+    sg.template load_all<2>();
+    sg.template finish_k<2>();
+    sg.store(tile, tid);
+  } else {
+    sg.template begin_k<1>(0);
+    sg.template load_all<1>();
+    sg.template finish_k<1>();
+    sg.store(tile, tid);
+  }
+  __syncthreads();
+  int boff[2], opy[2], opx[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int pix = wv * 32 + 16 * u + j;
+    opy[u] = pix / W;
+    opx[u] = pix % W;
+    boff[u] = g * tstride + opy[u] * Wp + opx[u];
+  }
+  // Per chunk the nine taps run as a two-stage software pipeline with a pinned order (left alone the compiler issued each
+  // tap's LDS reads right in front of the MFMAs that need them and waited: 62 % of the pipe; pinned: see DESIGN): the weight
+  // fragments and the four B operands of tap t + 1 are requested before tap t's 4 * CT16 MFMAs issue.
+  f32x2v wa[CT16], wb[CT16];
+  float ba[4], bb[4];
+#define POEM_T16_LOADW(A, TAP, CC)                                                                              \
+  _Pragma("unroll") for (int c = 0; c < CT16; ++c)                                                              \
+    A[c] = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, ((c * 9 + (TAP)) * KC + (CC)) * 512, 0));
+#define POEM_T16_LOADB(B, TAP)                                                                                  \
+  {                                                                                                             \
+    const int toff_ = ((TAP) / 3) * Wp + ((TAP) % 3);                                                           \
+    B[0] = tb[boff[0] + toff_]; B[1] = tb[boff[1] + toff_];                                                     \
+    B[2] = tb[boff[0] + 4 * tstride + toff_]; B[3] = tb[boff[1] + 4 * tstride + toff_];                         \
+  }
+#define POEM_T16_MMA(A, B)                                                                                      \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                 \
+    _Pragma("unroll") for (int c = 0; c < CT16; ++c) acc[c][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][0], B[u], acc[c][u], 0, 0, 0); \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                 \
+    _Pragma("unroll") for (int c = 0; c < CT16; ++c) acc[c][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[c][1], B[2 + u], acc[c][u], 0, 0, 0);
+#define POEM_T16_STEP(CUR_A, CUR_B, NXT_A, NXT_B, TAP)                                                          \
+  POEM_T16_LOADW(NXT_A, (TAP) + 1, cc) POEM_T16_LOADB(NXT_B, (TAP) + 1)                                         \
+  if constexpr (NEXT != 0 && (TAP) < SG::MAXLD) sg.template load_k<NEXT, ((TAP) < SG::MAXLD ? (TAP) : 0)>();    \
+  __builtin_amdgcn_sched_barrier(0);                                                                            \
+  POEM_T16_MMA(CUR_A, CUR_B)                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+  using SG = Conv3Stager<UPCAT>;
+  // one chunk; NEXT = kind of the chunk staged meanwhile (0: none, 1: plain input / skip tensor, 2: interpolated part)
+  auto chunk = [&](auto next_tag, const int cc) {
+    constexpr int NEXT = decltype(next_tag)::value;
+    if constexpr (NEXT != 0) sg.template begin_k<NEXT>(cc + 1);
+    const float* tb = tile + (cc & 1) * 8 * tstride;
+    POEM_T16_LOADB(ba, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_T16_STEP(wa, ba, wb, bb, 0) POEM_T16_STEP(wb, bb, wa, ba, 1) POEM_T16_STEP(wa, ba, wb, bb, 2) POEM_T16_STEP(wb, bb, wa, ba, 3)
+    POEM_T16_STEP(wa, ba, wb, bb, 4) POEM_T16_STEP(wb, bb, wa, ba, 5) POEM_T16_STEP(wa, ba, wb, bb, 6) POEM_T16_STEP(wb, bb, wa, ba, 7)
+    // last tap: the next chunk's first weight fragments ride behind it (its B operands wait for the barrier)
+    { const int ccn = min(cc + 1, KC - 1); POEM_T16_LOADW(wb, 0, ccn) }
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_T16_MMA(wa, ba)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < CT16; ++c) wa[c] = wb[c];
+    if constexpr (NEXT != 0) { sg.template finish_k<NEXT>(); sg.store(tile + ((cc + 1) & 1) * 8 * tstride, tid); }
+    __syncthreads();
+  };
+  POEM_T16_LOADW(wa, 0, 0)
+  {
+    const int n_up = UPCAT ? A.Ca / 8 : 0;         // chunks [0, n_up) are interpolated, [n_up, KC) plain / skip tensor
+    int cc = 0;
+    for (; cc + 1 < n_up; ++cc) chunk(std::integral_constant<int, 2>{}, cc);
+    for (; cc + 1 < KC; ++cc) chunk(std::integral_constant<int, 1>{}, cc);
+    chunk(std::integral_constant<int, 0>{}, cc);
+  }
+#undef POEM_T16_LOADW
+#undef POEM_T16_LOADB
+#undef POEM_T16_MMA
+#undef POEM_T16_STEP
+  // epilogue: lane (g, j) holds channels 16c + 4g + e of pixel (unit u, j)
+  const int Ho = A.H, Wo = A.W;
+#pragma unroll
+  for (int c = 0; c < CT16; ++c) {
+    const int cbase = c * 16 + 4 * g;
+    const float4 sc = *reinterpret_cast<const float4*>(A.scale + cbase);
+    const float4 sh = *reinterpret_cast<const float4*>(A.shift + cbase);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = cbase + e;
+      if (co >= A.Cout) continue;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int oy = y0 + opy[u];
+        float v = fmaf(acc[c][u][e], (&sc.x)[e], (&sh.x)[e]);
+        if (A.relu) v = fmaxf(v, 0.f);
+        if (A.res) v += A.res[((size_t)n * A.Cout + co) * (Ho * Wo) + oy * Wo + opx[u]];
+        A.out[(size_t)n * A.out_ns + (size_t)co * A.out_cs + oy * A.out_rs + opx[u] + A.out_off] = v;
+      }
+    }
+  }
+}
+
 static bool conv3x3_lds_ok(int Cout, int H, int W) {
   return (Cout + 31) / 32 <= 5 && W <= 64 && 256 % W == 0 && H % (256 / W) == 0 && 8 * (256 / W + 2) * (W + 2) <= 7 * 512;
 }
@@ -289,8 +491,20 @@ static bool conv3x3_lds_ok(int Cout, int H, int W) {
 template <bool UPCAT>
 static hipError_t launch_conv3x3_lds(const Conv3Args& a, hipStream_t s) {
   const int TR = 256 / a.W, cot = (a.Cout + 31) / 32;
-  const size_t lds = (size_t)2 * 8 * (TR + 2) * (a.W + 2) * sizeof(float);
   const dim3 grid((unsigned)(a.views * (a.H / TR))), block(512);
+  if (conv3x3_m16(a.Cout)) {
+    const int tplane = (TR + 2) * (a.W + 2), tstride = ((tplane + 15) & ~31) + 16;
+    const size_t lds16 = (size_t)2 * 8 * tstride * sizeof(float);
+#define POEM_CONVL16(CTV) hipLaunchKernelGGL((conv3x3_lds16_kernel<CTV, UPCAT>), grid, block, lds16, s, a)
+    switch ((a.Cout + 15) / 16) {
+      case 1: POEM_CONVL16(1); break;
+      case 3: POEM_CONVL16(3); break;
+      default: POEM_CONVL16(5); break;
+    }
+#undef POEM_CONVL16
+    return hipGetLastError();
+  }
+  const size_t lds = (size_t)2 * 8 * (TR + 2) * (a.W + 2) * sizeof(float);
 #define POEM_CONVL(CTV) hipLaunchKernelGGL((conv3x3_lds_kernel<CTV, UPCAT>), grid, block, lds, s, a)
   switch (cot) {
     case 1: POEM_CONVL(1); break;
@@ -311,8 +525,8 @@ extern "C" hipError_t poem_launch_upcat_conv3x3(const float* a_half, int Ca, con
                                                 hipStream_t s) {
   if (Ca % 8 || Cb % 8 || Ca + Cb <= 0 || H % 2 || W % 2 || !conv3x3_lds_ok(Cout, H, W) || (long)(H / 2) * (W / 2) >= (1 << 20))
     return hipErrorNotSupported;
-  Conv3Args a{nullptr, (const float4*)wp, scale, shift, nullptr, out, Ca + Cb, Cout, H, W, 1, relu, out_ns, out_cs, out_rs, out_off,
-              views, a_half, b_full, Ca, Cb};
+  Conv3Args a{nullptr, (const float4*)wp, (const float2*)((const float*)wp + conv3x3_floats32(Cout, Ca + Cb)), scale, shift, nullptr, out,
+              Ca + Cb, Cout, H, W, 1, relu, out_ns, out_cs, out_rs, out_off, views, a_half, b_full, Ca, Cb};
   return launch_conv3x3_lds<true>(a, s);
 }
 
@@ -326,8 +540,8 @@ extern "C" hipError_t poem_launch_conv3x3(const float* in, const void* wp, const
   const int Ho = H / stride, Wo = W / stride;
   if ((Ho * Wo) % 32) return hipErrorInvalidValue;
   if ((size_t)Cin * (H + 2) * (W + 2) * 4 >= (1ull << 31)) return hipErrorInvalidValue;
-  Conv3Args a{in, (const float4*)wp, scale, shift, res, out, Cin, Cout, H, W, stride, relu, out_ns, out_cs, out_rs, out_off, views,
-              nullptr, nullptr, 0, 0};
+  Conv3Args a{in, (const float4*)wp, (const float2*)((const float*)wp + conv3x3_floats32(Cout, Cin)), scale, shift, res, out, Cin, Cout, H, W,
+              stride, relu, out_ns, out_cs, out_rs, out_off, views, nullptr, nullptr, 0, 0};
   const int cot = (Cout + 31) / 32, ptiles = Ho * Wo / 32;
   if (stride == 1 && conv3x3_lds_ok(Cout, H, W)) return launch_conv3x3_lds<false>(a, s);
   const int pt = (ptiles % 2 == 0) ? 2 : 1;

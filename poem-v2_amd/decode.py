@@ -94,6 +94,7 @@ class FeatureDecoders:
         if not torch.cuda.is_available():
             raise RuntimeError("FeatureDecoders runs on the MI355X HIP path only (no CPU fallback)")
         self.device = torch.device(device)
+        self.fuse_upcat = [True, True, True]     # per uv_decode stage: poem_upcat_conv3x3 (one launch) vs upsample/concat + conv
         sd = state_dict
         with torch.cuda.device(self.device):
             self.feat_delayer = [_Conv3x3(sd, f"feat_delayer.{i}", self.device) for i in range(3)]
@@ -170,7 +171,7 @@ class FeatureDecoders:
             for i, conv in enumerate(self.uv_delayer):
                 r *= 2
                 y = torch.empty(views, conv.cout, r, r, dtype=torch.float32, device=self.device)
-                if not conv.upcat(x, rev[i + 1], r, r, y, _plain_strides(conv.cout, r, r)):     # one launch where the shape allows
+                if not (self.fuse_upcat[i] and conv.upcat(x, rev[i + 1], r, r, y, _plain_strides(conv.cout, r, r))):   # one launch where it pays
                     conv(upsample2_concat_pad(x, rev[i + 1], r, r, 1), r, r, 1, y, _plain_strides(conv.cout, r, r))
                 x = y
             hm = torch.empty(views, NUM_JOINTS, r // 2, r // 2, dtype=torch.float32, device=self.device)

@@ -89,6 +89,8 @@ def decode_case(views=256):
     sd = do.seeded_decoder_state(0)
     feats = [f.to(dev) for f in do.synthetic_mlvl_feats(views, 0)]
     dec = pk.decode.FeatureDecoders(sd, dev)
+    if os.environ.get("POEM_FUSE_UPCAT"):
+        dec.fuse_upcat = [c == "1" for c in os.environ["POEM_FUSE_UPCAT"]]
     t1 = timeit(lambda: dec.feat_decode(feats), 10)
     t2 = timeit(lambda: dec.heatmap_stage(feats, 256, 256), 10)
     fl1 = views * 2.0 * (9 * 40 * 80 * 1024 + 9 * 80 * 160 * 256 + 9 * 160 * 320 * 64 + 320 * 160 * 256)
