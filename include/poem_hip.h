@@ -279,6 +279,13 @@ int poem_conv3x3(const float* in_padded, const void* w_packed, const float* scal
                  int64_t out_view_stride, int out_ch_stride, int out_row_stride, int out_offset, void* stream);
 int poem_upsample2_concat_pad(const float* a, int ca, const float* b, int cb, float* out, int views, int h, int w, int pad,
                               void* stream);
+/* A stride-2 ConvBlock of feat_decode (POEM.py:183-189: padding 1, stride 2) straight from the UNBORDERED input
+ * (views,cin,h,w): LDS-staged, 16-channel matrix tiles; out / residual addressing as poem_conv3x3.  POEM_E_UNSUPPORTED for
+ * shapes other than HRNet-W40's three (cout, h = w) = (80, 64), (160, 32), (320, 16): use poem_conv3x3(stride 2) on a
+ * zero-bordered copy then. */
+int poem_conv3x3_down2(const float* in, const void* w_packed, const float* scale, const float* shift, const float* residual,
+                       float* out, int views, int cin, int cout, int h, int w, int relu, int64_t out_view_stride,
+                       int out_ch_stride, int out_row_stride, int out_offset, void* stream);
 /* One uv_decode stage in one launch (POEM.py:203-205: F.interpolate x2, torch.cat, ConvBlock): stride-1 conv3x3 of
  * [bilinear x2 of a_half (views,ca,h/2,w/2) | b_full (views,cb,h,w)] with the concatenation, the zero border and the
  * upsampling applied while the input halo is staged in LDS -- the concatenated tensor never exists.  Same epilogue and output

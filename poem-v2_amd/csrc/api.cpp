@@ -105,6 +105,9 @@ hipError_t poem_launch_pack_conv3x3(const float* w, int Cout, int Cin, void* out
 hipError_t poem_launch_conv3x3(const float* in, const void* wp, const float* scale, const float* shift, const float* res,
                                float* out, int views, int Cin, int Cout, int H, int W, int stride, int relu, long out_ns,
                                int out_cs, int out_rs, int out_off, hipStream_t s);
+hipError_t poem_launch_conv3x3_down2(const float* in, const void* wp, const float* scale, const float* shift, const float* res,
+                                     float* out, int views, int Cin, int Cout, int H, int W, int relu, long out_ns, int out_cs,
+                                     int out_rs, int out_off, hipStream_t s);
 hipError_t poem_launch_upcat_pad(const float* a, int Ca, const float* b, int Cb, float* out, int views, int H, int W,
                                  int pad, hipStream_t s);
 hipError_t poem_launch_pool_head(const float* x, const float* w, const float* bias, float* hmap, int views, int C, int J,
@@ -1327,6 +1330,17 @@ int poem_conv3x3(const float* in_padded, const void* w_packed, const float* scal
     return POEM_E_UNSUPPORTED;
   HIPCHK(poem_launch_conv3x3(in_padded, w_packed, scale, shift, residual, out, views, cin, cout, h, w, stride, relu,
                              (long)out_view_stride, out_ch_stride, out_row_stride, out_offset, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_conv3x3_down2(const float* in, const void* w_packed, const float* scale, const float* shift, const float* residual,
+                       float* out, int views, int cin, int cout, int h, int w, int relu, int64_t out_view_stride,
+                       int out_ch_stride, int out_row_stride, int out_offset, void* stream) {
+  if (!in || !w_packed || !scale || !shift || !out || views <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return POEM_E_ARG;
+  const hipError_t e = poem_launch_conv3x3_down2(in, w_packed, scale, shift, residual, out, views, cin, cout, h, w, relu,
+                                                 (long)out_view_stride, out_ch_stride, out_row_stride, out_offset, (hipStream_t)stream);
+  if (e == hipErrorNotSupported) return POEM_E_UNSUPPORTED;
+  HIPCHK(e);
   return POEM_OK;
 }
 

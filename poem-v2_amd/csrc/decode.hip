@@ -193,9 +193,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args A) {
 // every address is a scalar offset of a per-view buffer descriptor: `load` is loads only (no VALU), `finish` one multiply and
 // three fmas per interpolated float.  (Round 2 unpacked bit fields and formed 64-bit addresses per float and chunk: a fifth of
 // the fused kernels' time went into staging arithmetic that the fp32 MFMAs do not overlap with.)
-template <bool UPCAT>
+template <bool UPCAT, int MAXLD_ = 7>
 struct Conv3Stager {
-  static constexpr int MAXLD = 7;          // staged floats per thread and chunk: 8 * 396 / 512
+  static constexpr int MAXLD = MAXLD_;     // staged floats per thread and chunk (stride-1 halo: 8 * 396 / 512 -> 7)
   float st[MAXLD], r1[MAXLD], r2[MAXLD], r3[MAXLD];
   float q0[MAXLD], q1[MAXLD], q2[MAXLD], q3[MAXLD];       // bilinear tap weights
   int o0[MAXLD], o1[MAXLD], o2[MAXLD], o3[MAXLD], ob[MAXLD], sdst[MAXLD];
@@ -236,6 +236,29 @@ struct Conv3Stager {
       ob[u] = valid ? chl * sk_plane4 + (y * W + x) * 4 : -1;
     }
   }
+  // Stride-2 convolution (padding 1) of an UNBORDERED input (views, C, H, W) = A.skip_b: output rows [yo0, yo0 + 8) need input
+  // rows 2 yo0 - 1 .. 2 yo0 + 15 (17) and columns -1 .. W - 1; staged per channel as [row][column parity][column / 2] (row
+  // stride 2 RS, RS = W / 2 + 1) so that the 16 consecutive output columns of a unit read consecutive LDS words whatever the
+  // tap (input column 2 xo + tx - 1 -> parity tx & 1, half index xo + (tx >> 1)).  Every chunk is of kind 1; positions
+  // outside the image get offset -1 -> zero.
+  __device__ __forceinline__ void init_s2(const Conv3Args& A, int n, int yo0, int tid, int tstride, int nthreads) {
+    const int W = A.W, RS = W / 2 + 1, tplane = 17 * 2 * RS;
+    count = 8 * tplane;
+    Ca = 0;
+    up_plane4 = 0; in_plane4 = 0; sk_plane4 = A.H * W * 4;
+    rs_b = frag_rsrc(A.skip_b + (size_t)n * A.Cin * (A.H * W), (unsigned)((size_t)A.Cin * sk_plane4));
+    rs_a = rs_b;
+#pragma unroll
+    for (int u = 0; u < MAXLD; ++u) {
+      const int i = min(tid + nthreads * u, count - 1);
+      const int chl = i / tplane, o = i % tplane;
+      const int r = o / (2 * RS), pp = (o / RS) & 1, xh = o % RS;
+      const int y = 2 * yo0 - 1 + r, x = 2 * xh + pp - 1;
+      const bool valid = y >= 0 && y < A.H && x >= 0 && x < W;
+      sdst[u] = chl * tstride + o;
+      ob[u] = valid ? chl * sk_plane4 + (y * W + x) * 4 : -1;
+    }
+  }
   __device__ __forceinline__ static float ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
   }
@@ -254,9 +277,14 @@ struct Conv3Stager {
     else if (KIND == 2) { st[u] = ld(rs_a, o0[u], so); r1[u] = ld(rs_a, o1[u], so); r2[u] = ld(rs_a, o2[u], so); r3[u] = ld(rs_a, o3[u], so); }
     else st[u] = ld(rs_b, max(ob[u], 0), so);
   }
-  template <int KIND>
+  template <int KIND, int U = 0>
   __device__ __forceinline__ void load_all() {
-    load_k<KIND, 0>(); load_k<KIND, 1>(); load_k<KIND, 2>(); load_k<KIND, 3>(); load_k<KIND, 4>(); load_k<KIND, 5>(); load_k<KIND, 6>();
+    if constexpr (U < MAXLD) { load_k<KIND, U>(); load_all<KIND, U + 1>(); }
+  }
+  // staged floats [LO, HI) (a tap's share of the chunk in the pinned pipelines)
+  template <int KIND, int LO, int HI>
+  __device__ __forceinline__ void load_range() {
+    if constexpr (LO < HI && LO < MAXLD) { load_k<KIND, LO>(); load_range<KIND, LO + 1, HI>(); }
   }
   template <int KIND>
   __device__ __forceinline__ void finish_k() {
@@ -265,10 +293,10 @@ struct Conv3Stager {
     for (int u = 0; u < MAXLD; ++u)
       st[u] = KIND == 2 ? fmaf(q3[u], r3[u], fmaf(q2[u], r2[u], fmaf(q1[u], r1[u], q0[u] * st[u]))) : (ob[u] >= 0 ? st[u] : 0.f);
   }
-  __device__ __forceinline__ void store(float* buf, int tid) const {
+  __device__ __forceinline__ void store(float* buf, int tid, int nthreads = 512) const {
 #pragma unroll
     for (int u = 0; u < MAXLD; ++u)
-      if (tid + 512 * u < count) buf[sdst[u]] = st[u];
+      if (tid + nthreads * u < count) buf[sdst[u]] = st[u];
   }
 };
 
@@ -482,6 +510,180 @@ __global__ __launch_bounds__(512) void conv3x3_lds16_kernel(Conv3Args A) {
       }
     }
   }
+}
+
+// The three stride-2 ConvBlocks of feat_decode (POEM.py:183-189: 40 -> 80 at 64^2, 80 -> 160 at 32^2, 160 -> 320 at 16^2; each
+// 59 MFLOP per view) on the LDS staging, 16x16x4 tiles.  Round 2 ran them on the direct kernel (every tap of every wave a
+// strided global gather: 40 TFLOP/s) over zero-bordered copies.  Here a block of 8 waves owns 8 output rows of a view =
+// PXB pixel tiles of 32, and CG groups of five 16-channel tiles (wave = one pixel tile x one group): (PXB, CG) = (8, 1),
+// (4, 2), (2, 4) for the three layers -- the input is read unbordered (Conv3Stager::init_s2), the output written plain.
+template <int PXB, int CG, int MAXLD>
+__global__ __launch_bounds__(512, 4) void conv3x3_s2_kernel(Conv3Args A) {
+  constexpr int CT16 = 5;
+  static_assert(PXB * CG == 8, "eight waves");
+  extern __shared__ __attribute__((aligned(16))) float tile[];      // 2 x 8 x tstride
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
+  const int W = A.W, Wo = W / 2, Ho = A.H / 2, RS = W / 2 + 1, KC = A.Cin / 8;
+  // staged plane of a channel: 17 rows x 2 column parities x RS (see Conv3Stager::init_s2), padded to whole waves of 64 floats
+  // so that one wave-wide LDS-DMA request (lane l -> LDS base + 4 l) never straddles two channels; + 16: bank offset of planes
+  const int tplane = 17 * 2 * RS, tpad = (tplane + 63) & ~63, tstride = tpad + 16;
+  const int rblocks = Ho / 8;
+  const int rb = (int)(blockIdx.x % rblocks), n = (int)(blockIdx.x / rblocks);
+  const int yo0 = rb * 8;
+  const int ptile = wv % PXB, cgrp = wv / PXB;
+  const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(A.wp16 + (size_t)cgrp * CT16 * 9 * KC * 64, 0xffffffffu);
+  // Staging by LDS-DMA (buffer_load_dword ... lds): the loaded dwords go straight from the memory pipeline into LDS, no
+  // registers, no ds_write, and a position outside the image is simply an offset beyond the descriptor's range (the hardware
+  // writes zero).  Staged float i = 512 u + tid of a chunk (u < MAXLD): channel i / tpad, plane position i % tpad.
+  const int plane4 = A.H * W * 4;
+  const __amdgpu_buffer_rsrc_t xrs = frag_rsrc(A.skip_b + (size_t)n * A.Cin * (A.H * W), (unsigned)((size_t)A.Cin * plane4));
+  int voff[MAXLD];
+#pragma unroll
+  for (int u = 0; u < MAXLD; ++u) {
+    const int i = tid + 512 * u;
+    const int chl = i / tpad, o = i % tpad;
+    const int r = o / (2 * RS), pp = (o / RS) & 1, xh = o % RS;
+    const int y = 2 * yo0 - 1 + r, x = 2 * xh + pp - 1;
+    const bool valid = chl < 8 && o < tplane && y >= 0 && y < A.H && x >= 0 && x < W;
+    voff[u] = valid ? chl * plane4 + (y * W + x) * 4 : 0x7ffffff0;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // request staged floats [LO, HI) of chunk cc into buffer `buf` (all 64 lanes of a wave share the LDS base: wave-uniform)
+#define POEM_S2_DMA(U, CC, BUF)                                                                                  \
+  if constexpr ((U) < MAXLD) {                                                                                  \
+    const int i0_ = __builtin_amdgcn_readfirstlane(512 * (U) + 64 * wv);                                        \
+    if (i0_ < 8 * tpad)                                                                                         \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(tile + (BUF) * 8 * tstride + (i0_ / tpad) * tstride + i0_ % tpad), 4, \
+                                               voff[(U) < MAXLD ? (U) : 0], __builtin_amdgcn_readfirstlane(8 * (CC) * plane4), 0, 0); \
+  }
+  f32x4 acc[CT16][2];
+#pragma unroll
+  for (int c = 0; c < CT16; ++c)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[c][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    POEM_S2_DMA(0, 0, 0) POEM_S2_DMA(1, 0, 0) POEM_S2_DMA(2, 0, 0) POEM_S2_DMA(3, 0, 0) POEM_S2_DMA(4, 0, 0) POEM_S2_DMA(5, 0, 0)
+    POEM_S2_DMA(6, 0, 0) POEM_S2_DMA(7, 0, 0) POEM_S2_DMA(8, 0, 0) POEM_S2_DMA(9, 0, 0) POEM_S2_DMA(10, 0, 0) POEM_S2_DMA(11, 0, 0)
+    POEM_S2_DMA(12, 0, 0) POEM_S2_DMA(13, 0, 0) POEM_S2_DMA(14, 0, 0) POEM_S2_DMA(15, 0, 0) POEM_S2_DMA(16, 0, 0) POEM_S2_DMA(17, 0, 0)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int boff[2], opy[2], opx[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int pix = ptile * 32 + 16 * u + j;          // within the block's 8 x Wo output pixels
+    opy[u] = pix / Wo;
+    opx[u] = pix % Wo;
+    boff[u] = g * tstride + (2 * opy[u]) * 2 * RS + opx[u];
+  }
+  f32x2v wa[CT16], wb[CT16];
+  float ba[4], bb[4];
+#define POEM_S2_LOADW(AW, TAP, CC)                                                                              \
+  _Pragma("unroll") for (int c = 0; c < CT16; ++c)                                                              \
+    AW[c] = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, ((c * 9 + (TAP)) * KC + (CC)) * 512, 0));
+#define POEM_S2_LOADB(B, TAP)                                                                                   \
+  {                                                                                                             \
+    const int toff_ = ((TAP) / 3) * 2 * RS + (((TAP) % 3) & 1) * RS + (((TAP) % 3) >> 1);                       \
+    B[0] = tb[boff[0] + toff_]; B[1] = tb[boff[1] + toff_];                                                     \
+    B[2] = tb[boff[0] + 4 * tstride + toff_]; B[3] = tb[boff[1] + 4 * tstride + toff_];                         \
+  }
+#define POEM_S2_MMA(AW, B)                                                                                      \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                 \
+    _Pragma("unroll") for (int c = 0; c < CT16; ++c) acc[c][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW[c][0], B[u], acc[c][u], 0, 0, 0); \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                 \
+    _Pragma("unroll") for (int c = 0; c < CT16; ++c) acc[c][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW[c][1], B[2 + u], acc[c][u], 0, 0, 0);
+  // staging requests of the next chunk: two per tap (vmcnt retires in order: a burst in front of the taps would stand
+  // between every tap and its weight fragments)
+#define POEM_S2_STEP(CUR_A, CUR_B, NXT_A, NXT_B, TAP)                                                           \
+  POEM_S2_LOADW(NXT_A, (TAP) + 1, cc) POEM_S2_LOADB(NXT_B, (TAP) + 1)                                           \
+  if constexpr (NEXT != 0) { POEM_S2_DMA(2 * (TAP), cc + 1, (cc + 1) & 1) POEM_S2_DMA(2 * (TAP) + 1, cc + 1, (cc + 1) & 1) }  \
+  __builtin_amdgcn_sched_barrier(0);                                                                            \
+  POEM_S2_MMA(CUR_A, CUR_B)                                                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+  auto chunk = [&](auto next_tag, const int cc) {
+    constexpr int NEXT = decltype(next_tag)::value;
+    const float* tb = tile + (cc & 1) * 8 * tstride;
+    POEM_S2_LOADB(ba, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_S2_STEP(wa, ba, wb, bb, 0) POEM_S2_STEP(wb, bb, wa, ba, 1) POEM_S2_STEP(wa, ba, wb, bb, 2) POEM_S2_STEP(wb, bb, wa, ba, 3)
+    POEM_S2_STEP(wa, ba, wb, bb, 4) POEM_S2_STEP(wb, bb, wa, ba, 5) POEM_S2_STEP(wa, ba, wb, bb, 6) POEM_S2_STEP(wb, bb, wa, ba, 7)
+    { const int ccn = min(cc + 1, KC - 1); POEM_S2_LOADW(wb, 0, ccn) }
+    if constexpr (NEXT != 0) { POEM_S2_DMA(16, cc + 1, (cc + 1) & 1) POEM_S2_DMA(17, cc + 1, (cc + 1) & 1) }
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_S2_MMA(wa, ba)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < CT16; ++c) wa[c] = wb[c];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA of the next chunk has landed
+    __syncthreads();
+  };
+  POEM_S2_LOADW(wa, 0, 0)
+  {
+    int cc = 0;
+    for (; cc + 1 < KC; ++cc) chunk(std::integral_constant<int, 1>{}, cc);
+    chunk(std::integral_constant<int, 0>{}, cc);
+  }
+#undef POEM_S2_DMA
+#undef POEM_S2_LOADW
+#undef POEM_S2_LOADB
+#undef POEM_S2_MMA
+#undef POEM_S2_STEP
+  // epilogue: lane (g, j) holds channels 80 cgrp + 16c + 4g + e of output pixel (unit u, j)
+#pragma unroll
+  for (int c = 0; c < CT16; ++c) {
+    const int cbase = cgrp * (CT16 * 16) + c * 16 + 4 * g;
+    const float4 sc = *reinterpret_cast<const float4*>(A.scale + cbase);
+    const float4 sh = *reinterpret_cast<const float4*>(A.shift + cbase);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = cbase + e;
+      if (co >= A.Cout) continue;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int oy = yo0 + opy[u];
+        float v = fmaf(acc[c][u][e], (&sc.x)[e], (&sh.x)[e]);
+        if (A.relu) v = fmaxf(v, 0.f);
+        if (A.res) v += A.res[((size_t)n * A.Cout + co) * (Ho * Wo) + oy * Wo + opx[u]];
+        A.out[(size_t)n * A.out_ns + (size_t)co * A.out_cs + oy * A.out_rs + opx[u] + A.out_off] = v;
+      }
+    }
+  }
+}
+
+// Shapes conv3x3_s2_kernel takes: 80 / 160 / 320 output channels on 8-row output tiles of 32 / 16 / 8 columns.
+static int conv3x3_s2_shape(int Cout, int H, int W) {
+  if (H != W || H % 16) return 0;
+  if (Cout == 80 && W == 64) return 1;
+  if (Cout == 160 && W == 32) return 2;
+  if (Cout == 320 && W == 16) return 3;
+  return 0;
+}
+
+extern "C" hipError_t poem_launch_conv3x3_down2(const float* in, const void* wp, const float* scale, const float* shift,
+                                                const float* res, float* out, int views, int Cin, int Cout, int H, int W,
+                                                int relu, long out_ns, int out_cs, int out_rs, int out_off, hipStream_t s) {
+  const int shape = conv3x3_s2_shape(Cout, H, W);
+  if (!shape || Cin % 8) return hipErrorNotSupported;
+  Conv3Args a{nullptr, (const float4*)wp, (const float2*)((const float*)wp + conv3x3_floats32(Cout, Cin)), scale, shift, res, out, Cin, Cout,
+              H, W, 2, relu, out_ns, out_cs, out_rs, out_off, views, nullptr, in, 0, Cin};
+  const int RS = W / 2 + 1, tplane = 17 * 2 * RS, tstride = ((tplane + 63) & ~63) + 16;
+  const size_t lds = (size_t)2 * 8 * tstride * sizeof(float);
+  const dim3 grid((unsigned)(views * (H / 2 / 8))), block(512);
+  static std::atomic<unsigned long long> optin[3];
+  if (shape == 1) {
+    auto k = conv3x3_s2_kernel<8, 1, 18>;
+    if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(k), lds, optin[0]); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, block, lds, s, a);
+  } else if (shape == 2) {
+    auto k = conv3x3_s2_kernel<4, 2, 10>;
+    if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(k), lds, optin[1]); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, block, lds, s, a);
+  } else {
+    auto k = conv3x3_s2_kernel<2, 4, 5>;
+    if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(k), lds, optin[2]); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, block, lds, s, a);
+  }
+  return hipGetLastError();
 }
 
 static bool conv3x3_lds_ok(int Cout, int H, int W) {

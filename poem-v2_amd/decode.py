@@ -50,6 +50,18 @@ class _Conv3x3:
                                          int(relu), ns, cs, rs, off, hip.stream()), "poem_conv3x3")
 
 
+def _conv_down2(self, x, h, w, out, out_strides, residual=None, relu=True):
+    """stride-2 conv3x3 of the unbordered ``x`` in one LDS-staged launch (poem_conv3x3_down2); False when the shape is not taken."""
+    ns, cs, rs, off = out_strides
+    rc = hip.lib().poem_conv3x3_down2(hip.ptr(x), self.packed.data_ptr(), hip.ptr(self.scale), hip.ptr(self.shift),
+                                      hip.ptr(residual), hip.ptr(out), x.shape[0], self.cin, self.cout, h, w, int(relu), ns, cs, rs,
+                                      off, hip.stream())
+    if rc == hip.POEM_E_UNSUPPORTED:
+        return False
+    hip.check(rc, "poem_conv3x3_down2")
+    return True
+
+
 def _conv_upcat(self, a, b, h, w, out, out_strides, relu=True):
     """conv3x3 of [bilinear x2 of a | b] in one launch (poem_upcat_conv3x3); False when the shape is not taken."""
     views = b.shape[0]
@@ -64,6 +76,7 @@ def _conv_upcat(self, a, b, h, w, out, out_strides, relu=True):
 
 
 _Conv3x3.upcat = _conv_upcat
+_Conv3x3.down2 = _conv_down2
 
 
 def _padded_strides(c, h, w):
@@ -141,24 +154,31 @@ class FeatureDecoders:
         f = self._check(mlvl_feats)
         views, r = f[0].shape[0], f[0].shape[-1]
         with torch.cuda.device(self.device):
-            x = upsample2_concat_pad(None, f[0], r, r, 1)                       # zero-bordered copy of level 0
+            x, bordered = f[0], False
             for i, conv in enumerate(self.feat_delayer):
                 ro = r // 2
-                last = i == 2
-                if last:
-                    out = torch.empty(views, conv.cout, ro, ro, dtype=torch.float32, device=self.device)
-                    strides = _plain_strides(conv.cout, ro, ro)
-                else:                                                           # lands inside the next conv's input
-                    out = torch.zeros(views, conv.cout, ro + 2, ro + 2, dtype=torch.float32, device=self.device)
-                    strides = _padded_strides(conv.cout, ro, ro)
-                conv(x, r, r, 2, out, strides, residual=f[i + 1])
+                out = torch.empty(views, conv.cout, ro, ro, dtype=torch.float32, device=self.device)
+                if bordered or not conv.down2(x, r, r, out, _plain_strides(conv.cout, ro, ro), residual=f[i + 1]):
+                    # shapes the LDS-staged stride-2 kernel does not take: the direct kernel over zero-bordered tensors
+                    if not bordered:
+                        x = upsample2_concat_pad(None, x, r, r, 1)
+                    if i == 2:
+                        strides = _plain_strides(conv.cout, ro, ro)
+                    else:                                                       # lands inside the next conv's input
+                        out = torch.zeros(views, conv.cout, ro + 2, ro + 2, dtype=torch.float32, device=self.device)
+                        strides = _padded_strides(conv.cout, ro, ro)
+                    conv(x, r, r, 2, out, strides, residual=f[i + 1])
+                    bordered = i < 2
                 x, r = out, ro
-            x = upsample2_concat_pad(x, None, 2 * r, 2 * r, 0)                   # (BN,320,16,16)
-            hw = (2 * r) * (2 * r)
-            y = torch.empty(views, self.feat_in_out, 2 * r, 2 * r, dtype=torch.float32, device=self.device)
+            # feat_in is a 1x1 convolution: it commutes with the bilinear x2 in front of it (both linear, the interpolation
+            # weights sum to one, so the bias passes through) -- applied at the low resolution it is a quarter of the FLOPs
+            # and the (BN,320,16,16) intermediate never exists (POEM.py:190-193 upstream: interpolate, then feat_in)
+            hw = r * r
+            y8 = torch.empty(views, self.feat_in_out, r, r, dtype=torch.float32, device=self.device)
             hip.check(hip.lib().poem_input_proj(hip.ptr(x), self.feat_in_w.data_ptr(), hip.ptr(self.feat_in_b), None, None,
-                                                hip.ptr(y), views, int(x.shape[1]), self.feat_in_out, hw, hip.stream()),
+                                                hip.ptr(y8), views, int(x.shape[1]), self.feat_in_out, hw, hip.stream()),
                       "poem_input_proj")
+            y = upsample2_concat_pad(y8, None, 2 * r, 2 * r, 0)                  # (BN,160,16,16)
         return y
 
     def uv_decode(self, mlvl_feats):

@@ -80,6 +80,35 @@ def test_conv3x3_operator(cin, cout, r, stride, relu, res):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,r", [(40, 80, 64), (80, 160, 32), (160, 320, 16), (24, 80, 64), (40, 96, 64)])
+def test_conv3x3_down2_operator(cin, cout, r):
+    """poem_conv3x3_down2 (a stride-2 ConvBlock of feat_decode from the unbordered input, LDS-staged, 16-channel tiles)
+    against the ConvBlock in fp64 and against the direct kernel over a zero-bordered copy -- HRNet-W40's three shapes with
+    lateral add, a second input width, and a shape it does not take (the entry point says so)."""
+    import poem_v2_amd as pk
+    g = torch.Generator().manual_seed(cin + cout + r)
+    views = 3
+    x = torch.randn(views, cin, r, r, generator=g)
+    sd = {"c.conv.weight": torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5),
+          "c.conv.bias": 0.1 * torch.randn(cout, generator=g), "c.norm.weight": 1 + 0.2 * torch.randn(cout, generator=g),
+          "c.norm.bias": 0.1 * torch.randn(cout, generator=g), "c.norm.running_mean": 0.1 * torch.randn(cout, generator=g),
+          "c.norm.running_var": 0.5 + torch.rand(cout, generator=g)}
+    ro = r // 2
+    lateral = torch.randn(views, cout, ro, ro, generator=g)
+    ref = do.conv_block(x.double(), {k: v.double() for k, v in sd.items()}, "c", stride=2, relu=True) + lateral.double()
+    conv = pk.decode._Conv3x3(sd, "c", torch.device(DEV))
+    out = torch.full((views, cout, ro, ro), float("nan"), device=DEV)
+    taken = conv.down2(x.to(DEV), r, r, out, pk.decode._plain_strides(cout, ro, ro), residual=lateral.to(DEV))
+    assert taken == (cout != 96)
+    direct = torch.empty(views, cout, ro, ro, device=DEV)
+    conv(pk.decode.upsample2_concat_pad(None, x.to(DEV), r, r, 1), r, r, 2, direct, pk.decode._plain_strides(cout, ro, ro),
+         residual=lateral.to(DEV))
+    assert _md(direct, ref) < 2e-5
+    if taken:
+        assert _md(out, ref) < 2e-5 and _md(out, direct) < 2e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ca,cb,cout,r", [(320, 160, 160, 16), (160, 80, 80, 32), (80, 40, 40, 64), (16, 8, 33, 16), (24, 16, 200, 16)])
 def test_upcat_conv3x3_matches_the_two_launch_sequence_and_torch(ca, cb, cout, r):
     """poem_upcat_conv3x3 (one uv_decode stage in one launch: bilinear x2 | concat | zero border staged straight into the
