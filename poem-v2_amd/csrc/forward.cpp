@@ -1,0 +1,268 @@
+// poem_head_forward (POEM_Generalized_Head.forward, lib/models/heads/ptEmb_head.py:825-964 upstream) and poem_decoder_forward
+// (PtEmbedTRv4.forward, lib/models/layers/ptEmb_transformer.py:371-376).  One forward =
+//
+//   view_layout()   per-view index arrays (CSR of the ragged batch) into handle-owned device memory, when they changed
+//   inputs()        the four kernels that read the CALLER's tensors: input_proj (+ folded positional table), normalised
+//                   coordinates, inverted extrinsics, projection table                                   [:835-883 upstream]
+//   body()          sampling + Q1 + merge MLPs -> bps_feat ; query features ; the three decoder blocks (decoder.cpp)
+//                   -- workspace / handle memory only, so it replays as a hipGraph                       [:900-942]
+//   finalize        nan_to_num, x radius + centre into the caller's output                                [:944-958]
+#include "engine.h"
+
+namespace {
+
+// SPLIT_F16X3_ALL: every panel GEMM enqueued by the call whose weight lies in the handle's packed arena takes the split image at
+// the same offset (gemm.hip).  Thread-local host state; only a call that installed it clears it (an fp32 forward never touches it).
+struct SplitContext {
+  bool set = false;
+  explicit SplitContext(poem_handle_t h) {
+    if (h->precision != POEM_PRECISION_SPLIT_F16X3_ALL) return;
+    set = true;
+    poem_gemm_split_context(h->packed_base, h->packed_size, h->gemm_split, h->gemm_scales);
+    poem_cross_attention_split(1);
+    const int dh = h->cfg.embed / h->cfg.heads;
+    poem_gemm_split_images(dh == 32 || dh == 64);          // the head dims the split cross attention takes
+  }
+  ~SplitContext() {
+    if (!set) return;
+    poem_gemm_split_context(nullptr, 0, nullptr, nullptr);
+    poem_cross_attention_split(0);
+    poem_gemm_split_images(0);
+  }
+};
+
+struct HeadRun {
+  poem_handle_t h;
+  const poem_config_t& c;
+  Plan p;
+  const float *mlvl_feat, *cam_intr, *cam_extr, *reference_joints;
+  const int32_t* offs_host;
+  const int B, BN, C, S, Q, HW, BS, img_w, img_h;
+  hipStream_t s;
+  bool fused_fe = false;     // merge.hip front end (else the operator sequence of sample.hip + gemm.hip)
+  bool prof_fe = false;      // HIP-event pair around the sampling stage
+  int prof_slot = 0;
+
+  HeadRun(poem_handle_t h_, const float* feat, const float* intr, const float* extr, const int32_t* offs, int batch,
+          const float* ref_joints, int w, int hgt, void* workspace, hipStream_t s_)
+      : h(h_), c(h_->cfg), p(make_plan(h_->cfg, batch, offs[batch], workspace)), mlvl_feat(feat), cam_intr(intr), cam_extr(extr),
+        reference_joints(ref_joints), offs_host(offs), B(batch), BN(offs[batch]), C(c.embed), S(c.nsample), Q(c.nquery),
+        HW(c.feat_h * c.feat_w), BS(batch * c.nsample), img_w(w), img_h(hgt), s(s_) {}
+
+  // ---- view_sample[v] = sample of view v, pe_index[v] = its slot in the folded positional table.  Kept in handle-owned
+  // device memory and re-uploaded only when the layout changes: a pageable H2D copy blocks the host until the stream reaches
+  // it, i.e. until the PREVIOUS forward has finished.
+  int view_layout() {
+    std::vector<int32_t> vs(BN), pei(BN);
+    for (int b = 0; b < B; ++b) {
+      const int n = offs_host[b + 1] - offs_host[b];
+      if (n < 1 || n > c.max_views) return POEM_E_ARG;
+      for (int k = 0; k < n; ++k) {
+        vs[offs_host[b] + k] = b;
+        pei[offs_host[b] + k] = n * (n - 1) / 2 + k;
+      }
+    }
+    const size_t o1 = align_up((size_t)B + 1, 64), o2 = o1 + align_up((size_t)BN, 64), tot = o2 + align_up((size_t)BN, 64);
+    if (h->idx_dev && tot <= (size_t)poem_handle_s::IDX_CAP) {
+      std::vector<int32_t> cur(tot, 0);
+      std::copy(offs_host, offs_host + B + 1, cur.begin());
+      std::copy(vs.begin(), vs.end(), cur.begin() + o1);
+      std::copy(pei.begin(), pei.end(), cur.begin() + o2);
+      if (cur != h->idx_host) {      // (stream-ordered behind the previous forward's kernels, which may still read the old layout)
+        HIPCHK(hipMemcpyAsync(h->idx_dev, cur.data(), tot * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        h->idx_host.swap(cur);
+      }
+      p.offs = h->idx_dev;
+      p.view_sample = h->idx_dev + o1;
+      p.pe_index = h->idx_dev + o2;
+    } else {     // (the host vectors die at return: pageable H2D copies are staged before hipMemcpyAsync returns)
+      HIPCHK(hipMemcpyAsync(p.offs, offs_host, (B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(p.view_sample, vs.data(), BN * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(p.pe_index, pei.data(), BN * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    return POEM_OK;
+  }
+
+  // ---- block-0 anchor tables: the handle's (folded at poem_create) or, tables_cached = 0, rebuilt on the side stream
+  int anchor_tables() {
+    h->tables_pending = false;
+    if (!h->anchor_tables || h->precision != POEM_PRECISION_FP32) return POEM_OK;
+    if (h->tables_cached && h->tab_mem) {
+      p.canon_xyz = h->c_canon_xyz;
+      for (int k = 0; k < 2; ++k) { p.tab_g[k] = h->c_tab_g[k]; p.tab_p[k] = h->c_tab_p[k]; }
+      return POEM_OK;
+    }
+    return build_anchor_tables(h, p, s);
+  }
+
+  // ---- the kernels that read the caller's tensors
+  int inputs() {
+    prof_fe = h->prof_on && (size_t)(2 * h->prof_used + 1) < h->prof_ev.size();
+    prof_slot = h->prof_used;
+    if (prof_fe) { HIPCHK(hipEventRecord(h->prof_ev[2 * prof_slot], s)); h->prof_kind[h->prof_used++] = POEM_PROF_SAMPLING; }
+    fused_fe = h->fused_sampling && h->precision == POEM_PRECISION_FP32 && poem_sample_merge_supported(C, S, HW) != 0;
+    HIPCHK(poem_launch_conv1x1(mlvl_feat, h->P(T_INPROJ_W), h->R(T_INPROJ_B), h->pe_table, p.pe_index,
+                               (fused_fe && !h->taps) ? nullptr : p.x, fused_fe ? p.xt : nullptr, BN, c.in_channels, C, HW, s));
+    HIPCHK(poem_launch_prep_xyz(reference_joints, h->bps, h->tmpl, p.centre, p.pt_xyz, p.xyz[0], B, S, Q, c.radius, s));
+    if (fused_fe) {
+      float* inv = p.uv + (size_t)BN * S * 2;
+      HIPCHK(poem_launch_invert_extr(cam_extr, inv, BN, s));
+      HIPCHK(poem_launch_project_table(h->bps, p.centre, p.view_sample, cam_intr, inv, p.ptab, nullptr, BN, C, c.feat_h, c.feat_w, S,
+                                       img_w, img_h, s));
+    }
+    return POEM_OK;
+  }
+
+  // ---- F.grid_sample + the Q1 view + merge_features_mv / _sv -> bps_feat
+  int sampling(hipStream_t st) {
+    if (fused_fe) {
+      SampleMergeArgs sm{};
+      sm.xt = p.xt; sm.tab = (const float4*)p.ptab; sm.view_sample = p.view_sample; sm.offs = p.offs;
+      sm.w0 = (const float4*)h->P(T_M00_W); sm.b0 = h->R(T_M00_B); sm.w1 = (const float4*)h->P(T_M02_W); sm.b1 = h->R(T_M02_B);
+      sm.h2 = p.h2; sm.q1 = p.q1; sm.views = BN; sm.S = S; sm.hw = HW; sm.h2_tiled = 1;
+      // (per-forward table build only) The build on the neighbour-search stream holds 68 KB of LDS per block, and next to the
+      // MFMA-dense sample_merge waves its blocks linger: a CU that hosts one takes a single sample_merge block (2 x 66.5 KB no
+      // longer fit) and the persistent grid runs in two rounds.  sample_merge waits for the build (+0.06 ms on the critical path).
+      if (h->tables_first && h->tables_pending) HIPCHK(hipStreamWaitEvent(st, h->ev_tab, 0));
+      HIPCHK(poem_launch_sample_merge(&sm, C, st));
+      MergeTailArgs mt{};
+      mt.h2 = p.h2; mt.q1 = p.q1; mt.offs = p.offs;
+      mt.w0 = (const float4*)h->P(T_M10_W); mt.b0 = h->R(T_M10_B); mt.w1 = (const float4*)h->P(T_M12_W); mt.b1 = h->R(T_M12_B);
+      mt.out = p.bps_feat; mt.B = B; mt.S = S; mt.h2_tiled = 1;
+      HIPCHK(poem_launch_merge_tail(&mt, C, st));
+      return POEM_OK;
+    }
+    auto gemm = [&](const float* X, int ldx, int wi, int bi, float* Y, int ldy, int M, int N, int K, int act) -> int {
+      HIPCHK(poem_launch_gemm(X, ldx, h->P(wi), h->R(bi), nullptr, 0, Y, ldy, M, N, K, act, st));
+      return POEM_OK;
+    };
+    HIPCHK(poem_launch_project_sample(p.x, h->bps, p.centre, p.view_sample, cam_intr, cam_extr, p.uv + (size_t)BN * S * 2, p.uv, p.g,
+                                      BN, C, c.feat_h, c.feat_w, S, img_w, img_h, st));
+    // merge MLP 0 on the Q1 rows == the (BN*S, C) row-major view of g's memory
+    int rc = gemm(p.g, C, T_M00_W, T_M00_B, p.h1, C, BN * S, C, C, POEM_ACT_RELU);
+    if (rc == POEM_OK) rc = gemm(p.h1, C, T_M02_W, T_M02_B, p.h2, C / 2, BN * S, C / 2, C, POEM_ACT_NONE);
+    if (rc != POEM_OK) return rc;
+    HIPCHK(poem_launch_merge_reduce(p.h2, p.offs, p.mm, B, S, C / 2, st));
+    rc = gemm(p.mm, C / 2, T_M10_W, T_M10_B, p.mh, C / 2, BS, C / 2, C / 2, POEM_ACT_RELU);
+    if (rc == POEM_OK) rc = gemm(p.mh, C / 2, T_M12_W, T_M12_B, p.y, C, BS, C, C / 2, POEM_ACT_NONE);
+    if (rc != POEM_OK) return rc;
+    HIPCHK(poem_launch_merge_finalize(p.g, p.y, p.offs, p.bps_feat, B, S, C, st));
+    return POEM_OK;
+  }
+
+  // ---- everything between the inputs and the de-normalisation: workspace / handle memory only
+  int body(hipStream_t st, float* pose_dst, float* betas_dst) {
+    if (const int rc = sampling(st); rc != POEM_OK) return rc;
+    if (prof_fe) HIPCHK(hipEventRecord(h->prof_ev[2 * prof_slot + 1], st));
+    HIPCHK(poem_launch_broadcast(h->R(T_QEMB), p.feats0, (long)Q * C, B, st));       // query_feat_embedding, every sample
+    return run_decoder(h, p, p.feats0, p.pt_xyz, p.bps_feat, B, pose_dst, betas_dst, st, true);
+  }
+
+  // ---- hipGraph replay of body(): captured once per (batch, view layout, workspace, option set) on the handle's capture
+  // stream (the caller's may be the legacy default stream, which cannot be captured); the side-stream forks / joins of
+  // decoder.cpp become edges of the graph.  -> 1 replayed, 0 not eligible / capture failed (plain launches), < 0 error.
+  int replay(void* workspace, float* pose_aa, float* betas) {
+    if (!h->graphs || h->graph_broken || !fused_fe || h->prof_on || h->tables_pending || !h->cap_stream) return 0;
+    std::vector<int64_t> key = {B, BN, img_w, img_h, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
+                                h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
+                                h->tables_cached, h->knn_fma, h->taps, c.parametric};
+    key.insert(key.end(), offs_host, offs_host + B + 1);
+    poem_handle_s::GraphEntry* hit = nullptr;
+    for (auto& g : h->graph_cache)
+      if (g.key == key) { hit = &g; break; }
+    if (!hit) {
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      bool ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+      if (ok) {
+        const int rc = body(h->cap_stream, p.g_pose, p.g_betas);
+        const hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
+        ok = rc == POEM_OK && e == hipSuccess && graph != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (!ok) {
+        (void)hipGetLastError();
+        h->graph_broken = true;               // plain launches from now on (results are the same either way)
+        return 0;
+      }
+      if (h->graph_cache.size() >= poem_handle_s::GRAPH_CAP) {      // evict the least recently used
+        size_t lru = 0;
+        for (size_t i = 1; i < h->graph_cache.size(); ++i)
+          if (h->graph_cache[i].stamp < h->graph_cache[lru].stamp) lru = i;
+        (void)hipGraphExecDestroy(h->graph_cache[lru].exec);
+        h->graph_cache.erase(h->graph_cache.begin() + lru);
+      }
+      h->graph_cache.push_back({key, exec, 0});
+      hit = &h->graph_cache.back();
+    }
+    hit->stamp = ++h->graph_clock;
+    HIPCHK(hipGraphLaunch(hit->exec, s));
+    if (c.parametric) {      // the captured tail wrote pose / shape into the workspace
+      HIPCHK(hipMemcpyAsync(pose_aa, p.g_pose, (size_t)B * 48 * sizeof(float), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(betas, p.g_betas, (size_t)B * 10 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return 1;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_intr, const float* cam_extr,
+                      const int32_t* view_offsets_host, int batch, const float* reference_joints, int img_w, int img_h,
+                      float* out_xyz, float* pose_aa, float* betas, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  if (!h || !mlvl_feat || !cam_intr || !cam_extr || !view_offsets_host || batch <= 0 || !reference_joints || !out_xyz ||
+      !workspace || img_w <= 0 || img_h <= 0)
+    return POEM_E_ARG;
+  const poem_config_t& c = h->cfg;
+  if (c.nblocks > 8) return POEM_E_UNSUPPORTED;
+  if (c.parametric && (!pose_aa || !betas)) return POEM_E_ARG;
+  if (view_offsets_host[0] != 0 || view_offsets_host[batch] < batch) return POEM_E_ARG;
+  SplitContext split_ctx(h);
+  HeadRun run(h, mlvl_feat, cam_intr, cam_extr, view_offsets_host, batch, reference_joints, img_w, img_h, workspace, (hipStream_t)stream);
+  if (workspace_bytes < run.p.bytes) return POEM_E_WORKSPACE;
+  int rc = run.view_layout();
+  if (rc == POEM_OK) rc = run.anchor_tables();
+  if (rc == POEM_OK) rc = run.inputs();
+  if (rc != POEM_OK) return rc;
+  rc = run.replay(workspace, pose_aa, betas);
+  if (rc < 0) return rc;
+  if (rc == 0 && (rc = run.body(run.s, pose_aa, betas)) != POEM_OK) return rc;
+  HIPCHK(poem_launch_finalize(run.p.xyz[1], run.p.centre, out_xyz, c.nblocks, batch, c.nquery, c.radius, run.s));
+  register_taps(h, run.p, batch, run.BN, true);
+  return POEM_OK;
+}
+
+int poem_decoder_forward(poem_handle_t h, const float* query_xyz, const float* query_feat, const float* pt_xyz,
+                         const float* pt_feats, int batch, float* out_xyz_norm, float* pose_aa, float* betas,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !query_xyz || !query_feat || !pt_xyz || !pt_feats || batch <= 0 || !out_xyz_norm || !workspace)
+    return POEM_E_ARG;
+  const poem_config_t& c = h->cfg;
+  if (c.nblocks > 8) return POEM_E_UNSUPPORTED;
+  if (c.parametric && (!pose_aa || !betas)) return POEM_E_ARG;
+  Plan p = make_plan(c, batch, batch, workspace);
+  if (workspace_bytes < p.bytes) return POEM_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)batch * c.nquery * 3;
+  HIPCHK(hipMemcpyAsync(p.xyz[0], query_xyz, n * 4, hipMemcpyDeviceToDevice, s));
+  const int rc = run_decoder(h, p, query_feat, pt_xyz, pt_feats, batch, pose_aa, betas, s);
+  if (rc != POEM_OK) return rc;
+  HIPCHK(hipMemcpyAsync(out_xyz_norm, p.xyz[1], n * 4 * c.nblocks, hipMemcpyDeviceToDevice, s));
+  register_taps(h, p, batch, batch, false);
+  return POEM_OK;
+}
+
+int poem_finalize_parametric(poem_handle_t h, const float* mano_verts, const float* mano_joints,
+                             const float* reference_joints, int batch, float* out_xyz, void* stream) {
+  if (!h || !mano_verts || !mano_joints || !reference_joints || !out_xyz || batch <= 0) return POEM_E_ARG;
+  const poem_config_t& c = h->cfg;
+  float* last = out_xyz + (size_t)(c.nblocks - 1) * batch * c.nquery * 3;
+  HIPCHK(poem_launch_finalize_param(mano_verts, mano_joints, reference_joints, last, batch, c.nquery, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,428 @@
+// The handle of libpoem_hip.so (include/poem_hip.h): tensor table, weight packing and composition at creation, the constant
+// tables folded there (positional table, block-0 anchor tables), option switches, debug taps and the HIP-event profile.
+#include "engine.h"
+
+thread_local int g_last_hip_error = 0;
+
+std::vector<TensorSpec> tensor_table(const poem_config_t& c) {
+  const int C = c.embed, Q = c.nquery;
+  std::vector<TensorSpec> t;
+  auto lin = [&](int o, int i, bool pack, bool bias = true) {
+    t.push_back({o, i, pack});
+    if (bias) t.push_back({o, 1, false});
+  };
+  lin(C, c.in_channels, true);
+  lin(C, 3 * C / 2, true);
+  lin(C, C, true);
+  lin(C / 2, C, true);
+  lin(C / 2, C / 2, true);
+  lin(C, C / 2, true);
+  t.push_back({Q, C, false});
+  for (int b = 0; b < c.nblocks; ++b) {
+    lin(C, C, true);
+    for (int a = 0; a < 2; ++a) {
+      lin(C, C, true); lin(C, C, true); lin(C, C, true); lin(C, C, true);
+      t.push_back({C, 1, false}); t.push_back({C, 1, false});
+    }
+    for (int a = 0; a < 2; ++a) {
+      lin(C, C, true); lin(C, C, true);
+      lin(C, 3, false);
+      lin(C, C, true); lin(C, C, true); lin(C, C, true);
+      lin(C, C, true, false); lin(C, C, true, false); lin(C, C, true, false);
+    }
+    lin(C, C, true);
+    lin(3, C, false);
+    lin(4 * C, C, true);
+    lin(C, 4 * C, true);
+    t.push_back({C, 1, false}); t.push_back({C, 1, false});
+    if (c.parametric) {
+      lin(1, Q, false);
+      lin(106, C, false);
+    }
+  }
+  return t;
+}
+
+int check_config(const poem_config_t* c) {
+  if (!c) return POEM_E_ARG;
+  const int C = c->embed;
+  if (C < 32 || C > 1024 || (C & (C - 1))) return POEM_E_UNSUPPORTED;       // 32,64,...,1024
+  if (c->knn != 32) return POEM_E_UNSUPPORTED;
+  if (c->in_channels % 8 || c->nsample % 32 || c->nsample % C) return POEM_E_UNSUPPORTED;
+  if (c->heads <= 0 || C % c->heads) return POEM_E_UNSUPPORTED;
+  const int dh = C / c->heads;
+  if (!(dh == 8 || dh == 16 || dh == 32 || dh == 64 || dh == 128 || dh == 256)) return POEM_E_UNSUPPORTED;
+  if (c->nsample > 4096 || c->nquery > 4096 || c->nquery < 33) return POEM_E_UNSUPPORTED;
+  if ((c->feat_h * c->feat_w) % 32) return POEM_E_UNSUPPORTED;
+  if (c->max_views < 1 || c->max_views > 64 || c->nblocks < 1) return POEM_E_ARG;
+  return POEM_OK;
+}
+
+// ---- workspace plan -------------------------------------------------------------------------------------------------
+extern "C" {
+
+int poem_abi_version(void) { return 1; }
+int poem_last_hip_error(void) { return g_last_hip_error; }
+const char* poem_error_string(int code) {
+  switch (code) {
+    case POEM_OK: return "ok";
+    case POEM_E_ARG: return "bad argument";
+    case POEM_E_WORKSPACE: return "workspace too small";
+    case POEM_E_LAUNCH: return "HIP runtime/launch error";
+    case POEM_E_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown";
+  }
+}
+
+int poem_num_weight_tensors(const poem_config_t* cfg) {
+  if (check_config(cfg) != POEM_OK) return POEM_E_UNSUPPORTED;
+  return (int)tensor_table(*cfg).size();
+}
+
+int64_t poem_weight_tensor_numel(const poem_config_t* cfg, int index) {
+  if (check_config(cfg) != POEM_OK) return POEM_E_UNSUPPORTED;
+  auto t = tensor_table(*cfg);
+  if (index < 0 || index >= (int)t.size()) return POEM_E_ARG;
+  return (int64_t)t[index].rows * t[index].cols;
+}
+
+size_t poem_packed_bytes(const poem_config_t* cfg) {
+  if (check_config(cfg) != POEM_OK) return 0;
+  size_t total = 0;
+  for (auto& s : tensor_table(*cfg))
+    if (s.pack) total += align_up(packed_bytes_linear(s.rows, s.cols), 256);
+  const size_t hw = (size_t)cfg->feat_h * cfg->feat_w;
+  {   // fused images F1..F4 per block + their concatenated biases (F1, F4)
+    const size_t C = cfg->embed;
+    const size_t per = align_up(packed_bytes_linear(6 * C, C), 256) + align_up(packed_bytes_linear(2 * C, C), 256) +
+                       align_up(packed_bytes_linear(3 * C, C), 256) + align_up(packed_bytes_linear(5 * C, C), 256) +
+                       align_up(6 * C * 4, 256) + align_up(2 * C * 4, 256) + align_up(3 * C * 4, 256) + align_up(5 * C * 4, 256) +
+                       3 * align_up(packed_bytes_linear(C, C), 256) + 2 * align_up(C * 4, 256);
+    total += per * cfg->nblocks;
+    total += align_up((6 * C * C + 2 * C * C + 8 * C) * 4, 256) + 256;   // raw composites (init-time scratch, at the arena's end)
+  }
+  total += align_up((size_t)poem_handle_s::IDX_CAP * 4, 256);                              // per-view index arrays
+  total += align_up(pe_views(cfg->max_views) * cfg->embed * hw * 4, 256);              // folded positional table
+  total += align_up(pe_views(cfg->max_views) * (3 * cfg->embed / 2) * hw * 4, 256);    // sine scratch (init only)
+  return total;
+}
+
+size_t poem_packed_linear_bytes(int out_features, int in_features) {
+  if (in_features % 8) return 0;
+  return packed_bytes_linear(out_features, in_features);
+}
+
+int poem_pack_linear(const float* w, int out_features, int in_features, void* packed, void* stream) {
+  if (!w || !packed || in_features % 8 || out_features <= 0) return POEM_E_ARG;
+  HIPCHK(poem_launch_pack_linear(w, out_features, in_features, packed, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, const float* bps, const float* anchor,
+                const int32_t* anchor_idx, const float* template_xyz, void* packed, size_t packed_bytes, void* stream,
+                poem_handle_t* out) {
+  int rc = check_config(cfg);
+  if (rc != POEM_OK) return rc;
+  if (!raw_host || !bps || !anchor || !anchor_idx || !template_xyz || !packed || !out) return POEM_E_ARG;
+  auto* h = new poem_handle_s();
+  h->cfg = *cfg;
+  h->specs = tensor_table(*cfg);
+  if (n != (int)h->specs.size() || packed_bytes < poem_packed_bytes(cfg)) { poem_destroy(h); return POEM_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  char* cur = (char*)packed;
+  h->packed_base = (const char*)packed;
+  h->packed_size = packed_bytes;
+  if (cfg->embed >= 128) {
+    if (hipMalloc((void**)&h->gemm_split, packed_bytes) != hipSuccess ||
+        hipMalloc((void**)&h->gemm_scales, (packed_bytes / 256 + 1) * sizeof(float)) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
+    }
+  }
+  // mirror of a freshly packed fp32 image at `at`: the split image of the same row-major weight
+  auto mirror = [&](const float* w_rows, int rows, int cols, const char* at) -> hipError_t {
+    if (!h->gemm_split || cols % 16) return hipSuccess;
+    const size_t off = (size_t)(at - (const char*)packed);
+    return poem_launch_pack_split_tiles(w_rows, rows, cols, h->gemm_split + off, h->gemm_scales + off / 256, cols / 2, s);
+  };
+  h->raw.resize(n);
+  h->packed.assign(n, nullptr);
+  for (int i = 0; i < n; ++i) {
+    if (!raw_host[i]) { poem_destroy(h); return POEM_E_ARG; }
+    h->raw[i] = (const float*)raw_host[i];
+    if (h->specs[i].pack) {
+      hipError_t e = poem_launch_pack_linear(h->raw[i], h->specs[i].rows, h->specs[i].cols, cur, s);
+      if (e == hipSuccess) e = mirror(h->raw[i], h->specs[i].rows, h->specs[i].cols, cur);
+      if (e != hipSuccess) { g_last_hip_error = (int)e; poem_destroy(h); return POEM_E_LAUNCH; }
+      h->packed[i] = cur;
+      cur += align_up(packed_bytes_linear(h->specs[i].rows, h->specs[i].cols), 256);
+    }
+  }
+  h->bps = bps; h->anchor = anchor; h->anchor_idx = anchor_idx; h->tmpl = template_xyz;
+  const int C = cfg->embed, hw = cfg->feat_h * cfg->feat_w;
+  if (C >= 128) {
+    h->split.resize(2 * cfg->nblocks);
+    if (hipMalloc(&h->split_mem, (size_t)2 * cfg->nblocks * ((size_t)3 * C * C * 4 + 256)) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
+    }
+  }
+  {
+    h->fused.resize(cfg->nblocks);
+    // init-time scratch for raw composites: rows (<= 6C x C), T (C x C), t2 (C x C), bias vectors
+    float* raw_rows = (float*)((char*)packed + ((packed_bytes - align_up((size_t)(6 * C * C + 2 * C * C + 8 * C) * 4, 256)) & ~(size_t)255));
+    float* raw_T = raw_rows + (size_t)6 * C * C;
+    float* raw_tb = raw_T + (size_t)2 * C * C;       // C floats (+ spare)
+    bool ok = true;
+    auto LOK = [&](hipError_t e) { ok = ok && e == hipSuccess; };
+    // rows [slot*C, (slot+1)*C) of raw_rows = A . Bm ; bias slot likewise = A . b1 + b2
+    auto comp = [&](int slot, const float* A, const float* Bm, const float* b1, const float* b2, float* bias_out) {
+      LOK(poem_launch_compose_weight(A, Bm, raw_rows + (size_t)slot * C * C, C, C, C, s));
+      LOK(poem_launch_compose_bias(A, b1, b2, bias_out + (size_t)slot * C, C, C, s));
+    };
+    auto pack_rows = [&](int nslots, const void** wout) {
+      *wout = cur;
+      LOK(poem_launch_pack_linear(raw_rows, nslots * C, C, cur, s));
+      LOK(mirror(raw_rows, nslots * C, C, cur));
+      cur += align_up(packed_bytes_linear(nslots * C, C), 256);
+    };
+    for (int b = 0; b < cfg->nblocks && ok; ++b) {
+      const int bb = h->block_base(b);
+      const int a1 = bb + B_A1, a2 = bb + B_A2, vs = bb + B_VS, vc = bb + B_VC;
+      auto& f = h->fused[b];
+      const float* We = h->raw[bb + B_EMB_W];
+      const float* be = h->raw[bb + B_EMB_B];
+      // ---- F1: basis-point side
+      float* b0 = (float*)cur; cur += align_up((size_t)6 * C * 4, 256);
+      comp(0, h->raw[a1 + 2], We, be, h->raw[a1 + 3], b0);
+      comp(1, h->raw[a1 + 4], We, be, h->raw[a1 + 5], b0);
+      comp(2, h->raw[a2 + 2], We, be, h->raw[a2 + 3], b0);
+      comp(3, h->raw[a2 + 4], We, be, h->raw[a2 + 5], b0);
+      // T = fc1 . embedding, tb = fc1 . be + b_fc1 ; then (W_g1 w_ks) . T and w_vs . T (no bias of their own)
+      float* raw_T2 = raw_T + (size_t)C * C;
+      LOK(poem_launch_compose_weight(h->raw[vc + 0], We, raw_T, C, C, C, s));
+      LOK(poem_launch_compose_bias(h->raw[vc + 0], be, h->raw[vc + 1], raw_tb, C, C, s));
+      LOK(poem_launch_compose_weight(h->raw[vc + 8], h->raw[vc + 13], raw_T2, C, C, C, s));      // W_g1 w_ks
+      comp(4, raw_T2, raw_T, raw_tb, nullptr, b0);
+      comp(5, h->raw[vc + 14], raw_T, raw_tb, nullptr, b0);
+      f.b[0] = b0;
+      pack_rows(6, &f.w[0]);
+      // ---- F2: query side, embedding | attn.query o embedding
+      float* b1v = (float*)cur; cur += align_up((size_t)2 * C * 4, 256);
+      LOK(hipMemcpyAsync(raw_rows, We, (size_t)C * C * 4, hipMemcpyDeviceToDevice, s));
+      LOK(hipMemcpyAsync(b1v, be, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+      comp(1, h->raw[a1 + 0], We, be, h->raw[a1 + 1], b1v);
+      f.b[1] = b1v;
+      pack_rows(2, &f.w[1]);
+      // ---- F3: (W_g1 w_qs | W_g1 w_ks | w_vs) o fc1 of the vector self attention; the query part carries
+      //      cvec = W_g1 b_d2 + b_g1 (vecattn.hip, composed form)
+      float* b2v = (float*)cur; cur += align_up((size_t)3 * C * 4, 256);
+      float* cvec = raw_tb + 2 * C;
+      LOK(poem_launch_compose_bias(h->raw[vs + 8], h->raw[vs + 7], h->raw[vs + 9], cvec, C, C, s));
+      LOK(poem_launch_compose_weight(h->raw[vs + 8], h->raw[vs + 12], raw_T, C, C, C, s));       // W_g1 w_qs
+      comp(0, raw_T, h->raw[vs + 0], h->raw[vs + 1], cvec, b2v);
+      LOK(poem_launch_compose_weight(h->raw[vs + 8], h->raw[vs + 13], raw_T, C, C, C, s));       // W_g1 w_ks
+      comp(1, raw_T, h->raw[vs + 0], h->raw[vs + 1], nullptr, b2v);
+      comp(2, h->raw[vs + 14], h->raw[vs + 0], h->raw[vs + 1], nullptr, b2v);
+      f.b[2] = b2v;
+      pack_rows(3, &f.w[2]);
+      // ---- [4]: query of the vector cross attention, (W_g1 w_qs) f_self + (W_g1 b_d2 + b_g1)
+      float* b4v = (float*)cur; cur += align_up((size_t)C * 4, 256);
+      LOK(poem_launch_compose_bias(h->raw[vc + 8], h->raw[vc + 7], h->raw[vc + 9], b4v, C, C, s));
+      LOK(poem_launch_compose_weight(h->raw[vc + 8], h->raw[vc + 12], raw_rows, C, C, C, s));
+      f.b[4] = b4v;
+      pack_rows(1, &f.w[4]);
+      // ---- [5], [6]: W_g1 W_d2 of the two vector attentions
+      LOK(poem_launch_compose_weight(h->raw[vs + 8], h->raw[vs + 6], raw_rows, C, C, C, s));
+      pack_rows(1, &f.w[5]);
+      LOK(poem_launch_compose_weight(h->raw[vc + 8], h->raw[vc + 6], raw_rows, C, C, C, s));
+      pack_rows(1, &f.w[6]);
+      f.b[5] = f.b[6] = nullptr;
+      if (h->split_mem) {                      // split images: W_d2, W_g1 W_d2 (re-composed into raw_rows), W_g2
+        const size_t img = (size_t)C * C * 4;
+        for (int a = 0; a < 2; ++a) {
+          const int vb = a == 0 ? vs : vc;
+          char* base = (char*)h->split_mem + ((size_t)(2 * b + a)) * (3 * img + 256);
+          float* sc = (float*)(base + 3 * img);
+          LOK(poem_launch_pack_split(h->raw[vb + 6], C, base, sc + 0, s));
+          LOK(poem_launch_compose_weight(h->raw[vb + 8], h->raw[vb + 6], raw_rows, C, C, C, s));
+          LOK(poem_launch_pack_split(raw_rows, C, base + img, sc + 1, s));
+          LOK(poem_launch_pack_split(h->raw[vb + 10], C, base + 2 * img, sc + 2, s));
+          h->split[2 * b + a] = {{base, base + img, base + 2 * img}, sc};
+        }
+      }
+      // F4: reg_branch.0 | intermediate.dense share f_cross; intermediate.dense is (4C, C): four C-row slabs of the raw tensor
+      f.w[3] = cur;
+      ok = ok && poem_launch_pack_linear(h->raw[bb + B_REG0_W], C, C, cur, s) == hipSuccess;
+      LOK(mirror(h->raw[bb + B_REG0_W], C, C, cur));
+      cur += packed_bytes_linear(C, C);
+      ok = ok && poem_launch_pack_linear(h->raw[bb + B_INT_W], 4 * C, C, cur, s) == hipSuccess;
+      LOK(mirror(h->raw[bb + B_INT_W], 4 * C, C, cur));
+      cur += packed_bytes_linear(4 * C, C);
+      cur = (char*)packed + align_up((size_t)(cur - (char*)packed), 256);
+      f.b[3] = (const float*)cur;
+      ok = ok && hipMemcpyAsync(cur, h->raw[bb + B_REG0_B], (size_t)C * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
+      ok = ok && hipMemcpyAsync(cur + (size_t)C * 4, h->raw[bb + B_INT_B], (size_t)4 * C * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
+      cur += align_up((size_t)5 * C * 4, 256);
+    }
+    if (!ok) { g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH; }
+  }
+  h->idx_dev = (int32_t*)cur;
+  cur += align_up((size_t)poem_handle_s::IDX_CAP * 4, 256);
+  h->pe_table = (float*)cur;
+  cur += align_up(pe_views(cfg->max_views) * C * hw * 4, 256);
+  float* sine = (float*)cur;
+  rc = poem_pe_table(h->P(T_ADAPT_W), h->R(T_ADAPT_B), C, cfg->feat_h, cfg->feat_w, cfg->max_views, sine, h->pe_table,
+                     stream);
+  if (rc != POEM_OK) { poem_destroy(h); return rc; }
+  {
+    bool ok = hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
+    auto mk = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
+    mk(&h->ev_fork); mk(&h->ev_join_bps); mk(&h->ev_join_knn); mk(&h->ev_tab); mk(&h->ev_fork0);
+    for (int i = 0; i < 8; ++i) { mk(&h->ev_bps[i]); mk(&h->ev_xyz[i]); mk(&h->ev_knn[i]); }
+    if (!ok) { poem_destroy(h); return POEM_E_LAUNCH; }
+  }
+  {   // block-0 anchor tables (see poem_handle_s::tables_cached): handle-owned, built here once
+    const size_t tf = poem_vector_attention_table_floats(cfg->nquery, C);
+    const size_t cx = align_up((size_t)cfg->nquery * 3, 64);
+    if (hipMalloc((void**)&h->tab_mem, (cx + 4 * tf) * sizeof(float)) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
+    }
+    h->c_canon_xyz = h->tab_mem;
+    Plan tp{};
+    tp.canon_xyz = h->c_canon_xyz;
+    for (int k = 0; k < 2; ++k) {
+      tp.tab_g[k] = h->c_tab_g[k] = h->tab_mem + cx + (size_t)(2 * k) * tf;
+      tp.tab_p[k] = h->c_tab_p[k] = h->tab_mem + cx + (size_t)(2 * k + 1) * tf;
+    }
+    rc = build_anchor_tables(h, tp, s, true);
+    if (rc != POEM_OK) { poem_destroy(h); return rc; }
+  }
+  *out = h;
+  return POEM_OK;
+}
+
+void poem_destroy(poem_handle_t h) {
+  if (!h) return;
+  for (auto e : h->prof_ev) (void)hipEventDestroy(e);
+  auto de = [](hipEvent_t e) { if (e) (void)hipEventDestroy(e); };
+  de(h->ev_fork); de(h->ev_join_bps); de(h->ev_join_knn); de(h->ev_tab); de(h->ev_fork0);
+  for (int i = 0; i < 8; ++i) { de(h->ev_bps[i]); de(h->ev_xyz[i]); de(h->ev_knn[i]); }
+  if (h->tab_mem) (void)hipFree(h->tab_mem);
+  if (h->split_mem) (void)hipFree(h->split_mem);
+  if (h->gemm_split) (void)hipFree(h->gemm_split);
+  if (h->gemm_scales) (void)hipFree(h->gemm_scales);
+  for (auto& g : h->graph_cache) (void)hipGraphExecDestroy(g.exec);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->bps_stream) (void)hipStreamDestroy(h->bps_stream);
+  if (h->knn_stream) (void)hipStreamDestroy(h->knn_stream);
+  delete h;
+}
+
+int poem_set_overlap(poem_handle_t h, int enable) {
+  if (!h) return POEM_E_ARG;
+  h->overlap = enable != 0;
+  return POEM_OK;
+}
+
+int poem_set_chains(poem_handle_t h, int enable) {
+  if (!h) return POEM_E_ARG;
+  h->chains = enable != 0;
+  return POEM_OK;
+}
+
+int poem_set_option(poem_handle_t h, const char* name, int value) {
+  if (!h || !name) return POEM_E_ARG;
+  const std::string k(name);
+  if (k == "overlap") h->overlap = value != 0;
+  else if (k == "anchor_tables") h->anchor_tables = value != 0;
+  else if (k == "chains") h->chains = value != 0;
+  else if (k == "knn_early") h->knn_early = value != 0;
+  else if (k == "fused_sampling") h->fused_sampling = value != 0;
+  else if (k == "chain_combine") h->chain_combine = value != 0;
+  else if (k == "tables_first") h->tables_first = value != 0;
+  else if (k == "tables_cached") h->tables_cached = value != 0;
+  else if (k == "knn_fma") h->knn_fma = value != 0;
+  else if (k == "graphs") h->graphs = value != 0;
+  else if (k == "chain_tile") { if (value < 0 || value > 3) return POEM_E_ARG; h->chain_tile = value; }
+  else return POEM_E_ARG;
+  return POEM_OK;
+}
+
+int poem_set_anchor_tables(poem_handle_t h, int enable) {
+  if (!h) return POEM_E_ARG;
+  h->anchor_tables = enable != 0;
+  return POEM_OK;
+}
+
+int poem_set_precision(poem_handle_t h, int mode) {
+  if (!h || mode < POEM_PRECISION_FP32 || mode > POEM_PRECISION_SPLIT_F16X3_ALL) return POEM_E_ARG;
+  if (mode != POEM_PRECISION_FP32 && (!h->split_mem || !h->gemm_split)) return POEM_E_UNSUPPORTED;      // embed < 128
+  h->precision = mode;
+  return POEM_OK;
+}
+
+int poem_enable_taps(poem_handle_t h, int enable) {
+  if (!h) return POEM_E_ARG;
+  h->taps = enable != 0;
+  return POEM_OK;
+}
+
+int64_t poem_tap(poem_handle_t h, const char* name, void* dst, int64_t dst_elems, void* stream) {
+  if (!h || !name) return POEM_E_ARG;
+  auto it = h->tapmap.find(name);
+  if (it == h->tapmap.end()) return POEM_E_ARG;
+  if (dst) {
+    if (dst_elems < it->second.elems) return POEM_E_ARG;
+    HIPCHK(hipMemcpyAsync(dst, it->second.p, (size_t)it->second.elems * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  }
+  return it->second.elems;
+}
+int poem_profile_enable(poem_handle_t h, int max_launches) {
+  if (!h || max_launches < 0) return POEM_E_ARG;
+  for (auto e : h->prof_ev) (void)hipEventDestroy(e);
+  h->prof_ev.clear();
+  h->prof_used = 0;
+  h->prof_on = max_launches > 0;
+  h->prof_kind.assign((size_t)max_launches, 0);
+  for (int i = 0; i < 2 * max_launches; ++i) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    h->prof_ev.push_back(e);
+  }
+  return POEM_OK;
+}
+
+static int profile_sum(poem_handle_t h, int kind, int* launches, float* total_ms) {
+  float tot = 0.f;
+  int n = 0;
+  for (int i = 0; i < h->prof_used; ++i) {
+    if (h->prof_kind[i] != kind) continue;
+    HIPCHK(hipEventSynchronize(h->prof_ev[2 * i + 1]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+    tot += ms;
+    ++n;
+  }
+  *launches = n;
+  *total_ms = tot;
+  return POEM_OK;
+}
+
+int poem_profile_read(poem_handle_t h, int* launches, float* total_ms, int reset) {
+  if (!h || !launches || !total_ms) return POEM_E_ARG;
+  const int rc = profile_sum(h, 0, launches, total_ms);
+  if (rc == POEM_OK && reset) h->prof_used = 0;
+  return rc;
+}
+
+int poem_profile_read_anchored(poem_handle_t h, int* launches, float* total_ms) {
+  if (!h || !launches || !total_ms) return POEM_E_ARG;
+  return profile_sum(h, 1, launches, total_ms);
+}
+
+int poem_profile_read_stage(poem_handle_t h, int stage, int* launches, float* total_ms) {
+  if (!h || !launches || !total_ms || stage < 0 || stage > 7) return POEM_E_ARG;
+  return profile_sum(h, stage, launches, total_ms);
+}
+}  // extern "C"

@@ -314,7 +314,7 @@ def test_eval_single_cfg_edits_match_reference():
 
 
 def test_internal_launcher_declarations_match_their_definitions():
-    """csrc/api.cpp declares the kernel launchers of the .hip files as extern "C": such symbols carry no signature, so
+    """csrc/launchers.h declares the kernel launchers of the .hip files as extern "C": such symbols carry no signature, so
     a drifted declaration still links and then corrupts the call (stream read from the wrong slot).  Compare the
     parameter type lists textually."""
     import importlib.util

@@ -1,4 +1,4 @@
-"""Development check: every `extern "C"` launcher declared in csrc/api.cpp has the same parameter TYPE list as its
+"""Development check: every `extern "C"` launcher declared in csrc/launchers.h has the same parameter TYPE list as its
 definition in the .hip files (extern "C" symbols carry no signature, so a drifted declaration links fine and corrupts
 the call)."""
 import glob
@@ -18,8 +18,7 @@ def types(params):
 
 
 def main():
-    decl = open(os.path.join(CSRC, "api.cpp")).read()
-    decl = decl[:decl.index("static thread_local int g_last_hip_error")]
+    decl = open(os.path.join(CSRC, "launchers.h")).read()
     decls = {m.group(2): re.sub(r"\s+", " ", m.group(3))
              for m in re.finditer(r"(hipError_t|size_t)\s+(poem_\w+)\s*\(([^;]*?)\)\s*;", decl, re.S)}
     defs = {}
