@@ -135,6 +135,7 @@ struct poem_handle_s {
   bool graphs = true;
   bool graph_broken = false;         // a capture failed once on this handle: stay on plain launches
   hipStream_t cap_stream = nullptr;
+  int stream_device = 0;             // device whose stream pool (handle.cpp) the three streams belong to
   struct GraphEntry { std::vector<int64_t> key; hipGraphExec_t exec; uint64_t stamp; };
   std::vector<GraphEntry> graph_cache;
   uint64_t graph_clock = 0;

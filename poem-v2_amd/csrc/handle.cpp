@@ -4,6 +4,48 @@
 
 thread_local int g_last_hip_error = 0;
 
+// The capture stream and the two side streams of a handle come from a process-wide pool per device and go back to it at
+// poem_destroy instead of being destroyed: on ROCm 7.0's runtime, destroying streams that took part in a stream capture
+// AND the graph exec instantiated from it makes a LATER handle's hipGraphLaunch crash inside libamdhip64 (reproduced with
+// five handle life cycles in one process, tools/parity_report.py; either destruction alone is harmless).  A handle's
+// streams are idle when it is destroyed, so the next handle can take them over as they are.
+#include <mutex>
+namespace {
+struct StreamSet { hipStream_t cap, bps, knn; };
+std::mutex g_pool_mutex;
+std::map<int, std::vector<StreamSet>> g_stream_pool;       // device id -> idle sets
+
+bool take_streams(poem_handle_t h) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  h->stream_device = dev;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    auto& pool = g_stream_pool[dev];
+    if (!pool.empty()) {
+      h->cap_stream = pool.back().cap; h->bps_stream = pool.back().bps; h->knn_stream = pool.back().knn;
+      pool.pop_back();
+      return true;
+    }
+  }
+  return hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
+}
+
+void return_streams(poem_handle_t h) {
+  if (!h->cap_stream || !h->bps_stream || !h->knn_stream) {     // a partly created set: nothing was captured on it
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->bps_stream) (void)hipStreamDestroy(h->bps_stream);
+    if (h->knn_stream) (void)hipStreamDestroy(h->knn_stream);
+  } else {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_stream_pool[h->stream_device].push_back({h->cap_stream, h->bps_stream, h->knn_stream});
+  }
+  h->cap_stream = h->bps_stream = h->knn_stream = nullptr;
+}
+}  // namespace
+
 std::vector<TensorSpec> tensor_table(const poem_config_t& c) {
   const int C = c.embed, Q = c.nquery;
   std::vector<TensorSpec> t;
@@ -274,9 +316,7 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
                      stream);
   if (rc != POEM_OK) { poem_destroy(h); return rc; }
   {
-    bool ok = hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = take_streams(h);
     auto mk = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
     mk(&h->ev_fork); mk(&h->ev_join_bps); mk(&h->ev_join_knn); mk(&h->ev_tab); mk(&h->ev_fork0);
     for (int i = 0; i < 8; ++i) { mk(&h->ev_bps[i]); mk(&h->ev_xyz[i]); mk(&h->ev_knn[i]); }
@@ -313,9 +353,7 @@ void poem_destroy(poem_handle_t h) {
   if (h->gemm_split) (void)hipFree(h->gemm_split);
   if (h->gemm_scales) (void)hipFree(h->gemm_scales);
   for (auto& g : h->graph_cache) (void)hipGraphExecDestroy(g.exec);
-  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-  if (h->bps_stream) (void)hipStreamDestroy(h->bps_stream);
-  if (h->knn_stream) (void)hipStreamDestroy(h->knn_stream);
+  return_streams(h);
   delete h;
 }
 
