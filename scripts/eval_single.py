@@ -299,6 +299,11 @@ def main(args):
                        batch_size=args.batch_size, pyramid=args.pyramid, template=args.template)
     if rank == 0:
         exp_id = f"{args.dataset}_view_{view_range[0]}_{view_range[1]}_{args.model}"
+        if args.model == "huge":
+            # C = 1024 (dh = 256) is outside the widths the fused kernels are instantiated for (merge.hip / chain.hip: 128 / 256 /
+            # 512): the head runs the round-1 operator sequence -- same results, ~100 samples/s at batch 8 instead of the
+            # medium model's 1400 (not a BASELINE config; upstream's README lists only the other four models)
+            res["note"] = "POEM-huge runs the operator sequence (no fused front end / chain kernels at embed 1024)"
         print(json.dumps({"exp_id": exp_id, **res}))
     if world > 1:
         torch.distributed.destroy_process_group()
