@@ -13,9 +13,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- p
 # (ii) the default command, every leg (the driver's invocation)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_full -o bench -- python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
 rm -f $OUT/stats_full/*kernel_trace.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python bench.py --steps 1 --warmup 1 --headline-only > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python bench.py --steps 1 --warmup 1 --headline-only > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o pmc -- python bench.py --steps 1 --warmup 1 --headline-only > /dev/null 2> $OUT/pmc_mfma.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python bench.py --steps 1 --warmup 1 --headline-only --option graphs=0 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python bench.py --steps 1 --warmup 1 --headline-only --option graphs=0 > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o pmc -- python bench.py --steps 1 --warmup 1 --headline-only --option graphs=0 > /dev/null 2> $OUT/pmc_mfma.err
 find $OUT -name "*.db" -delete
 ls -la $OUT $OUT/*/ | head -40
 tail -2 $OUT/bench.json
