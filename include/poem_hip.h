@@ -286,6 +286,13 @@ int poem_upsample2_concat_pad(const float* a, int ca, const float* b, int cb, fl
 int poem_conv3x3_down2(const float* in, const void* w_packed, const float* scale, const float* shift, const float* residual,
                        float* out, int views, int cin, int cout, int h, int w, int relu, int64_t out_view_stride,
                        int out_ch_stride, int out_row_stride, int out_offset, void* stream);
+/* feat_decode's tail in one launch (POEM.py:190-193: F.interpolate(x, scale_factor=2, mode="bilinear") followed by feat_in, a
+ * 1x1 convolution with bias): in (views,cin,h,w) -> out (views,cout,2h,2w).  The convolution is applied BEFORE the
+ * interpolation (they commute: both linear, the interpolation weights sum to one) on the matrix cores with the input and the
+ * low-resolution result in LDS.  w_packed: poem_pack_linear image of the (cout, cin) weight.  POEM_E_UNSUPPORTED unless
+ * h = w = 8, cin % 8 == 0, cout % 32 == 0, (cin + cout) * 256 B <= 160 KB: use poem_input_proj + poem_upsample2_concat_pad then. */
+int poem_conv1x1_upsample2(const float* in, const void* w_packed, const float* bias, float* out, int views, int cin, int cout,
+                           int h, int w, void* stream);
 /* One uv_decode stage in one launch (POEM.py:203-205: F.interpolate x2, torch.cat, ConvBlock): stride-1 conv3x3 of
  * [bilinear x2 of a_half (views,ca,h/2,w/2) | b_full (views,cb,h,w)] with the concatenation, the zero border and the
  * upsampling applied while the input halo is staged in LDS -- the concatenated tensor never exists.  Same epilogue and output

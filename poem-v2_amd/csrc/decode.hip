@@ -800,6 +800,80 @@ extern "C" hipError_t poem_launch_upcat_pad(const float* a, int Ca, const float*
   return hipGetLastError();
 }
 
+// feat_decode's tail (POEM.py:190-193 upstream: F.interpolate(x, scale_factor=2, bilinear) then feat_in, a 1x1 ConvBlock
+// without norm / activation) in one launch, for the 8 x 8 level of the HRNet pyramid: the 1x1 convolution commutes with the
+// interpolation (both linear, the interpolation weights sum to one, so the bias passes through), so a block takes one view,
+// stages its K x 64 input in LDS, runs the (C x K) . (K x 64) product on the fp32 matrix cores (wave = one 32-channel tile
+// x one 32-pixel tile; packed Linear weights as A, four chunks ahead), leaves the 8 x 8 result in LDS and writes its
+// bilinear x2 -- upcat_pad_kernel's expression -- as (C, 16, 16).  Round 3 before: conv1x1_kernel<1> (49 us, dependent
+// 4-byte operand loads from L2) + upcat_pad_kernel (35 us) with the 8 x 8 tensor through HBM.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv1x1_up2_kernel(const float* __restrict__ in, const float4* __restrict__ Wp,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int K,
+                                                             int C) {
+  constexpr int HW = 64, SIDE = 8;
+  extern __shared__ __attribute__((aligned(16))) float ftile[];    // K * 64 input, then C * 64 result
+  float* ytile = ftile + (size_t)K * HW;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int v = blockIdx.x, KC = K >> 3, ctiles = C / 32;
+  {
+    const float4* src = reinterpret_cast<const float4*>(in + (size_t)v * K * HW);
+    for (int i = tid; i < K * (HW / 4); i += NW * 64) reinterpret_cast<float4*>(ftile)[i] = src[i];
+  }
+  __syncthreads();
+  for (int job = wv; job < ctiles * 2; job += NW) {
+    const int ct = job >> 1, pt = job & 1;
+    const float4* wp = Wp + (size_t)ct * KC * 64 + lane;
+    const float* fb = ftile + (4 * h) * HW + pt * 32 + r;
+    f32x16 acc = zero16();
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = wp[(size_t)min(u, KC - 1) * 64];
+    for (int kc0 = 0; kc0 < KC; kc0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int kc = kc0 + u;
+        if (kc < KC) {
+          const float4 ac = a[u];
+          a[u] = wp[(size_t)min(kc + 4, KC - 1) * 64];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc = mfma32((&ac.x)[t], fb[(kc * 8 + t) * HW], acc);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = ct * 32 + mfma_row(i, h);
+      ytile[c * HW + pt * 32 + r] = acc[i] + (bias ? bias[c] : 0.f);
+    }
+  }
+  __syncthreads();
+  float* dst = out + (size_t)v * C * (4 * HW);
+  for (int i = tid; i < C * 4 * HW; i += NW * 64) {
+    const int c = i >> 8, y = (i >> 4) & 15, x = i & 15;
+    // F.interpolate(scale_factor=2, mode='bilinear', align_corners=False): src = (dst + 0.5) / 2 - 0.5, clamped at 0
+    const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, SIDE - 1), x1 = min(x0 + 1, SIDE - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* p = ytile + c * HW;
+    dst[i] = hy * (hx * p[y0 * SIDE + x0] + lx * p[y0 * SIDE + x1]) + ly * (hx * p[y1 * SIDE + x0] + lx * p[y1 * SIDE + x1]);
+  }
+}
+
+// in (views, K, 8, 8), packed Linear weights (C x K, pack_linear order), out (views, C, 16, 16)
+extern "C" hipError_t poem_launch_conv1x1_up2(const float* in, const void* wp, const float* bias, float* out, int views, int K,
+                                              int C, int h, int w, hipStream_t s) {
+  const size_t lds = (size_t)(K + C) * 64 * sizeof(float);
+  if (h != 8 || w != 8 || K % 8 || C % 32 || lds > 160 * 1024 || ((uintptr_t)in & 15)) return hipErrorNotSupported;
+  constexpr int NW = 10;
+  auto kern = conv1x1_up2_kernel<NW>;
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), 160 * 1024, optin); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)views), dim3(NW * 64), lds, s, in, (const float4*)wp, bias, out, K, C);
+  return hipGetLastError();
+}
+
 // x (views, C, H, W) -> 2x2 max-pool -> 1x1 conv (J x C, bias) -> sigmoid -> hmap (views, J, H/2, W/2).
 // One thread per pooled pixel; weights (J*C + J floats) staged in LDS.  C <= 64, J <= 32.
 __global__ __launch_bounds__(256) void pool_head_kernel(const float* __restrict__ x, const float* __restrict__ w,

@@ -242,6 +242,15 @@ int poem_upcat_conv3x3(const float* a_half, int ca, const float* b_full, int cb,
   return POEM_OK;
 }
 
+int poem_conv1x1_upsample2(const float* in, const void* w_packed, const float* bias, float* out, int views, int cin, int cout,
+                           int h, int w, void* stream) {
+  if (!in || !w_packed || !out || views <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return POEM_E_ARG;
+  const hipError_t e = poem_launch_conv1x1_up2(in, w_packed, bias, out, views, cin, cout, h, w, (hipStream_t)stream);
+  if (e == hipErrorNotSupported) return POEM_E_UNSUPPORTED;
+  HIPCHK(e);
+  return POEM_OK;
+}
+
 int poem_upsample2_concat_pad(const float* a, int ca, const float* b, int cb, float* out, int views, int h, int w, int pad,
                               void* stream) {
   if (!out || views <= 0 || ca < 0 || cb < 0 || ca + cb <= 0 || (ca && !a) || (cb && !b) || h <= 0 || w <= 0) return POEM_E_ARG;

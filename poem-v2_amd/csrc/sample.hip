@@ -128,16 +128,26 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __res
     f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = zero16();
-    float4 a = wp[0];
-    for (int kc = 0; kc < KC; ++kc) {
-      const float4 an = wp[(size_t)min(kc + 1, KC - 1) * 64];
+    // weight fragments four chunks ahead (a chunk is 16 MFMAs = 1024 cycles: less than a trip to HBM / Infinity Cache, which
+    // is where the first kernel of a forward finds them)
+    float4 a[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float* row = fb + (kc * 8 + t) * 128;
+    for (int u = 0; u < 4; ++u) a[u] = wp[(size_t)min(u, KC - 1) * 64];
+    for (int kc0 = 0; kc0 < KC; kc0 += 4) {
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) acc[pt] = mfma32((&a.x)[t], row[pt * 32], acc[pt]);
+      for (int u = 0; u < 4; ++u) {
+        const int kc = kc0 + u;
+        if (kc < KC) {
+          const float4 ac = a[u];
+          a[u] = wp[(size_t)min(kc + 4, KC - 1) * 64];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float* row = fb + (kc * 8 + t) * 128;
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[pt] = mfma32((&ac.x)[t], row[pt * 32], acc[pt]);
+          }
+        }
       }
-      a = an;
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {

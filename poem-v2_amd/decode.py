@@ -108,6 +108,7 @@ class FeatureDecoders:
             raise RuntimeError("FeatureDecoders runs on the MI355X HIP path only (no CPU fallback)")
         self.device = torch.device(device)
         self.fuse_upcat = [True, True, True]     # per uv_decode stage: poem_upcat_conv3x3 (one launch) vs upsample/concat + conv
+        self.fuse_feat_in = True                 # feat_in + bilinear x2 in one launch (poem_conv1x1_upsample2)
         sd = state_dict
         with torch.cuda.device(self.device):
             self.feat_delayer = [_Conv3x3(sd, f"feat_delayer.{i}", self.device) for i in range(3)]
@@ -174,11 +175,18 @@ class FeatureDecoders:
             # weights sum to one, so the bias passes through) -- applied at the low resolution it is a quarter of the FLOPs
             # and the (BN,320,16,16) intermediate never exists (POEM.py:190-193 upstream: interpolate, then feat_in)
             hw = r * r
-            y8 = torch.empty(views, self.feat_in_out, r, r, dtype=torch.float32, device=self.device)
-            hip.check(hip.lib().poem_input_proj(hip.ptr(x), self.feat_in_w.data_ptr(), hip.ptr(self.feat_in_b), None, None,
-                                                hip.ptr(y8), views, int(x.shape[1]), self.feat_in_out, hw, hip.stream()),
-                      "poem_input_proj")
-            y = upsample2_concat_pad(y8, None, 2 * r, 2 * r, 0)                  # (BN,160,16,16)
+            y = torch.empty(views, self.feat_in_out, 2 * r, 2 * r, dtype=torch.float32, device=self.device)
+            rc = hip.lib().poem_conv1x1_upsample2(hip.ptr(x), self.feat_in_w.data_ptr(), hip.ptr(self.feat_in_b), hip.ptr(y),
+                                                  views, int(x.shape[1]), self.feat_in_out, r, r, hip.stream()) \
+                if self.fuse_feat_in else hip.POEM_E_UNSUPPORTED
+            if rc == hip.POEM_E_UNSUPPORTED:                                     # other pyramid sizes: two launches
+                y8 = torch.empty(views, self.feat_in_out, r, r, dtype=torch.float32, device=self.device)
+                hip.check(hip.lib().poem_input_proj(hip.ptr(x), self.feat_in_w.data_ptr(), hip.ptr(self.feat_in_b), None, None,
+                                                    hip.ptr(y8), views, int(x.shape[1]), self.feat_in_out, hw, hip.stream()),
+                          "poem_input_proj")
+                y = upsample2_concat_pad(y8, None, 2 * r, 2 * r, 0)              # (BN,160,16,16)
+            else:
+                hip.check(rc, "poem_conv1x1_upsample2")
         return y
 
     def uv_decode(self, mlvl_feats):

@@ -80,6 +80,7 @@ SIGNATURES = {
     "poem_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp]),
     "poem_conv3x3_down2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp]),
     "poem_upsample2_concat_pad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "poem_conv1x1_upsample2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_upcat_conv3x3": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp]),
     "poem_pool_conv1x1_sigmoid": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_pa_epe": (_i, [_vp, _vp, _vp, _i, _i, _vp]),

@@ -109,6 +109,37 @@ def test_conv3x3_down2_operator(cin, cout, r):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,r", [(320, 160, 8), (64, 32, 8), (320, 160, 4)])
+def test_conv1x1_upsample2_operator(cin, cout, r):
+    """poem_conv1x1_upsample2 (feat_decode's tail in one launch: feat_in applied at the low resolution, result upsampled
+    from LDS) against the reference's order -- F.interpolate x2 THEN the 1x1 convolution, POEM.py:190-193 -- in fp64, and
+    against the two-launch sequence (poem_input_proj + poem_upsample2_concat_pad); a size it does not take says so."""
+    import torch.nn.functional as F
+    import poem_v2_amd as pk
+    from poem_v2_amd import hip
+    g = torch.Generator().manual_seed(cin + r)
+    views = 5
+    x = torch.randn(views, cin, r, r, generator=g)
+    w, b = torch.randn(cout, cin, generator=g) / cin ** 0.5, 0.1 * torch.randn(cout, generator=g)
+    up = F.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    ref = torch.einsum("oc,vchw->vohw", w.double(), up) + b.double()[None, :, None, None]
+    wp = hip.pack_linear(w.to(DEV))
+    y8 = torch.empty(views, cout, r, r, device=DEV)
+    hip.check(hip.lib().poem_input_proj(hip.ptr(x.to(DEV)), wp.data_ptr(), hip.ptr(b.to(DEV)), None, None, hip.ptr(y8), views, cin,
+                                        cout, r * r, hip.stream()), "poem_input_proj")
+    two = pk.decode.upsample2_concat_pad(y8, None, 2 * r, 2 * r, 0)
+    assert _md(two, ref) < 2e-5
+    one = torch.full((views, cout, 2 * r, 2 * r), float("nan"), device=DEV)
+    xd, bd = x.to(DEV), b.to(DEV)
+    rc = hip.lib().poem_conv1x1_upsample2(hip.ptr(xd), wp.data_ptr(), hip.ptr(bd), hip.ptr(one), views, cin, cout, r, r, hip.stream())
+    if r != 8:
+        assert rc == hip.POEM_E_UNSUPPORTED
+        return
+    hip.check(rc, "poem_conv1x1_upsample2")
+    assert _md(one, ref) < 2e-5 and _md(one, two) < 2e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ca,cb,cout,r", [(320, 160, 160, 16), (160, 80, 80, 32), (80, 40, 40, 64), (16, 8, 33, 16), (24, 16, 200, 16)])
 def test_upcat_conv3x3_matches_the_two_launch_sequence_and_torch(ca, cb, cout, r):
     """poem_upcat_conv3x3 (one uv_decode stage in one launch: bilinear x2 | concat | zero border staged straight into the
