@@ -263,7 +263,7 @@ class Engine:
 
     def profile_read_stage(self, stage):
         """(launches, total ms) of one timed span kind: 0 full vector attention, 1 anchored block-0 form, 2 sampling front
-        end (input_proj .. merge finalize), 3 query-side Linear / LayerNorm chain  (include/poem_hip.h POEM_PROF_*)."""
+        end (input_proj .. merge finalize)  (include/poem_hip.h POEM_PROF_*; other values read (0, 0))."""
         n, ms = _i(0), _f(0.0)
         check(lib().poem_profile_read_stage(self.handle, int(stage), ctypes.byref(n), ctypes.byref(ms)), "poem_profile_read_stage")
         return n.value, ms.value
