@@ -142,7 +142,10 @@ int poem_set_chains(poem_handle_t h, int enable);
  * does not exist; 0 = the operator sequence (poem_project_sample, poem_gemm x4, poem_merge_reduce / _finalize), same
  * results to fp32 round-off (the cross-view dot products reduce in another order); "chain_combine" (default 1, chain mode,
  * 4 heads): the chain kernel behind a cross attention merges the attention's split-key partials while it fills its tile
- * instead of a separate combine launch writing the context rows (bit-identical); "tables_first" (default 1): the fused
+ * instead of a separate combine launch writing the context rows (bit-identical); "xattn_merge" (default 0, fp32 mode, head
+ * dim 64, 4096 keys): the cross attention kernel merges its four split-key partials through LDS and writes the context rows
+ * itself -- no partials in HBM, "chain_combine" then has nothing to do (bit-identical; measured 0.5 % slower end to end,
+ * hence off); "tables_first" (default 1): the fused
  * sampling kernel is ordered behind the block-0 anchor-table build of the neighbour-search stream (a CU that hosts a table
  * block takes one sampling block instead of two; results unaffected).  Unknown names return POEM_E_ARG. */
 int poem_set_option(poem_handle_t h, const char* name, int value);
@@ -174,6 +177,11 @@ int poem_set_precision(poem_handle_t h, int mode);
 /* Operator level of the split panel GEMM: image (ceil(n/32)*32 * k * 4 bytes) and scales (ceil(n/32) floats, device) from
  * poem_pack_split_gemm; y = act(x w^T + bias) + residual as poem_gemm.  POEM_E_UNSUPPORTED for shapes the panel kernel
  * does not take (k % 16, n % 32, a 32-column panel beyond 128 KiB of LDS). */
+/* poem_cross_attention with the four split-key partials of a query tile merged inside the kernel (four waves of one block,
+ * through LDS, chunk order: the bits of poem_cross_attention) -- what poem_head_forward runs under "xattn_merge" = 1.
+ * POEM_E_UNSUPPORTED unless embed / heads == 64 and nk / 32 splits into four chunks of >= 8 key tiles (nk = 4096). */
+int poem_cross_attention_merged(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk, int embed,
+                                int heads, void* scratch, size_t scratch_bytes, void* stream);
 /* poem_cross_attention with both contractions as hi/lo f16 splits (head dims 32 and 64; POEM_E_UNSUPPORTED otherwise);
  * same arguments, scratch and partial/combine structure as poem_cross_attention. */
 int poem_cross_attention_split_f16x3(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk,

@@ -100,18 +100,24 @@ __device__ long long xattn_ph[8];
 #define XA_STAMP(k) do { } while (0)
 #endif
 
-template <int DH, int W>
+// MERGE (round 3; four key chunks, the head path's shape): the four chunks of a query tile run on four waves of ONE block at
+// the same time -- wave w = (group w / 4, chunk w % 4), a block's W groups take consecutive query tiles -- and the block
+// merges their partials through LDS (attn_combine_kernel's arithmetic, chunk order) and writes the normalised context rows:
+// the partials (4 x 26 MB written per launch at the headline batch and read back by the consumer) never reach HBM.  The waves
+// of a group read different K/V chunks, the W waves with the same chunk the same one (the tile barrier keeps them together).
+template <int DH, int W, bool MERGE = false>
 __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restrict__ q, int ldq, int qbr,
                                                            const float4* __restrict__ kimg,
                                                            const float4* __restrict__ vimg,
                                                            float4* __restrict__ part_o, float2* __restrict__ part_ml,
                                                            int B, int NQ, int NK, int C, int heads, int tpc, float kc2,
-                                                           float lazy_raw, int map, int prio_rot) {
+                                                           float lazy_raw, int map, int prio_rot, float* __restrict__ ctx) {
   constexpr int KC = DH / 8;               // K fragments (float4) per key tile
   constexpr int DT = (DH + 31) / 32;       // 32-channel tiles of the output
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int nqt = (NQ + 31) / 32, nkt = NK / 32, chunks = nkt / tpc;
-  const int items = B * heads * chunks * nqt;
+  const int items = MERGE ? B * heads * nqt : B * heads * chunks * nqt;      // MERGE: one item = a query tile, all four chunks
+  extern __shared__ __attribute__((aligned(16))) float xa_lds[];            // MERGE: 4W x (DT*4 x 64 float4 | 32 float2)
   // logical block id: blocks of one XCD (blockIdx % 8) take neighbouring item ranges -> one L2 serves a K/V chunk
   const int nb = gridDim.x;
   const int lb = (nb % 8 == 0) ? (int)(blockIdx.x % 8) * (nb / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
@@ -119,13 +125,13 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
   //        the SIMDs stay balanced to within one item) -- every wave of the CU streams the same K/V chunk at the same
   //        time: one HBM/L2 fetch serves them all.
   // map 0: each SIMD owns a contiguous range, dealt to its W waves.
-  const int sg = map ? lb : lb * 4 + (wv & 3), ng = map ? nb : nb * 4;
+  const int sg = (map || MERGE) ? lb : lb * 4 + (wv & 3), ng = (map || MERGE) ? nb : nb * 4;
   const int ibase = items / ng, irem = items % ng;
   const int lo = ibase * sg + min(sg, irem), hi = lo + ibase + (sg < irem ? 1 : 0);
-  const int first = map ? wv : (wv >> 2), stride = map ? 4 * W : W;
+  const int first = MERGE ? (wv >> 2) : (map ? wv : (wv >> 2)), stride = MERGE ? W : (map ? 4 * W : W);
   const __amdgpu_buffer_rsrc_t krs = frag_rsrc(kimg, 0xffffffffu), vrs = frag_rsrc(vimg, 0xffffffffu);
   const int loff = lane * 16;
-  const bool sync_tiles = map != 0 && prio_rot != 3;      // (prio_rot == 3: lab switch to turn the tile barrier off)
+  const bool sync_tiles = MERGE || (map != 0 && prio_rot != 3);      // (prio_rot == 3: lab switch to turn the tile barrier off)
 #ifdef POEM_LAB
   const long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
   int dbg_items = 0;
@@ -141,8 +147,8 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
 #endif
     const int qt = item % nqt;
     int t = item / nqt;
-    const int ch = t % chunks;
-    t /= chunks;
+    const int ch = MERGE ? (wv & 3) : t % chunks;
+    if (!MERGE) t /= chunks;
     const int head = t % heads, b = t / heads;
     const int qrow = min(qt * 32 + r, NQ - 1);
 
@@ -236,15 +242,59 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
       XA_STAMP(3);
     }
 
-    // partial (O, m, l): fragment order, one coalesced 1 KiB store per (channel tile, register group)
     l_run = half_sum(l_run);
-    float4* po = part_o + (size_t)item * (DT * 4) * 64 + lane;
+    if constexpr (MERGE) {
+      // ---- the four chunk partials of this wave's group meet in LDS (fragment order, as the HBM partials)
+      constexpr int WSTRIDE = DT * 4 * 64 * 4 + 64;          // floats per wave: O image | (m, l) of its 32 rows
+      float* mine = xa_lds + wv * WSTRIDE;
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+      for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        nt_store4(po + (d * 4 + g) * 64, make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]));
-    if (h == 0) part_ml[(size_t)item * 32 + r] = make_float2(m_ref, l_run);
+        for (int g = 0; g < 4; ++g)
+          reinterpret_cast<float4*>(mine)[(d * 4 + g) * 64 + lane] = make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]);
+      if (h == 0) reinterpret_cast<float2*>(mine + DT * 4 * 64 * 4)[r] = make_float2(m_ref, l_run);
+      __syncthreads();                        // every live wave is at the end of an item (all items have tpc tiles)
+      // ---- ctx[b, q, head*DH + c] = sum_s w_s O_s[c] / sum_s w_s l_s (attn_combine_kernel, chunk order); chunk-wave c of the
+      // group takes float4 groups c, c + 4, ... of the DT * 4
+      const float* grp = xa_lds + (wv & ~3) * WSTRIDE;
+      float w4[4], M = -INFINITY, den = 0.f;
+#pragma unroll
+      for (int sx = 0; sx < 4; ++sx) {
+        w4[sx] = reinterpret_cast<const float2*>(grp + sx * WSTRIDE + DT * 4 * 64 * 4)[r].x;
+        M = fmaxf(M, w4[sx]);
+      }
+#pragma unroll
+      for (int sx = 0; sx < 4; ++sx) {
+        const float lx = reinterpret_cast<const float2*>(grp + sx * WSTRIDE + DT * 4 * 64 * 4)[r].y;
+        w4[sx] = (w4[sx] == M) ? 1.0f : __builtin_amdgcn_exp2f((w4[sx] - M) * kc2);
+        den = fmaf(w4[sx], lx, den);
+      }
+      if (qt * 32 + r < NQ) {
+        float* out = ctx + ((size_t)b * NQ + qt * 32 + r) * C + head * DH;
+#pragma unroll
+        for (int k = (wv & 3); k < DT * 4; k += 4) {
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int sx = 0; sx < 4; ++sx) {
+            const float4 pp = reinterpret_cast<const float4*>(grp + sx * WSTRIDE)[k * 64 + lane];
+            acc.x = fmaf(w4[sx], pp.x, acc.x); acc.y = fmaf(w4[sx], pp.y, acc.y);
+            acc.z = fmaf(w4[sx], pp.z, acc.z); acc.w = fmaf(w4[sx], pp.w, acc.w);
+          }
+          const int d = k >> 2, g = k & 3;
+          *reinterpret_cast<float4*>(out + 32 * d + 8 * g + 4 * h) = make_float4(acc.x / den, acc.y / den, acc.z / den, acc.w / den);
+        }
+      }
+      // (the next item's tile barriers -- tpc >= 8, checked at launch -- order these reads before its LDS writes)
+    } else {
+      // partial (O, m, l): fragment order, one coalesced 1 KiB store per (channel tile, register group)
+      float4* po = part_o + (size_t)item * (DT * 4) * 64 + lane;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          nt_store4(po + (d * 4 + g) * 64, make_float4(o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]));
+      if (h == 0) part_ml[(size_t)item * 32 + r] = make_float2(m_ref, l_run);
+    }
     // drain the stores here: with stores possibly pending at the key loop's header hipcc cannot count on in-order
     // returns and waits for vmcnt(0) on every iteration, i.e. for the V prefetch it has just issued
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -665,7 +715,7 @@ extern "C" hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, 
   const int waves = B * heads * nqt;
 #define POEM_XATTN(D, WV)                                                                                         \
   hipLaunchKernelGGL((xattn_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, qbr, (const float4*)kimg,        \
-                     (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map, prio_rot); \
+                     (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map, prio_rot, (float*)nullptr); \
   if (ctx) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
 #define POEM_XSTREAM(D, WV)                                                                                        \
@@ -718,6 +768,33 @@ extern "C" hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, 
   return hipGetLastError();
 }
 
+// The same attention with the split-key partials merged inside the kernel (xattn_kernel MERGE): ctx is written directly, no
+// scratch.  hipErrorNotSupported for shapes other than head dim 64 with four key chunks of >= 8 tiles (the head path's
+// 4096 keys): the caller uses poem_launch_cross_attention_imgq then.  Same bits as partials + attn_combine_kernel.
+extern "C" int poem_cross_attention_merges(int NK, int C, int heads) {
+  if (heads <= 0 || C % heads || NK % 32) return 0;
+  const int dh = C / heads, tpc = attn_tiles_per_chunk(NK, dh);
+  return dh == 64 && (NK / 32) / tpc == 4 && tpc >= 8;
+}
+extern "C" hipError_t poem_launch_cross_attention_merged(const float* q, int ldq, int qbr, const void* kimg, const void* vimg,
+                                                         float* ctx, int B, int NQ, int NK, int C, int heads, hipStream_t s) {
+  if (!poem_cross_attention_merges(NK, C, heads) || !ctx) return hipErrorNotSupported;
+  if ((size_t)B * NK * C * 4 >= (1ull << 31)) return hipErrorInvalidValue;
+  constexpr int DH = 64, WV = 3, DT = 2;
+  const int tpc = attn_tiles_per_chunk(NK, DH), nqt = (NQ + 31) / 32;
+  const float kc2 = (float)(1.4426950408889634 / sqrt((double)DH));
+  const float lazy_raw = POEM_ATTN_LAZY_LOG2 / kc2;
+  const size_t lds = (size_t)4 * WV * (DT * 4 * 64 * 4 + 64) * sizeof(float);
+  auto kern = xattn_kernel<DH, WV, true>;
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin); e != hipSuccess) return e;
+  const long items = (long)B * heads * nqt;
+  const int grid = (int)std::min<long>(poem_attn_cus(), items);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WV), lds, s, q, ldq, qbr, (const float4*)kimg, (const float4*)vimg,
+                     (float4*)nullptr, (float2*)nullptr, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, 1, 0, ctx);
+  return hipGetLastError();
+}
+
 // row-major k, v (B*NK rows, ldkv) -> images in scratch -> kernel above
 extern "C" hipError_t poem_launch_cross_attention(const float* q, const float* k, const float* v, float* ctx, int B,
                                                   int NQ, int NK, int C, int heads, int ldkv, float* scratch,
@@ -730,4 +807,17 @@ extern "C" hipError_t poem_launch_cross_attention(const float* q, const float* k
   hipLaunchKernelGGL(attn_pack_k_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k, ldkv, C, kimg, total);
   hipLaunchKernelGGL(attn_pack_v_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, v, ldkv, C, vimg, total);
   return poem_launch_cross_attention_img(q, C, kimg, vimg, ctx, B, NQ, NK, C, heads, scratch, s);
+}
+
+// row-major k, v -> images in scratch -> the merged kernel (operator-level entry point of MERGE, for the tests)
+extern "C" hipError_t poem_launch_cross_attention_merged_rm(const float* q, const float* k, const float* v, float* ctx, int B,
+                                                            int NQ, int NK, int C, int heads, float* scratch, hipStream_t s) {
+  if (!poem_cross_attention_merges(NK, C, heads)) return hipErrorNotSupported;
+  const size_t part = poem_cross_attention_scratch_floats(B, NQ, NK, C, heads, 0);
+  float4* kimg = reinterpret_cast<float4*>(scratch + part);
+  float4* vimg = kimg + (size_t)B * NK * C / 4;
+  const long total = (long)B * NK * C / 4;
+  hipLaunchKernelGGL(attn_pack_k_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k, C, C, kimg, total);
+  hipLaunchKernelGGL(attn_pack_v_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, v, C, C, vimg, total);
+  return poem_launch_cross_attention_merged(q, C, NQ, kimg, vimg, ctx, B, NQ, NK, C, heads, s);
 }

@@ -183,14 +183,19 @@ struct DecoderRun {
       int pchunks = 0;
       float pkc2 = 0.f;
       poem_cross_attention_partials(B, Q, S, C, c.heads, p.attn_scratch, &part_o, &part_ml, &pchunks, &pkc2);
-      const bool comb = h->chain_combine && poem_chain_combines(C, c.heads, pchunks) != 0;
+      // the kernel merges the partials itself where it can (attn.hip MERGE); else the chain does while it fills its tile
+      const bool merged = h->xattn_merge && poem_cross_attention_merges(S, C, c.heads) != 0;
+      const bool comb = !merged && h->chain_combine && poem_chain_combines(C, c.heads, pchunks) != 0;
+      auto attention = [&](const float* q, int ldq, int qb, const float* kimg, const float* vimg) -> hipError_t {
+        if (merged) return poem_launch_cross_attention_merged(q, ldq, qb, kimg, vimg, p.ctx, B, Q, S, C, c.heads, s);
+        return poem_launch_cross_attention_imgq(q, ldq, qb, kimg, vimg, comb ? nullptr : p.ctx, B, Q, S, C, c.heads, p.attn_scratch, s);
+      };
       auto from_partials = [&](ChainArgs& a) {
         if (!comb) return;
         a.x = nullptr; a.part_o = (const float4*)part_o; a.part_ml = (const float2*)part_ml;
         a.pc_heads = c.heads; a.pc_chunks = pchunks; a.pc_nq = Q; a.pc_kc2 = pkc2;
       };
-      HIPCHK(poem_launch_cross_attention_imgq(q0, 2 * C, q_batch, p.y1[i], p.y1[i] + (size_t)BS * C, comb ? nullptr : p.ctx, B, Q, S,
-                                              C, c.heads, p.attn_scratch, s));
+      HIPCHK(attention(q0, 2 * C, q_batch, p.y1[i], p.y1[i] + (size_t)BS * C));
       ChainArgs ca = chain_args(0);
       ca.x = p.ctx; ca.ldx = C;
       from_partials(ca);
@@ -198,8 +203,7 @@ struct DecoderRun {
       ca.ln_g = h->R(a1 + 8); ca.ln_b = h->R(a1 + 9); ca.y1 = p.h_attn; ca.ldy1 = C;
       ca.w2 = (const float4*)h->P(a2 + 0); ca.b2 = h->R(a2 + 1); ca.n2 = 1; ca.y2 = p.qp; ca.ldy2 = C;
       HIPCHK(poem_launch_chain(&ca, C, s));
-      HIPCHK(poem_launch_cross_attention_imgq(p.qp, C, Q, p.y1[i] + (size_t)2 * BS * C, p.y1[i] + (size_t)3 * BS * C,
-                                              comb ? nullptr : p.ctx, B, Q, S, C, c.heads, p.attn_scratch, s));
+      HIPCHK(attention(p.qp, C, Q, p.y1[i] + (size_t)2 * BS * C, p.y1[i] + (size_t)3 * BS * C));
       ChainArgs cb = chain_args(0);
       cb.x = p.ctx; cb.ldx = C;
       from_partials(cb);
@@ -227,8 +231,12 @@ struct DecoderRun {
       }
       if (ov && a == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
       if (h->precision == POEM_PRECISION_SPLIT_F16X3_ALL) poem_cross_attention_split(h->kv_presplit[i] ? 2 : 1);
-      HIPCHK(poem_launch_cross_attention_img(qptr, ldq, p.y1[i] + (size_t)(2 * a) * BS * C, p.y1[i] + (size_t)(2 * a + 1) * BS * C,
-                                             p.ctx, B, Q, S, C, c.heads, p.attn_scratch, s));
+      if (h->precision == POEM_PRECISION_FP32 && h->xattn_merge && poem_cross_attention_merges(S, C, c.heads))
+        HIPCHK(poem_launch_cross_attention_merged(qptr, ldq, Q, p.y1[i] + (size_t)(2 * a) * BS * C, p.y1[i] + (size_t)(2 * a + 1) * BS * C,
+                                                  p.ctx, B, Q, S, C, c.heads, s));
+      else
+        HIPCHK(poem_launch_cross_attention_img(qptr, ldq, p.y1[i] + (size_t)(2 * a) * BS * C, p.y1[i] + (size_t)(2 * a + 1) * BS * C,
+                                               p.ctx, B, Q, S, C, c.heads, p.attn_scratch, s));
       const int rc = gemm(p.ctx, C, ab + 6, ab + 7, hidden, ldh, p.att, C, BQ, C, C, POEM_ACT_NONE);
       if (rc != POEM_OK) return rc;
       HIPCHK(poem_launch_layernorm(p.att, h->R(ab + 8), h->R(ab + 9), hout, BQ, C, c.ln_eps, s));

@@ -126,6 +126,11 @@ struct poem_handle_s {
   bool fused_sampling = true;
   bool tables_first = true;    // the fused sampling kernel starts behind the anchor-table build (see poem_head_forward)
   bool chain_combine = true;   // chain kind A combines the cross attention's split-key partials itself (no attn_combine launch)
+  // the cross attention merges its four split-key partials inside the kernel and writes the context rows itself (attn.hip
+  // xattn_kernel MERGE; fp32 mode, head dim 64, 4096 keys): no partials in HBM, chain kind A fills its tile from ctx.
+  // Bit-identical; default OFF: measured 0.5 % slower end to end (the attention +27 us per launch -- four K/V chunk
+  // streams per CU instead of one overflow the 32 KB L1 -- against -12 us per chain launch; LABNOTES R3.5)
+  bool xattn_merge = false;
   bool knn_early = true;     // chain mode: issue block i+1's neighbour searches right behind block i's coordinate update
   // hipGraph replay of the step's launch list (everything between the four kernels that read the caller's inputs and the
   // one that writes the caller's output touches workspace / handle memory only): captured once per (batch, view layout,

@@ -165,7 +165,7 @@ struct HeadRun {
     if (!h->graphs || h->graph_broken || !fused_fe || h->prof_on || h->tables_pending || !h->cap_stream) return 0;
     std::vector<int64_t> key = {B, BN, img_w, img_h, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
                                 h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
-                                h->tables_cached, h->knn_fma, h->taps, c.parametric};
+                                h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge};
     key.insert(key.end(), offs_host, offs_host + B + 1);
     poem_handle_s::GraphEntry* hit = nullptr;
     for (auto& g : h->graph_cache)

@@ -69,6 +69,11 @@ hipError_t poem_launch_pack_split_tiles(const float* w, int N, int K, void* img,
 void poem_gemm_split_context(const void* packed, size_t bytes, const void* split, const float* scales);
 void poem_gemm_split_explicit(const void* img, const float* scales);
 void poem_cross_attention_split(int on);
+int poem_cross_attention_merges(int NK, int C, int heads);
+hipError_t poem_launch_cross_attention_merged_rm(const float* q, const float* k, const float* v, float* ctx, int B, int NQ, int NK,
+                                                 int C, int heads, float* scratch, hipStream_t s);
+hipError_t poem_launch_cross_attention_merged(const float* q, int ldq, int q_batch_rows, const void* kimg, const void* vimg, float* ctx,
+                                              int B, int NQ, int NK, int C, int heads, hipStream_t s);
 int poem_gemm_split_applies(const void* Wp, int M, int ldx, int K);
 void poem_gemm_split_images(int on);
 hipError_t poem_launch_vector_attention_split(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,

@@ -100,6 +100,17 @@ int poem_cross_attention(const float* q, const float* k, const float* v, float* 
   return POEM_OK;
 }
 
+int poem_cross_attention_merged(const float* q, const float* k, const float* v, float* ctx, int batch, int nq, int nk, int embed,
+                                int heads, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!q || !k || !v || !ctx || batch <= 0 || nq <= 0 || nk % 32 || heads <= 0 || embed % heads) return POEM_E_ARG;
+  const size_t need = poem_cross_attention_scratch_bytes(batch, nq, nk, embed, heads);
+  if (need && (!scratch || scratch_bytes < need || ((uintptr_t)scratch & 15))) return POEM_E_WORKSPACE;
+  const hipError_t e = poem_launch_cross_attention_merged_rm(q, k, v, ctx, batch, nq, nk, embed, heads, (float*)scratch, (hipStream_t)stream);
+  if (e == hipErrorNotSupported) return POEM_E_UNSUPPORTED;
+  HIPCHK(e);
+  return POEM_OK;
+}
+
 int poem_pack_split_gemm(const float* w, int out_features, int in_features, void* image, float* scales, void* stream) {
   if (!w || !image || !scales || out_features <= 0 || in_features <= 0 || in_features % 16) return POEM_E_ARG;
   HIPCHK(poem_launch_pack_split_tiles(w, out_features, in_features, image, scales, 1, (hipStream_t)stream));

@@ -72,6 +72,7 @@ SIGNATURES = {
     "poem_merge_finalize": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "poem_cross_attention_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "poem_cross_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "poem_cross_attention_merged": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "poem_cross_attention_split_f16x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "poem_triangulate_dlt": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "poem_heatmap_uv": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
@@ -373,12 +374,12 @@ def layernorm(x, g, b, eps):
     return y
 
 
-def cross_attention(q, k, v, heads, split=False):
+def cross_attention(q, k, v, heads, split=False, merged=False):
     B, NQ, C = q.shape
     ctx = torch.empty_like(q)
     need = lib().poem_cross_attention_scratch_bytes(B, NQ, k.shape[1], C, heads)
     scratch = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
-    fn = lib().poem_cross_attention_split_f16x3 if split else lib().poem_cross_attention
+    fn = lib().poem_cross_attention_split_f16x3 if split else (lib().poem_cross_attention_merged if merged else lib().poem_cross_attention)
     check(fn(ptr(q), ptr(k), ptr(v), ptr(ctx), B, NQ, k.shape[1], C, heads, scratch.data_ptr(), need, stream()),
           "poem_cross_attention")
     return ctx

@@ -109,7 +109,7 @@ def test_conv3x3_down2_operator(cin, cout, r):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cin,cout,r", [(320, 160, 8), (64, 32, 8), (320, 160, 4)])
+@pytest.mark.parametrize("cin,cout,r", [(320, 160, 8), (64, 32, 8), (40, 32, 16)])
 def test_conv1x1_upsample2_operator(cin, cout, r):
     """poem_conv1x1_upsample2 (feat_decode's tail in one launch: feat_in applied at the low resolution, result upsampled
     from LDS) against the reference's order -- F.interpolate x2 THEN the 1x1 convolution, POEM.py:190-193 -- in fp64, and

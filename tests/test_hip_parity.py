@@ -126,6 +126,29 @@ def test_cross_attention_split_needs_head_dim_32_or_64():
         hip.cross_attention(q, k, k, 4, split=True)            # head dim 128: exact kernels only
 
 
+@pytest.mark.parametrize("B,NQ", [(1, 799), (3, 799), (2, 40), (5, 97)])
+def test_cross_attention_merged_in_kernel_equals_partials_and_combine(B, NQ):
+    """attn.hip xattn_kernel MERGE (option "xattn_merge"): the four key chunks of a query tile on four waves of one block,
+    merged through LDS -- against the partials-in-HBM + attn_combine form BIT for bit (same merge arithmetic, chunk order),
+    at the head's shape (4096 keys, head dim 64), several batch sizes / query counts incl. a partial last query tile and
+    blocks whose wave groups run out of items at different times; a spiked late key exercises the lazy stabiliser; shapes
+    the merged kernel does not take say so."""
+    g = torch.Generator().manual_seed(B * 1000 + NQ)
+    NK, C, heads = 4096, 256, 4
+    q, k, v = (torch.randn(B, n, C, generator=g) for n in (NQ, NK, NK))
+    k[0, 3000] = q[0, 5] * 4
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    a = hip.cross_attention(qd, kd, vd, heads)
+    b = hip.cross_attention(qd, kd, vd, heads, merged=True)
+    assert torch.equal(a, b)
+    dh = C // heads
+    sp = lambda t: t.double().view(B, -1, heads, dh).permute(0, 2, 1, 3)   # noqa: E731
+    ref = (torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(dh), -1) @ sp(v)).permute(0, 2, 1, 3).reshape(B, NQ, C)
+    assert _md(b, ref) < 2e-5
+    with pytest.raises(RuntimeError):
+        hip.cross_attention(qd, kd[:, :1024].contiguous(), vd[:, :1024].contiguous(), heads, merged=True)   # one chunk: not taken
+
+
 def test_cross_attention_spiked_key_forces_rescale():
     # one key dominates late in the sequence: the running max jumps -> alpha-rescale branch must be right
     g = torch.Generator().manual_seed(9)
@@ -848,7 +871,10 @@ def test_full_size_batch_properties():
     eng = head._engine
     # ... and the hipGraph replay of the launch list against plain launches (first call of a layout captures, later calls replay)
     for name, val in (("chain_tile", 1), ("chain_tile", 2), ("chain_tile", 3), ("chain_tile", 0), ("tables_cached", 0), ("tables_cached", 1),
-                      ("graphs", 0), ("graphs", 1), ("graphs", 1)):
+                      ("graphs", 0), ("graphs", 1), ("graphs", 1),
+                      # the cross attention's split-key partials merged by the chain kernel that consumes them (default), by a
+                      # combine launch, inside the attention kernel: the same merge arithmetic in chunk order, three places
+                      ("chain_combine", 0), ("xattn_merge", 1), ("xattn_merge", 0), ("chain_combine", 1)):
         eng.set_option(name, val)
         with torch.no_grad():
             again = head(feat, metas, rj)["all_coords_preds"]
