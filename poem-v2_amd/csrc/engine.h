@@ -31,6 +31,14 @@ extern thread_local int g_last_hip_error;      // handle.cpp
     }                                                \
   } while (0)
 
+// POEM_TRACE=<file> in the environment: one line per phase of a forward appended to that file (diagnosis of crashes inside
+// the HIP runtime on boxes without a debugger; a file because test runners capture stderr); read once.
+static inline FILE* poem_trace_file() {
+  static FILE* f = getenv("POEM_TRACE") ? fopen(getenv("POEM_TRACE"), "a") : nullptr;
+  return f;
+}
+#define POEM_TRACE(...) do { if (FILE* tf_ = poem_trace_file()) { fprintf(tf_, __VA_ARGS__); fputc('\n', tf_); fflush(tf_); } } while (0)
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline size_t packed_bytes_linear(int N, int K) { return (size_t)((N + 31) / 32) * (size_t)(K / 8) * 64 * 16; }
 
@@ -207,6 +215,8 @@ struct Plan {
 
 Plan make_plan(const poem_config_t& c, int B, int BN, void* base);
 void register_taps(poem_handle_t h, const Plan& p, int B, int BN, bool sampling);
+
+void poem_park_graph_exec(hipGraphExec_t e);      // handle.cpp: an evicted exec is parked, not destroyed (runtime bug, see there)
 
 // ---- launch sequence (decoder.cpp) -------------------------------------------------------------------------------------------
 int build_anchor_tables(poem_handle_t h, Plan& p, hipStream_t s, bool at_create = false);

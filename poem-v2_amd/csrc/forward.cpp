@@ -173,14 +173,19 @@ struct HeadRun {
     if (!hit) {
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
+      POEM_TRACE("capture begin h=%p B=%d cached=%zu", (void*)h, B, h->graph_cache.size());
       bool ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
       if (ok) {
         const int rc = body(h->cap_stream, p.g_pose, p.g_betas);
+        POEM_TRACE("capture body rc=%d", rc);
         const hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
+        POEM_TRACE("capture end e=%d graph=%p", (int)e, (void*)graph);
         ok = rc == POEM_OK && e == hipSuccess && graph != nullptr;
       }
       if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      POEM_TRACE("instantiate ok=%d exec=%p", (int)ok, (void*)exec);
       if (graph) (void)hipGraphDestroy(graph);
+      POEM_TRACE("graph destroyed");
       if (!ok) {
         (void)hipGetLastError();
         h->graph_broken = true;               // plain launches from now on (results are the same either way)
@@ -190,14 +195,16 @@ struct HeadRun {
         size_t lru = 0;
         for (size_t i = 1; i < h->graph_cache.size(); ++i)
           if (h->graph_cache[i].stamp < h->graph_cache[lru].stamp) lru = i;
-        (void)hipGraphExecDestroy(h->graph_cache[lru].exec);
+        poem_park_graph_exec(h->graph_cache[lru].exec);      // (not destroyed: handle.cpp, capture kits)
         h->graph_cache.erase(h->graph_cache.begin() + lru);
       }
       h->graph_cache.push_back({key, exec, 0});
       hit = &h->graph_cache.back();
     }
     hit->stamp = ++h->graph_clock;
+    POEM_TRACE("graph launch exec=%p", (void*)hit->exec);
     HIPCHK(hipGraphLaunch(hit->exec, s));
+    POEM_TRACE("graph launched");
     if (c.parametric) {      // the captured tail wrote pose / shape into the workspace
       HIPCHK(hipMemcpyAsync(pose_aa, p.g_pose, (size_t)B * 48 * sizeof(float), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(betas, p.g_betas, (size_t)B * 10 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -224,15 +231,19 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   SplitContext split_ctx(h);
   HeadRun run(h, mlvl_feat, cam_intr, cam_extr, view_offsets_host, batch, reference_joints, img_w, img_h, workspace, (hipStream_t)stream);
   if (workspace_bytes < run.p.bytes) return POEM_E_WORKSPACE;
+  POEM_TRACE("head_forward h=%p B=%d C=%d", (void*)h, batch, c.embed);
   int rc = run.view_layout();
   if (rc == POEM_OK) rc = run.anchor_tables();
   if (rc == POEM_OK) rc = run.inputs();
+  POEM_TRACE("inputs rc=%d", rc);
   if (rc != POEM_OK) return rc;
   rc = run.replay(workspace, pose_aa, betas);
+  POEM_TRACE("replay rc=%d", rc);
   if (rc < 0) return rc;
   if (rc == 0 && (rc = run.body(run.s, pose_aa, betas)) != POEM_OK) return rc;
   HIPCHK(poem_launch_finalize(run.p.xyz[1], run.p.centre, out_xyz, c.nblocks, batch, c.nquery, c.radius, run.s));
   register_taps(h, run.p, batch, run.BN, true);
+  POEM_TRACE("head_forward done");
   return POEM_OK;
 }
 

@@ -4,47 +4,89 @@
 
 thread_local int g_last_hip_error = 0;
 
-// The capture stream and the two side streams of a handle come from a process-wide pool per device and go back to it at
-// poem_destroy instead of being destroyed: on ROCm 7.0's runtime, destroying streams that took part in a stream capture
-// AND the graph exec instantiated from it makes a LATER handle's hipGraphLaunch crash inside libamdhip64 (reproduced with
-// five handle life cycles in one process, tools/parity_report.py; either destruction alone is harmless).  A handle's
-// streams are idle when it is destroyed, so the next handle can take them over as they are.
+// Everything of a handle that takes part in a stream capture -- the capture stream, the two side streams, the fork / join
+// events -- comes from a process-wide pool per device ("capture kit") and goes back to it at poem_destroy instead of being
+// destroyed, and the graph execs of a destroyed handle are parked, not destroyed: on ROCm 7.0's runtime hipGraphLaunch of a
+// LATER, freshly instantiated exec crashes inside libamdhip64 (SIGSEGV, host side) after earlier handles' capture objects
+// were destroyed.  Observed: with streams destroyed after five handle life cycles (round 3, first session: streams pooled
+// since); with streams pooled but events and execs destroyed, in the 204-test GPU suite right after Python's collector
+// released ten heads at once (POEM_TRACE: the second capture of the next head instantiates, its launch crashes) --
+// reproducible on a box whose MIOpen cache is warm, never with one handle at a time (tools/lab/lifecycle_probe.py, 120
+// cycles).  A kit's objects are idle when its handle is destroyed, so the next handle takes them over as they are.  Parked
+// execs cost their host-side node copies (41 kernel nodes each, at most GRAPH_CAP per handle) until the process ends.
 #include <mutex>
 namespace {
-struct StreamSet { hipStream_t cap, bps, knn; };
+struct CaptureKit {
+  hipStream_t cap = nullptr, bps = nullptr, knn = nullptr;
+  hipEvent_t ev[5 + 24] = {};
+};
 std::mutex g_pool_mutex;
-std::map<int, std::vector<StreamSet>> g_stream_pool;       // device id -> idle sets
+std::map<int, std::vector<CaptureKit>> g_kit_pool;         // device id -> idle kits
+std::vector<hipGraphExec_t> g_parked_execs;                // never destroyed (see above)
 
-bool take_streams(poem_handle_t h) {
+hipEvent_t** kit_event_slots(poem_handle_t h, hipEvent_t** out) {
+  int n = 0;
+  out[n++] = &h->ev_fork; out[n++] = &h->ev_join_bps; out[n++] = &h->ev_join_knn; out[n++] = &h->ev_tab; out[n++] = &h->ev_fork0;
+  for (int i = 0; i < 8; ++i) { out[n++] = &h->ev_bps[i]; out[n++] = &h->ev_xyz[i]; out[n++] = &h->ev_knn[i]; }
+  return out;
+}
+
+bool take_kit(poem_handle_t h) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   h->stream_device = dev;
+  hipEvent_t* slots[5 + 24];
+  kit_event_slots(h, slots);
   {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
-    auto& pool = g_stream_pool[dev];
+    auto& pool = g_kit_pool[dev];
     if (!pool.empty()) {
-      h->cap_stream = pool.back().cap; h->bps_stream = pool.back().bps; h->knn_stream = pool.back().knn;
+      const CaptureKit k = pool.back();
       pool.pop_back();
+      h->cap_stream = k.cap; h->bps_stream = k.bps; h->knn_stream = k.knn;
+      for (int i = 0; i < 5 + 24; ++i) *slots[i] = k.ev[i];
       return true;
     }
   }
-  return hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
-         hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess &&
-         hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
+  bool ok = hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 5 + 24; ++i) ok = ok && hipEventCreateWithFlags(slots[i], hipEventDisableTiming) == hipSuccess;
+  return ok;
 }
 
-void return_streams(poem_handle_t h) {
-  if (!h->cap_stream || !h->bps_stream || !h->knn_stream) {     // a partly created set: nothing was captured on it
+void return_kit(poem_handle_t h) {
+  hipEvent_t* slots[5 + 24];
+  kit_event_slots(h, slots);
+  bool whole = h->cap_stream && h->bps_stream && h->knn_stream;
+  for (int i = 0; i < 5 + 24; ++i) whole = whole && *slots[i] != nullptr;
+  if (!whole) {                             // a partly created kit: nothing was captured on it
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->bps_stream) (void)hipStreamDestroy(h->bps_stream);
     if (h->knn_stream) (void)hipStreamDestroy(h->knn_stream);
+    for (int i = 0; i < 5 + 24; ++i) if (*slots[i]) (void)hipEventDestroy(*slots[i]);
   } else {
+    CaptureKit k;
+    k.cap = h->cap_stream; k.bps = h->bps_stream; k.knn = h->knn_stream;
+    for (int i = 0; i < 5 + 24; ++i) k.ev[i] = *slots[i];
     std::lock_guard<std::mutex> lock(g_pool_mutex);
-    g_stream_pool[h->stream_device].push_back({h->cap_stream, h->bps_stream, h->knn_stream});
+    g_kit_pool[h->stream_device].push_back(k);
   }
   h->cap_stream = h->bps_stream = h->knn_stream = nullptr;
+  for (int i = 0; i < 5 + 24; ++i) *slots[i] = nullptr;
+}
+
+void park_execs(poem_handle_t h) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  for (auto& g : h->graph_cache) g_parked_execs.push_back(g.exec);
+  h->graph_cache.clear();
 }
 }  // namespace
+
+void poem_park_graph_exec(hipGraphExec_t e) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  g_parked_execs.push_back(e);
+}
 
 std::vector<TensorSpec> tensor_table(const poem_config_t& c) {
   const int C = c.embed, Q = c.nquery;
@@ -316,11 +358,7 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
                      stream);
   if (rc != POEM_OK) { poem_destroy(h); return rc; }
   {
-    bool ok = take_streams(h);
-    auto mk = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
-    mk(&h->ev_fork); mk(&h->ev_join_bps); mk(&h->ev_join_knn); mk(&h->ev_tab); mk(&h->ev_fork0);
-    for (int i = 0; i < 8; ++i) { mk(&h->ev_bps[i]); mk(&h->ev_xyz[i]); mk(&h->ev_knn[i]); }
-    if (!ok) { poem_destroy(h); return POEM_E_LAUNCH; }
+    if (!take_kit(h)) { poem_destroy(h); return POEM_E_LAUNCH; }
   }
   {   // block-0 anchor tables (see poem_handle_s::tables_cached): handle-owned, built here once
     const size_t tf = poem_vector_attention_table_floats(cfg->nquery, C);
@@ -344,16 +382,14 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
 
 void poem_destroy(poem_handle_t h) {
   if (!h) return;
+  POEM_TRACE("destroy h=%p graphs=%zu", (void*)h, h->graph_cache.size());
   for (auto e : h->prof_ev) (void)hipEventDestroy(e);
-  auto de = [](hipEvent_t e) { if (e) (void)hipEventDestroy(e); };
-  de(h->ev_fork); de(h->ev_join_bps); de(h->ev_join_knn); de(h->ev_tab); de(h->ev_fork0);
-  for (int i = 0; i < 8; ++i) { de(h->ev_bps[i]); de(h->ev_xyz[i]); de(h->ev_knn[i]); }
   if (h->tab_mem) (void)hipFree(h->tab_mem);
   if (h->split_mem) (void)hipFree(h->split_mem);
   if (h->gemm_split) (void)hipFree(h->gemm_split);
   if (h->gemm_scales) (void)hipFree(h->gemm_scales);
-  for (auto& g : h->graph_cache) (void)hipGraphExecDestroy(g.exec);
-  return_streams(h);
+  park_execs(h);
+  return_kit(h);
   delete h;
 }
 

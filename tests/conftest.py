@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """POEM_NATIVE_BT=<path of tools/lab/segv_bt.so>: native backtrace on SIGSEGV / SIGABRT (there is no gdb on the GPU
+    boxes; Python's faulthandler, which pytest enables, shows the Python frames only).  Loaded here -- after pytest's own
+    faulthandler -- so that its handlers are the ones in place while the tests run."""
+    so = os.environ.get("POEM_NATIVE_BT")
+    if so:
+        import ctypes
+        ctypes.CDLL(so)
+
+
 def pytest_collection_modifyitems(config, items):
     """``pytest tests`` on a box without a GPU skips the ``gpu``-marked tests instead of failing in them."""
     import torch
