@@ -172,6 +172,17 @@ def test_knn_matches_oracle(NQ, NS):
     assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("B,NQ,NS", [(300, 40, 64), (1, 5, 4096), (7, 799, 130)])
+def test_knn_block_shapes(B, NQ, NS):
+    """knn.hip sizes its blocks to the batch (one block per CU over the batch, a block = a query range of one sample, waves
+    pull queries from an LDS counter): more samples than CUs (one block per sample), fewer queries than waves, a source
+    count that is no multiple of the 128-candidate step."""
+    g = torch.Generator().manual_seed(B + NQ + NS)
+    qx = torch.rand(B, NQ, 3, generator=g) * 2 - 1
+    sx = torch.rand(B, NS, 3, generator=g) * 2 - 1
+    assert torch.equal(hip.knn(qx.to(DEV), sx.to(DEV)).cpu().long(), po.knn_indices(qx, sx, 32))
+
+
 @pytest.mark.parametrize("NS,mode", [(4096, "same"), (4096, "grid"), (799, "grid"), (1024, "cluster"), (4096, "cluster"),
                                      (300, "nan")])
 def test_knn_selection_paths(NS, mode):
