@@ -1,5 +1,16 @@
-# final un-profiled numbers of the round: the full default bench line + five short runs on one box
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout 900 python bench.py 2> gpurun_out/bench_unprofiled.err | tail -1 > gpurun_out/bench_unprofiled.json
-for i in 1 2 3 4 5; do timeout 300 python bench.py --cpu-samples 0 --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['value'],1), round(d['ms_per_step'],3), round(r['avg_launch_ms'],4), round(r['frac'],4), round(r['anchored_block0']['avg_launch_ms'],4), round(d['pyramid_scope']['value'],1))"; done | tee gpurun_out/bench_runs.txt
-cut -c1-300 gpurun_out/bench_unprofiled.json
+#!/bin/bash
+# final numbers of a round: the driver's bench invocation unprofiled (wall time recorded) + a kernel timeline of one step
+set -u
+TAG=${1:-r03}
+OUT=gpurun_out/final_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+T0=$(date +%s)
+python bench.py > $OUT/bench_unprofiled.json 2> $OUT/bench.err
+echo "bench wall $(( $(date +%s) - T0 )) s" | tee $OUT/wall.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python bench.py --headline-only > /dev/null 2> $OUT/trace.err
+T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
+python tools/step_timeline.py $T 9 > $OUT/timeline_B32.txt 2>> $OUT/trace.err
+rm -rf $OUT/trace
+head -24 $OUT/timeline_B32.txt
+tail -c 600 $OUT/bench_unprofiled.json
