@@ -114,10 +114,22 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __res
   const int v = blockIdx.x / pgroups, pg = blockIdx.x % pgroups;
   const int KC = K >> 3, ctiles = C / 32;
   {
+    // all of a thread's loads in flight before the first LDS store (a load-store loop waited for every load in turn: ten
+    // trips to HBM in a row at the head of every forward)
     const float* src = feat + (size_t)v * K * hw + pg * 128;
-    for (int i = tid; i < K * 32; i += NW * 64) {
-      const int k = i >> 5, c4 = i & 31;
-      reinterpret_cast<float4*>(ftile)[i] = *reinterpret_cast<const float4*>(src + (size_t)k * hw + 4 * c4);
+    constexpr int STG = 6;
+    for (int i0 = tid; i0 < K * 32; i0 += STG * NW * 64) {
+      float4 buf[STG];
+#pragma unroll
+      for (int u = 0; u < STG; ++u) {
+        const int i = min(i0 + u * NW * 64, K * 32 - 1);
+        buf[u] = *reinterpret_cast<const float4*>(src + (size_t)(i >> 5) * hw + 4 * (i & 31));
+      }
+#pragma unroll
+      for (int u = 0; u < STG; ++u) {
+        const int i = i0 + u * NW * 64;
+        if (i < K * 32) reinterpret_cast<float4*>(ftile)[i] = buf[u];
+      }
     }
   }
   __syncthreads();
