@@ -133,6 +133,76 @@ def time_leg(head, batches, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def draw_views(rule, B, rng, lo=2, hi=10):
+    """Views per sample of one batch as the reference's data pipeline draws them: ``gauss`` = int(round(gauss(4, 2))) clipped
+    to the view range (lib/data_wds/multiview_wds.py:86-95 upstream, random_n_views); ``uniform`` = U{lo..hi}."""
+    if rule == "gauss":
+        return [int(min(max(lo, int(round(rng.gauss(4, 2)))), hi)) for _ in range(B)]
+    return [rng.randint(lo, hi) for _ in range(B)]
+
+
+def make_stream(B, rule, n_layouts, dev, seed=0, lo=2, hi=10):
+    """``n_layouts`` batches of B samples whose VIEW LAYOUT differs from batch to batch (what collation_random_n_views hands the
+    head every step, lib/utils/collation.py:7-25 upstream), all resident on the device: features are prefixes of one resident
+    pool of B * hi views, the cameras of every layout are uploaded up front.  -> [(mlvl_feat, img_metas, reference_joints)]"""
+    import random
+    rng = random.Random(1000 + seed)
+    g = torch.Generator().manual_seed(4000 + seed)
+    pool = torch.randn(B * hi, 160, 16, 16, generator=g).to(dev)
+    rj = (torch.tensor([0.0, 0.0, 0.6]) + 0.03 * torch.randn(B, 21, 3, generator=g)).to(dev)
+    K = torch.tensor([[300.0, 0, 128.0], [0, 300.0, 128.0], [0, 0, 1]])
+    items, prev = [], None
+    while len(items) < n_layouts:
+        views = draw_views(rule, B, rng, lo, hi)
+        if views == prev and hi > lo:      # every batch differs from the one before it (small batches cannot all be distinct)
+            continue
+        prev = views
+        bn = sum(views)
+        extr = torch.cat([pk.inputs.ring_extrinsics(n, ring=max(8, hi), jitter=0.05 * torch.randn(n, generator=g)) for n in views], 0)
+        metas = {"inp_img_shape": (256, 256), "cam_intr": K[None].repeat(bn, 1, 1).contiguous().to(dev),
+                 "cam_extr": extr.contiguous().to(dev), "master_id": [0] * B, "cam_view_num": np.asarray(views, dtype=np.int64)}
+        items.append((pool[:bn], metas, rj))
+    return items
+
+
+def time_stream(head, items, steps, warmup, start=0):
+    """Mean seconds per forward of ``head`` walking through ``items`` (a new item every forward)."""
+    with torch.no_grad():
+        for i in range(warmup):
+            head(*items[(start + i) % len(items)])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            head(*items[(start + warmup + i) % len(items)])
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def fresh_layout_scope(head, dev, B, rule, steps, warmup=6):
+    """A stream of batches with a FRESH view layout every forward against the same head replaying ONE layout (the batch of the
+    stream whose view total is closest to the stream's mean): the launch graph is keyed by the batch size, not by the layout
+    (csrc/forward.cpp), so the two must agree."""
+    items = make_stream(B, rule, steps + warmup, dev, seed=B)
+    totals = [int(it[1]["cam_view_num"].sum()) for it in items]
+    with torch.no_grad():
+        head(*items[0])
+    eng = head._engine
+    g0 = eng.graph_stats()
+    sec = time_stream(head, items, steps, warmup)
+    g1 = eng.graph_stats()
+    timed_mean = float(np.mean([totals[(warmup + i) % len(items)] for i in range(steps)]))
+    k = int(np.argmin([abs(t - timed_mean) for t in totals]))
+    fixed = time_stream(head, [items[k]], steps, warmup)
+    return {"batch": B, "view_rule": "int(round(gauss(4,2))) clipped to 2..10 (multiview_wds.py:86-95)" if rule == "gauss" else "U{2..10} (SURVEY 8d c5)",
+            "layouts_timed": steps, "distinct_layouts": len({tuple(it[1]["cam_view_num"].tolist()) for it in items}),
+            "mean_views_per_batch": timed_mean,
+            "fresh_layout": {"samples_per_s": B / sec, "ms_per_forward": sec * 1e3},
+            "fixed_layout": {"samples_per_s": B / fixed, "ms_per_forward": fixed * 1e3, "views_in_batch": totals[k]},
+            "fresh_over_fixed": fixed / sec,
+            "graph_cache_delta": {k2: g1[k2] - g0[k2] for k2 in ("captures", "instantiations", "replays", "plain_forwards", "layout_uploads")},
+            "graph_cache_after": {k2: g1[k2] for k2 in ("cached_execs", "parked_execs", "exec_reuses", "exec_update_refusals")}}
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` without a launcher: start the N ranks here (torch.distributed.run, one process per GPU,
     rendezvous on 127.0.0.1) instead of silently measuring one.  Refuses loudly when the box has fewer GPUs -- unless
@@ -353,16 +423,31 @@ def main():
             eng.set_overlap(False)
             for _ in range(args.warmup):
                 step()
-        eng.profile_enable(8 * args.steps)
+        # The timed region runs the path exactly as it ships: launch-graph replay on, the library's HIP-event profile OFF (the
+        # profile needs plain launches).  One torch event per step boundary on the launch stream (no host sync) gives the
+        # per-step durations whose MEDIAN is reported beside the mean.
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         meter.reset()
         pdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for i in range(args.steps):
             preds = step()
+            marks[i + 1].record()
         torch.cuda.synchronize()
         pdist.barrier()
         dt = time.perf_counter() - t0
+        step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        graph_stats = eng.graph_stats()
+        mpvpe_timed = meter.result() * 1e3
+        # separate short leg for the roofline: the same steps with the library's HIP events around the dominant kernel and the
+        # sampling stage (plain launches, ~130 event records per step -- which is why it is not the timed region)
+        ev_steps = max(2, min(args.steps, 6))
+        eng.profile_enable(8 * ev_steps)
+        for _ in range(ev_steps):
+            step()
+        torch.cuda.synchronize()
     dt_rank = dt
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     pdist.all_reduce_max_(tmax)
@@ -400,7 +485,9 @@ def main():
         else f"samples/sec (multi-view frames) POEM-{args.model} " +
              (f"{args.views_range[0]}-{args.views_range[1]} views (ragged)" if args.views_range else f"{args.views}-view"),
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": step_ms[len(step_ms) // 2] if len(step_ms) % 2 else
+        0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{baseline_config_name(args.model, args.views, args.views_range, args.batch, parametric)}: POEM-{args.model} head "
                                f"(POEM_Generalized_Head + PtEmbedTRv4), {('ragged ' + str(args.views_range)) if args.views_range else args.views} views, "
@@ -427,7 +514,7 @@ def main():
         fe_s = fe_ms / n_fe * 1e-3
         sb = sampling_stage_bytes(C, views)
         res["sampling_stage"] = {"span": "input_proj -> projection -> bilinear sampling -> merge MLPs -> bps_feat (HIP events)",
-                                 "avg_ms": fe_ms / n_fe, "forwards_timed": n_fe, "share_of_step": fe_ms / (dt * 1e3),
+                                 "avg_ms": fe_ms / n_fe, "forwards_timed": n_fe, "share_of_step": (fe_ms / n_fe) / (dt / args.steps * 1e3),
                                  "algorithmic_bytes": sb, "GBps_algorithmic": sb / fe_s / 1e9,
                                  "hbm_frac_of_8TBps": sb / fe_s / 8e12,
                                  "executed_TFLOPs": (sum(views) * 4096 * 3.0 * C * C + len(views) * 4096 * 1.5 * C * C
@@ -459,17 +546,25 @@ def main():
                                               "command (tools/collect_profiles.sh), NOT measured in the run that printed this line")
                            if traffic is not None else None,
                            "launches_timed": n_launch, "avg_launch_ms": va_ms / n_launch,
-                           "share_of_step": va_ms / (dt * 1e3)}
+                           "share_of_step": (va_ms / ev_steps) / (dt / args.steps * 1e3)}
         if n_anch > 0:
             res["roofline"]["anchored_block0"] = {
                 "kernel": "vecattn_kernel MODE 2 (block 0: positional products from the per-forward anchor tables)",
-                "launches_timed": n_anch, "avg_launch_ms": anch_ms / n_anch, "share_of_step": anch_ms / (dt * 1e3),
+                "launches_timed": n_anch, "avg_launch_ms": anch_ms / n_anch, "share_of_step": (anch_ms / ev_steps) / (dt / args.steps * 1e3),
                 "as_written_TFLOPs": vecattn_flops_per_launch(args.batch, C) / (anch_ms / n_anch * 1e-3) / 1e12,
                 "executed_TFLOPs": vecattn_flops_per_launch(args.batch, C) / 3.0 / (anch_ms / n_anch * 1e-3) / 1e12,
                 "note": "not part of `achieved`: a third of the as-written products are executed per sample"}
     if scale_diag is not None:
         res["scaling_diagnostics"] = scale_diag
-    res["mpvpe_synthetic_gt_mm"] = meter.result() * 1e3
+    res["mpvpe_synthetic_gt_mm"] = mpvpe_timed
+    res["timed_region"] = {"launch_graph_replays": graph_stats["replays"], "plain_launch_forwards": graph_stats["plain_forwards"],
+                           "graph_captures": graph_stats["captures"], "view_layout_uploads": graph_stats["layout_uploads"],
+                           "note": "counters of the head since its creation (warm-up included): the timed steps replay the launch graph; "
+                                   "`ms_per_step` = wall time of the region / steps (value's basis), `ms_per_step_median` = median of the "
+                                   "per-step GPU durations between events recorded on the launch stream"}
+    if "roofline" in res:
+        res["roofline"]["events_leg"] = (f"{ev_steps} steps right after the timed region with the library's HIP events on the launch stream "
+                                         "(plain launches); the timed region itself runs without them")
     if args.precision != "fp32":
         res["dtype"] = "f32 (vector-attention C x C products as hi/lo f16 splits on the f16 matrix cores, fp32 accumulation)"
         if "roofline" in res:
@@ -572,6 +667,17 @@ def main():
             small["error"] = repr(e)[:200]
         res["small_batch_scope"] = small
         torch.cuda.empty_cache()
+        # RAGGED STREAMS as the reference's data pipeline produces them: a fresh view layout every batch
+        # (collation_random_n_views; evaluation at --val_batch_size 2, lib/opt.py:27-30 upstream)
+        fresh = {}
+        for name, (b_, rule, n_) in {"B2_gauss": (2, "gauss", 60), "B8_uniform": (8, "uniform", 40), "c5_B64_uniform": (64, "uniform", 12)}.items():
+            try:
+                with torch.no_grad():
+                    fresh[name] = fresh_layout_scope(head, dev, b_, rule, n_)
+            except Exception as e:   # informational: never fail the bench line on it
+                fresh[name] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
+        res["fresh_layout_scope"] = fresh
         # the per-GPU loads of the other BASELINE configs, same code path, short legs (reported beside the headline)
         extras = {}
         legs = {"c3_medium_MANO_8views_batch32": ("medium_MANO", [8] * 32, True),

@@ -111,7 +111,19 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
 void poem_destroy(poem_handle_t h);
 
 /* ---- whole path ---------------------------------------------------------------------------------------- */
+/* Bytes of the caller-owned workspace of a forward of `batch` samples with `total_views` views in all.  Passing
+ * total_views = batch * cfg.max_views (the worst case of the batch size) makes poem_head_forward lay the workspace out
+ * for that capacity whatever the batch's own view counts are: every pointer of the forward is then a function of the batch
+ * size alone and ONE captured launch graph per batch size serves every view layout (a stream of ragged batches, the
+ * reference's collation_random_n_views, lib/utils/collation.py:7-25).  A workspace sized for the batch's own total works
+ * too; its graph is then shared by the layouts with that total only. */
 size_t poem_workspace_bytes(poem_handle_t h, int batch, int total_views);
+/* Diagnostics of the launch-graph cache, n >= 9 slots: [0] graph execs cached by this handle, [1] stream captures,
+ * [2] hipGraphInstantiate calls, [3] forwards replayed from a graph, [4] forwards issued as plain launches,
+ * [5] view-layout uploads (a forward whose layout equals the previous one uploads nothing), [6] retired execs parked in the
+ * process, [7] parked execs taken over by a later capture (hipGraphExecUpdate), [8] updates the runtime refused.
+ * A forward never blocks the host: the layout travels in a kernel's argument segment. */
+int poem_graph_stats(poem_handle_t h, int64_t* out, int n);
 /* view_offsets_host: B+1 prefix sums of views per sample (host memory, the reference's cam_view_num).
  * cam_extr is camera->master (as in the reference's img_metas["cam_extr"]).
  * out_xyz: (nblocks, B, Q, 3) metres in the master frame (all_coords_preds).
@@ -147,7 +159,9 @@ int poem_set_chains(poem_handle_t h, int enable);
  * itself -- no partials in HBM, "chain_combine" then has nothing to do (bit-identical; measured 0.5 % slower end to end,
  * hence off); "tables_first" (default 1): the fused
  * sampling kernel is ordered behind the block-0 anchor-table build of the neighbour-search stream (a CU that hosts a table
- * block takes one sampling block instead of two; results unaffected).  Unknown names return POEM_E_ARG. */
+ * block takes one sampling block instead of two; results unaffected); "graphs" (default 1): replay the launch list of a
+ * forward as a hipGraph, keyed by (batch size, workspace, options) -- NOT by the view layout; "graph_eager" (default 0): capture
+ * at the first forward of a key instead of the second.  Unknown names return POEM_E_ARG. */
 int poem_set_option(poem_handle_t h, const char* name, int value);
 /* Block-0 anchor tables of poem_head_forward (default on, fp32 mode).  In the first decoder block every query's
  * neighbours are the 32 fixed anchors (anchor_points, lib/models/bricks/point_transformers.py:10-32) and every sample's

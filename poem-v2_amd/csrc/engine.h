@@ -149,10 +149,15 @@ struct poem_handle_s {
   bool graph_broken = false;         // a capture failed once on this handle: stay on plain launches
   hipStream_t cap_stream = nullptr;
   int stream_device = 0;             // device whose stream pool (handle.cpp) the three streams belong to
-  struct GraphEntry { std::vector<int64_t> key; hipGraphExec_t exec; uint64_t stamp; };
+  struct GraphEntry { std::vector<int64_t> key; hipGraphExec_t exec; uint64_t stamp; uint64_t shape; };
   std::vector<GraphEntry> graph_cache;
+  std::vector<std::vector<int64_t>> graph_seen;      // keys met once: a key is captured at its second forward
+  bool graph_eager = false;                          // capture at the first forward of a key (tests / benches that want it)
   uint64_t graph_clock = 0;
   static constexpr size_t GRAPH_CAP = 12;
+  // counters (poem_graph_stats)
+  int64_t graph_captures = 0, graph_instantiations = 0, graph_replays = 0, plain_forwards = 0, layout_uploads = 0;
+  int small_batch = 1;       // small-batch launch shapes (decoder.cpp); part of the graph key
   int knn_fma = 0;           // neighbour distances with the fma contraction of pytorch3d's CUDA kernel (knn.hip); default: the CPU path's rounding
   int chain_tile = 0;        // chain row-tile height: 0 = per launch (chain.hip chain_tile_p), 1 = 32 rows, 2 = 64 rows (A/B)
   // The block-0 anchor tables are functions of the handle's constants only (template, anchors, weights): like the folded
@@ -216,7 +221,9 @@ struct Plan {
 Plan make_plan(const poem_config_t& c, int B, int BN, void* base);
 void register_taps(poem_handle_t h, const Plan& p, int B, int BN, bool sampling);
 
-void poem_park_graph_exec(hipGraphExec_t e);      // handle.cpp: an evicted exec is parked, not destroyed (runtime bug, see there)
+// handle.cpp: a retired exec is parked, not destroyed (runtime bug, see there), and offered to the next capture of the same shape
+void poem_park_graph_exec(hipGraphExec_t e, uint64_t shape);
+hipGraphExec_t poem_reuse_graph_exec(hipGraph_t graph, uint64_t shape);      // a parked exec updated to `graph`, or nullptr
 
 // ---- launch sequence (decoder.cpp) -------------------------------------------------------------------------------------------
 int build_anchor_tables(poem_handle_t h, Plan& p, hipStream_t s, bool at_create = false);

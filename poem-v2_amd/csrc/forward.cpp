@@ -1,7 +1,8 @@
 // poem_head_forward (POEM_Generalized_Head.forward, lib/models/heads/ptEmb_head.py:825-964 upstream) and poem_decoder_forward
 // (PtEmbedTRv4.forward, lib/models/layers/ptEmb_transformer.py:371-376).  One forward =
 //
-//   view_layout()   per-view index arrays (CSR of the ragged batch) into handle-owned device memory, when they changed
+//   view_layout()   per-view index arrays (CSR of the ragged batch) into handle-owned device memory, when they changed: built
+//                   by a kernel from offsets carried in its arguments -- the host never waits for the previous forward
 //   inputs()        the four kernels that read the CALLER's tensors: input_proj (+ folded positional table), normalised
 //                   coordinates, inverted extrinsics, projection table                                   [:835-883 upstream]
 //   body()          sampling + Q1 + merge MLPs -> bps_feat ; query features ; the three decoder blocks (decoder.cpp)
@@ -35,6 +36,7 @@ struct HeadRun {
   poem_handle_t h;
   const poem_config_t& c;
   Plan p;
+  const int plan_views;
   const float *mlvl_feat, *cam_intr, *cam_extr, *reference_joints;
   const int32_t* offs_host;
   const int B, BN, C, S, Q, HW, BS, img_w, img_h;
@@ -43,42 +45,58 @@ struct HeadRun {
   bool prof_fe = false;      // HIP-event pair around the sampling stage
   int prof_slot = 0;
 
-  HeadRun(poem_handle_t h_, const float* feat, const float* intr, const float* extr, const int32_t* offs, int batch,
+  // plan_views: the view capacity the workspace plan (and every captured launch) is laid out for: batch * max_views when the
+  // caller's workspace holds that plan -- one graph per batch size, whatever the view layout -- else this batch's own total.
+  HeadRun(poem_handle_t h_, const float* feat, const float* intr, const float* extr, const int32_t* offs, int batch, int plan_views_,
           const float* ref_joints, int w, int hgt, void* workspace, hipStream_t s_)
-      : h(h_), c(h_->cfg), p(make_plan(h_->cfg, batch, offs[batch], workspace)), mlvl_feat(feat), cam_intr(intr), cam_extr(extr),
+      : h(h_), c(h_->cfg), p(make_plan(h_->cfg, batch, plan_views_, workspace)), plan_views(plan_views_), mlvl_feat(feat), cam_intr(intr), cam_extr(extr),
         reference_joints(ref_joints), offs_host(offs), B(batch), BN(offs[batch]), C(c.embed), S(c.nsample), Q(c.nquery),
         HW(c.feat_h * c.feat_w), BS(batch * c.nsample), img_w(w), img_h(hgt), s(s_) {}
 
-  // ---- view_sample[v] = sample of view v, pe_index[v] = its slot in the folded positional table.  Kept in handle-owned
-  // device memory and re-uploaded only when the layout changes: a pageable H2D copy blocks the host until the stream reaches
-  // it, i.e. until the PREVIOUS forward has finished.
+  // ---- view_offsets | view_sample[v] = sample of view v | pe_index[v] = its slot in the folded positional table.  Kept in
+  // handle-owned device memory and rebuilt only when the layout changes, by view_layout_kernel from offsets that ride in the
+  // kernel-argument segment: stream-ordered behind the previous forward's readers, and the host returns at once.  (A pageable
+  // H2D copy -- rounds 1-3 -- blocks the host until the stream reaches it, i.e. until the PREVIOUS forward has finished: with a
+  // fresh layout per batch, which is what the reference's collation produces (lib/utils/collation.py:7-25,
+  // lib/data_wds/multiview_wds.py:86-95 upstream), the host could never run ahead of the GPU.)
   int view_layout() {
-    std::vector<int32_t> vs(BN), pei(BN);
     for (int b = 0; b < B; ++b) {
       const int n = offs_host[b + 1] - offs_host[b];
       if (n < 1 || n > c.max_views) return POEM_E_ARG;
-      for (int k = 0; k < n; ++k) {
-        vs[offs_host[b] + k] = b;
-        pei[offs_host[b] + k] = n * (n - 1) / 2 + k;
-      }
     }
-    const size_t o1 = align_up((size_t)B + 1, 64), o2 = o1 + align_up((size_t)BN, 64), tot = o2 + align_up((size_t)BN, 64);
-    if (h->idx_dev && tot <= (size_t)poem_handle_s::IDX_CAP) {
-      std::vector<int32_t> cur(tot, 0);
-      std::copy(offs_host, offs_host + B + 1, cur.begin());
-      std::copy(vs.begin(), vs.end(), cur.begin() + o1);
-      std::copy(pei.begin(), pei.end(), cur.begin() + o2);
-      if (cur != h->idx_host) {      // (stream-ordered behind the previous forward's kernels, which may still read the old layout)
-        HIPCHK(hipMemcpyAsync(h->idx_dev, cur.data(), tot * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        h->idx_host.swap(cur);
-      }
+    // (array positions are functions of the batch size and the plan's capacity only: a captured launch holds these pointers)
+    const size_t cap = (size_t)std::max(plan_views, BN);
+    const size_t o1 = align_up((size_t)B + 1, 64), o2 = o1 + align_up(cap, 64), tot = o2 + align_up(cap, 64);
+    const bool owned = h->idx_dev && tot <= (size_t)poem_handle_s::IDX_CAP;
+    if (owned) {
       p.offs = h->idx_dev;
       p.view_sample = h->idx_dev + o1;
       p.pe_index = h->idx_dev + o2;
+      if (h->idx_host.size() == (size_t)B + 2 && h->idx_host[B + 1] == (int32_t)cap && std::equal(offs_host, offs_host + B + 1, h->idx_host.begin()))
+        return POEM_OK;
+    }
+    h->idx_host.clear();       // (a failed upload leaves no signature behind)
+    if (B <= POEM_LAYOUT_MAX_BATCH && BN <= 65535) {
+      ViewLayoutArgs a;
+      a.offs = p.offs; a.view_sample = p.view_sample; a.pe_index = p.pe_index; a.B = B;
+      for (int b = 0; b <= B; ++b) a.off16[b] = (unsigned short)offs_host[b];
+      HIPCHK(poem_launch_view_layout(&a, s));
+      ++h->layout_uploads;
     } else {     // (the host vectors die at return: pageable H2D copies are staged before hipMemcpyAsync returns)
+      std::vector<int32_t> vs(BN), pei(BN);
+      for (int b = 0; b < B; ++b)
+        for (int k = 0, n = offs_host[b + 1] - offs_host[b]; k < n; ++k) {
+          vs[offs_host[b] + k] = b;
+          pei[offs_host[b] + k] = n * (n - 1) / 2 + k;
+        }
       HIPCHK(hipMemcpyAsync(p.offs, offs_host, (B + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
       HIPCHK(hipMemcpyAsync(p.view_sample, vs.data(), BN * sizeof(int32_t), hipMemcpyHostToDevice, s));
       HIPCHK(hipMemcpyAsync(p.pe_index, pei.data(), BN * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      ++h->layout_uploads;
+    }
+    if (owned) {      // (workspace arrays are the caller's scratch: never trusted to persist)
+      h->idx_host.assign(offs_host, offs_host + B + 1);
+      h->idx_host.push_back((int32_t)cap);
     }
     return POEM_OK;
   }
@@ -119,7 +137,8 @@ struct HeadRun {
       SampleMergeArgs sm{};
       sm.xt = p.xt; sm.tab = (const float4*)p.ptab; sm.view_sample = p.view_sample; sm.offs = p.offs;
       sm.w0 = (const float4*)h->P(T_M00_W); sm.b0 = h->R(T_M00_B); sm.w1 = (const float4*)h->P(T_M02_W); sm.b1 = h->R(T_M02_B);
-      sm.h2 = p.h2; sm.q1 = p.q1; sm.views = BN; sm.S = S; sm.hw = HW; sm.h2_tiled = 1;
+      sm.h2 = p.h2; sm.q1 = p.q1; sm.S = S; sm.hw = HW; sm.h2_tiled = 1;
+      sm.views = plan_views; sm.views_dev = p.offs + B;      // the grid is sized for the plan, the kernel reads the batch's own count
       // (per-forward table build only) The build on the neighbour-search stream holds 68 KB of LDS per block, and next to the
       // MFMA-dense sample_merge waves its blocks linger: a CU that hosts one takes a single sample_merge block (2 x 66.5 KB no
       // longer fit) and the persistent grid runs in two rounds.  sample_merge waits for the build (+0.06 ms on the critical path).
@@ -158,19 +177,33 @@ struct HeadRun {
     return run_decoder(h, p, p.feats0, p.pt_xyz, p.bps_feat, B, pose_dst, betas_dst, st, true);
   }
 
-  // ---- hipGraph replay of body(): captured once per (batch, view layout, workspace, option set) on the handle's capture
+  // ---- hipGraph replay of body(): captured once per (batch size, plan capacity, workspace, option set) on the handle's capture
   // stream (the caller's may be the legacy default stream, which cannot be captured); the side-stream forks / joins of
-  // decoder.cpp become edges of the graph.  -> 1 replayed, 0 not eligible / capture failed (plain launches), < 0 error.
+  // decoder.cpp become edges of the graph.  The VIEW LAYOUT is not part of the key: every launch of the body takes its per-view
+  // arrays, its view count included, from device memory (view_layout()), and its pointers from a plan laid out for plan_views
+  // -- so a stream of ragged batches whose layout changes every batch, which is what the reference's collation produces
+  // (lib/utils/collation.py:7-25 upstream), replays ONE graph per batch size.  A key is captured the second time it is seen (a
+  // one-off shape -- the short last batch of an epoch -- never pays capture + instantiate), and an exec retired by eviction or
+  // by a destroyed handle is re-used through hipGraphExecUpdate before a new one is instantiated (handle.cpp: execs are never
+  // destroyed).  -> 1 replayed, 0 not eligible / not yet captured / capture failed (plain launches), < 0 error.
   int replay(void* workspace, float* pose_aa, float* betas) {
     if (!h->graphs || h->graph_broken || !fused_fe || h->prof_on || h->tables_pending || !h->cap_stream) return 0;
-    std::vector<int64_t> key = {B, BN, img_w, img_h, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
-                                h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
-                                h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge};
-    key.insert(key.end(), offs_host, offs_host + B + 1);
+    const std::vector<int64_t> key = {B, plan_views, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
+                                      h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
+                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch};
     poem_handle_s::GraphEntry* hit = nullptr;
     for (auto& g : h->graph_cache)
       if (g.key == key) { hit = &g; break; }
     if (!hit) {
+      if (!h->graph_eager) {
+        bool seen = false;
+        for (auto& k : h->graph_seen) seen = seen || k == key;
+        if (!seen) {
+          if (h->graph_seen.size() >= 64) h->graph_seen.erase(h->graph_seen.begin());
+          h->graph_seen.push_back(key);
+          return 0;
+        }
+      }
       hipGraph_t graph = nullptr;
       hipGraphExec_t exec = nullptr;
       POEM_TRACE("capture begin h=%p B=%d cached=%zu", (void*)h, B, h->graph_cache.size());
@@ -182,7 +215,14 @@ struct HeadRun {
         POEM_TRACE("capture end e=%d graph=%p", (int)e, (void*)graph);
         ok = rc == POEM_OK && e == hipSuccess && graph != nullptr;
       }
-      if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      ++h->graph_captures;
+      if (ok) {
+        exec = poem_reuse_graph_exec(graph, graph_shape());
+        if (!exec) {
+          ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+          ++h->graph_instantiations;
+        }
+      }
       POEM_TRACE("instantiate ok=%d exec=%p", (int)ok, (void*)exec);
       if (graph) (void)hipGraphDestroy(graph);
       POEM_TRACE("graph destroyed");
@@ -195,21 +235,32 @@ struct HeadRun {
         size_t lru = 0;
         for (size_t i = 1; i < h->graph_cache.size(); ++i)
           if (h->graph_cache[i].stamp < h->graph_cache[lru].stamp) lru = i;
-        poem_park_graph_exec(h->graph_cache[lru].exec);      // (not destroyed: handle.cpp, capture kits)
+        poem_park_graph_exec(h->graph_cache[lru].exec, h->graph_cache[lru].shape);      // (not destroyed: handle.cpp)
         h->graph_cache.erase(h->graph_cache.begin() + lru);
       }
-      h->graph_cache.push_back({key, exec, 0});
+      h->graph_cache.push_back({key, exec, 0, graph_shape()});
       hit = &h->graph_cache.back();
     }
     hit->stamp = ++h->graph_clock;
     POEM_TRACE("graph launch exec=%p", (void*)hit->exec);
     HIPCHK(hipGraphLaunch(hit->exec, s));
+    ++h->graph_replays;
     POEM_TRACE("graph launched");
     if (c.parametric) {      // the captured tail wrote pose / shape into the workspace
       HIPCHK(hipMemcpyAsync(pose_aa, p.g_pose, (size_t)B * 48 * sizeof(float), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(betas, p.g_betas, (size_t)B * 10 * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     return 1;
+  }
+
+  // what decides the TOPOLOGY of the captured body (node count and kinds): a retired exec is offered for update only to a
+  // graph of the same shape
+  uint64_t graph_shape() const {
+    uint64_t v = (uint64_t)c.embed | (uint64_t)c.nblocks << 12 | (uint64_t)c.parametric << 16 | (uint64_t)h->anchor_tables << 17 |
+                 (uint64_t)h->chains << 18 | (uint64_t)h->chain_combine << 19 | (uint64_t)h->knn_early << 20 | (uint64_t)h->overlap << 21 |
+                 (uint64_t)h->xattn_merge << 22 | (uint64_t)h->tables_cached << 23 | (uint64_t)h->small_batch << 24 |
+                 (uint64_t)(h->precision & 3) << 26 | (uint64_t)c.heads << 28 | (uint64_t)(c.nsample / 32) << 36;
+    return v;
   }
 };
 
@@ -229,7 +280,15 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   if (c.parametric && (!pose_aa || !betas)) return POEM_E_ARG;
   if (view_offsets_host[0] != 0 || view_offsets_host[batch] < batch) return POEM_E_ARG;
   SplitContext split_ctx(h);
-  HeadRun run(h, mlvl_feat, cam_intr, cam_extr, view_offsets_host, batch, reference_joints, img_w, img_h, workspace, (hipStream_t)stream);
+  // A workspace that holds the plan of batch * max_views views (poem_workspace_bytes(h, batch, batch * max_views)) makes every
+  // pointer of the forward a function of the batch size alone; a smaller one is laid out for this batch's own view total.
+  const int total_views = view_offsets_host[batch];
+  const long cap_views = (long)batch * c.max_views;
+  int plan_views = total_views;
+  if (cap_views > total_views && cap_views < (1l << 30) && workspace_bytes >= make_plan(c, batch, (int)cap_views, nullptr).bytes)
+    plan_views = (int)cap_views;
+  HeadRun run(h, mlvl_feat, cam_intr, cam_extr, view_offsets_host, batch, plan_views, reference_joints, img_w, img_h, workspace,
+              (hipStream_t)stream);
   if (workspace_bytes < run.p.bytes) return POEM_E_WORKSPACE;
   POEM_TRACE("head_forward h=%p B=%d C=%d", (void*)h, batch, c.embed);
   int rc = run.view_layout();
@@ -240,6 +299,7 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   rc = run.replay(workspace, pose_aa, betas);
   POEM_TRACE("replay rc=%d", rc);
   if (rc < 0) return rc;
+  if (rc == 0) ++h->plain_forwards;
   if (rc == 0 && (rc = run.body(run.s, pose_aa, betas)) != POEM_OK) return rc;
   HIPCHK(poem_launch_finalize(run.p.xyz[1], run.p.centre, out_xyz, c.nblocks, batch, c.nquery, c.radius, run.s));
   register_taps(h, run.p, batch, run.BN, true);

@@ -12,8 +12,10 @@ thread_local int g_last_hip_error = 0;
 // since); with streams pooled but events and execs destroyed, in the 204-test GPU suite right after Python's collector
 // released ten heads at once (POEM_TRACE: the second capture of the next head instantiates, its launch crashes) --
 // reproducible on a box whose MIOpen cache is warm, never with one handle at a time (tools/lab/lifecycle_probe.py, 120
-// cycles).  A kit's objects are idle when its handle is destroyed, so the next handle takes them over as they are.  Parked
-// execs cost their host-side node copies (41 kernel nodes each, at most GRAPH_CAP per handle) until the process ends.
+// cycles).  A kit's objects are idle when its handle is destroyed, so the next handle takes them over as they are.
+//   Parked execs are RE-USED (round 4): the next capture of the same shape (forward.cpp graph_shape) takes one over through
+// hipGraphExecUpdate instead of instantiating a new exec, so the number of execs alive in the process is bounded by the largest
+// number ever cached at once per shape, not by the number of handles created or layouts met (poem_graph_stats reports both).
 #include <mutex>
 namespace {
 struct CaptureKit {
@@ -22,7 +24,9 @@ struct CaptureKit {
 };
 std::mutex g_pool_mutex;
 std::map<int, std::vector<CaptureKit>> g_kit_pool;         // device id -> idle kits
-std::vector<hipGraphExec_t> g_parked_execs;                // never destroyed (see above)
+struct ParkedExec { hipGraphExec_t exec; uint64_t shape; };
+std::vector<ParkedExec> g_parked_execs;                    // never destroyed (see above); re-used by poem_reuse_graph_exec
+int64_t g_exec_reuses = 0, g_exec_update_failures = 0;
 
 hipEvent_t** kit_event_slots(poem_handle_t h, hipEvent_t** out) {
   int n = 0;
@@ -78,14 +82,45 @@ void return_kit(poem_handle_t h) {
 
 void park_execs(poem_handle_t h) {
   std::lock_guard<std::mutex> lock(g_pool_mutex);
-  for (auto& g : h->graph_cache) g_parked_execs.push_back(g.exec);
+  for (auto& g : h->graph_cache) g_parked_execs.push_back({g.exec, g.shape});
   h->graph_cache.clear();
 }
 }  // namespace
 
-void poem_park_graph_exec(hipGraphExec_t e) {
+void poem_park_graph_exec(hipGraphExec_t e, uint64_t shape) {
   std::lock_guard<std::mutex> lock(g_pool_mutex);
-  g_parked_execs.push_back(e);
+  g_parked_execs.push_back({e, shape});
+}
+
+// A parked exec of the same shape, updated in place to the freshly captured graph (kernel arguments, grids and functions of
+// every node are rewritten; earlier launches of the exec that are still in flight keep what they were launched with).  An
+// update the runtime refuses leaves the exec parked.
+hipGraphExec_t poem_reuse_graph_exec(hipGraph_t graph, uint64_t shape) {
+  ParkedExec cand{nullptr, 0};
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (size_t i = g_parked_execs.size(); i-- > 0;)
+      if (g_parked_execs[i].shape == shape) {
+        cand = g_parked_execs[i];
+        g_parked_execs.erase(g_parked_execs.begin() + i);
+        break;
+      }
+  }
+  if (!cand.exec) return nullptr;
+  hipGraphNode_t err_node = nullptr;
+  hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+  const hipError_t e = hipGraphExecUpdate(cand.exec, graph, &err_node, &res);
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  if (e == hipSuccess && res == hipGraphExecUpdateSuccess) {
+    ++g_exec_reuses;
+    return cand.exec;
+  }
+  (void)hipGetLastError();
+  POEM_TRACE("exec update refused e=%d res=%d", (int)e, (int)res);
+  ++g_exec_update_failures;
+  // shape 0 never matches a capture: an exec the runtime would not update is kept out of further attempts
+  g_parked_execs.insert(g_parked_execs.begin(), {cand.exec, 0});
+  return nullptr;
 }
 
 std::vector<TensorSpec> tensor_table(const poem_config_t& c) {
@@ -419,8 +454,22 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "tables_cached") h->tables_cached = value != 0;
   else if (k == "knn_fma") h->knn_fma = value != 0;
   else if (k == "graphs") h->graphs = value != 0;
+  else if (k == "graph_eager") h->graph_eager = value != 0;
+  else if (k == "small_batch") h->small_batch = value;
   else if (k == "chain_tile") { if (value < 0 || value > 3) return POEM_E_ARG; h->chain_tile = value; }
   else return POEM_E_ARG;
+  return POEM_OK;
+}
+
+// [0] execs cached by this handle  [1] captures  [2] instantiations  [3] graph replays  [4] forwards on plain launches
+// [5] view-layout uploads  [6] execs parked in the process  [7] parked execs re-used by update  [8] updates the runtime refused
+int poem_graph_stats(poem_handle_t h, int64_t* out, int n) {
+  if (!h || !out || n < 9) return POEM_E_ARG;
+  out[0] = (int64_t)h->graph_cache.size();
+  out[1] = h->graph_captures; out[2] = h->graph_instantiations; out[3] = h->graph_replays; out[4] = h->plain_forwards;
+  out[5] = h->layout_uploads;
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  out[6] = (int64_t)g_parked_execs.size(); out[7] = g_exec_reuses; out[8] = g_exec_update_failures;
   return POEM_OK;
 }
 

@@ -192,8 +192,10 @@ extern "C" hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int*
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   auto kern = fma ? knn_kernel<QPB, true> : knn_kernel<QPB, false>;
   static std::atomic<unsigned long long> optin[2];
+  // (opted in once per device to the CU's whole 160 KB: the need grows with NS, and the per-kernel "done" bit of poem_optin_lds
+  //  does not remember the size it was set for)
   if (lds > 64 * 1024)
-    if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin[fma ? 1 : 0]); e != hipSuccess) return e;
+    if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), 160 * 1024, optin[fma ? 1 : 0]); e != hipSuccess) return e;
   // blocks per sample: about one block per CU over the batch (a block stages the sample's sources once: fewer, longer
   // blocks), never fewer than QPB queries per block
   const int cus = poem_device_cus();

@@ -23,6 +23,7 @@ int poem_sample_merge_supported(int C, int S, int hw);
 hipError_t poem_launch_project_table(const float* bps, const float* centre, const int* view_sample, const float* intr,
                                      const float* inv_extr, void* tab, float* uv, int views, int C, int fh, int fw, int S,
                                      int img_w, int img_h, hipStream_t s);
+hipError_t poem_launch_view_layout(const ViewLayoutArgs* a, hipStream_t s);
 hipError_t poem_launch_sample_merge(const SampleMergeArgs* a, int C, hipStream_t s);
 hipError_t poem_launch_merge_tail(const MergeTailArgs* a, int C, hipStream_t s);
 hipError_t poem_launch_invert_extr(const float* extr, float* inv, int views, hipStream_t s);

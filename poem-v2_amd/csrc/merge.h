@@ -13,6 +13,22 @@ struct SampleMergeArgs {
   float* q1;                  // (B * S, C): the Q1 rows with n == 0 (the residual of merge_features_mv / _sv)
   int views, S, hw;
   int h2_tiled;               // 0: row-major Q1 rows; 1: tile-major (see merge.hip)
+  // Layout-independent launches (forward.cpp, hipGraph replay): when set, the kernel reads the batch's view count from device
+  // memory (= view_offsets[B]) and `views` is only the capacity the grid was sized for -- the captured launch then serves every
+  // view layout of a batch size.
+  const int* views_dev;
+};
+
+// The per-view index arrays of a ragged batch, built on the device from offsets that travel in the KERNEL-ARGUMENT segment
+// (misc.hip view_layout_kernel): no host buffer whose lifetime must outlast the copy, no pageable H2D copy that would block
+// the host behind the previous forward.
+#define POEM_LAYOUT_MAX_BATCH 1663
+struct ViewLayoutArgs {
+  int* offs;                  // (B + 1) out
+  int* view_sample;           // (views) out: view -> sample
+  int* pe_index;              // (views) out: slot in the folded positional table, n (n - 1) / 2 + k for view k of an n-view sample
+  int B;
+  unsigned short off16[POEM_LAYOUT_MAX_BATCH + 1];   // view_offsets (total views <= 65535)
 };
 
 struct MergeTailArgs {

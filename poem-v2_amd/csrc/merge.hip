@@ -79,7 +79,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
   // and tables (384 KB per view) stay in every XCD's L2.  (An XCD-aware order -- the blocks of XCD x = blockIdx % 8 walking
   // the views x, x + 8, ... -- measured 1 % slower.)
   const int slot = (int)blockIdx.x, L = (int)gridDim.x;
-  const int nv = A.views;
+  const int nv = A.views_dev ? min(*A.views_dev, A.views) : A.views;
   const unsigned CC4 = (unsigned)(C * C * 4);
   const int q = lane / LPP, cg = lane % LPP;
 

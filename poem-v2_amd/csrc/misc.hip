@@ -1,6 +1,8 @@
 // Small glue kernels of the path: coordinate normalisation, query-embedding broadcast, output de-normalisation,
 // and the medium_MANO parametric tail (Q3 re-interpretation + rot6d -> axis-angle).
 #include "common.h"
+#include <algorithm>
+#include "merge.h"
 
 // centre = reference_joints[:, 9];  pt_xyz = ((bps + c) - c) / radius;  query_xyz = ((c + template) - c) / radius
 // evaluated exactly the reference's way (ptEmb_head.py:873-874,893-894,934-935 upstream): (bps + c) - c is NOT bps in fp32.
@@ -224,5 +226,28 @@ extern "C" hipError_t poem_launch_compose_weight(const float* A, const float* Bm
 extern "C" hipError_t poem_launch_compose_bias(const float* A, const float* b1, const float* b2, float* out, int N, int Cm,
                                                hipStream_t s) {
   hipLaunchKernelGGL(compose_bias_kernel, dim3((N + 63) / 64), dim3(64), 0, s, A, b1, b2, out, N, Cm);
+  return hipGetLastError();
+}
+
+// view_sample / pe_index / view_offsets of a ragged batch from the offsets held in the kernel arguments (merge.h ViewLayoutArgs;
+// lib/utils/collation.py:7-25 upstream is where the per-sample view counts come from): thread v finds its sample by bisection.
+__global__ void view_layout_kernel(ViewLayoutArgs A) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const int BN = A.off16[A.B];
+  if (v <= A.B) A.offs[v] = A.off16[v];
+  if (v >= BN) return;
+  int lo = 0, hi = A.B;                  // off16[lo] <= v < off16[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)A.off16[mid] <= v) lo = mid; else hi = mid;
+  }
+  const int n = (int)A.off16[lo + 1] - (int)A.off16[lo];
+  A.view_sample[v] = lo;
+  A.pe_index[v] = n * (n - 1) / 2 + (v - (int)A.off16[lo]);
+}
+
+extern "C" hipError_t poem_launch_view_layout(const ViewLayoutArgs* a, hipStream_t s) {
+  const int n = std::max<int>(a->off16[a->B], a->B + 1);
+  hipLaunchKernelGGL(view_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *a);
   return hipGetLastError();
 }

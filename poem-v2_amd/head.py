@@ -97,13 +97,15 @@ class POEM_Generalized_Head(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _engine_for(self, device):
-        # The engine packs the weights once; it is rebuilt when any parameter's storage or version counter changes
-        # (load_state_dict, .to(), in-place edits).  The Parameter objects are cached: walking the module tree for its 199
-        # parameters costs ~0.3 ms of host time per forward -- more than enqueueing the whole step (a hipGraph replay).
+        # The engine packs the weights once; it is rebuilt when any parameter's identity, storage or version counter changes
+        # (load_state_dict incl. assign=True, `module.weight = nn.Parameter(...)`, .to(), in-place edits).  The submodules'
+        # `_parameters` dicts are cached and read directly: walking the module tree for its 199 parameters costs ~0.3 ms of
+        # host time per forward -- more than enqueueing the whole step (a hipGraph replay); reading the dicts costs ~0.06 ms
+        # and, unlike a cached list of Parameter objects, sees a Parameter that was REPLACED.
         self._pcheck = getattr(self, "_pcheck", 0) + 1
         if getattr(self, "_plist", None) is None or self._pcheck % 256 == 0:
-            self._plist = list(self.parameters())
-        sig = (str(device),) + tuple((p.data_ptr(), p._version) for p in self._plist)
+            self._plist = [m._parameters for m in self.modules()]      # (the module set itself: refreshed every 256 forwards)
+        sig = (str(device),) + tuple((id(p), p.data_ptr(), p._version) for d in self._plist for p in d.values() if p is not None)
         if self._engine is None or self._engine_sig != sig:
             t = self.transformer
             cfg = hip.make_config(self.embed_dims, in_channels=self.in_channels, nsample=self.nsample, nquery=799,

@@ -39,6 +39,7 @@ SIGNATURES = {
     "poem_create": (_i, [_cfgp, ctypes.POINTER(_vp), _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp, ctypes.POINTER(_vp)]),
     "poem_destroy": (None, [_vp]),
     "poem_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "poem_graph_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_int64), _i]),
     "poem_head_forward": (_i, [_vp, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_int32), _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
                                _sz, _vp]),
     "poem_decoder_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -224,13 +225,24 @@ class Engine:
             pass
 
     def _ws(self, batch, views):
+        # head path: sized for the batch size's worst case (batch * max_views): the library then lays the workspace out for
+        # that capacity and one launch graph per batch size serves every view layout (include/poem_hip.h poem_workspace_bytes)
         need = lib().poem_workspace_bytes(self.handle, batch, views)
         if need == 0:
             raise RuntimeError("poem_workspace_bytes failed")
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = None
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self.workspace, need
+        return self.workspace, self.workspace.numel()
+
+    GRAPH_STAT_NAMES = ("cached_execs", "captures", "instantiations", "replays", "plain_forwards", "layout_uploads",
+                        "parked_execs", "exec_reuses", "exec_update_refusals")
+
+    def graph_stats(self):
+        """Counters of the launch-graph cache (include/poem_hip.h poem_graph_stats)."""
+        out = (ctypes.c_int64 * 9)()
+        check(lib().poem_graph_stats(self.handle, out, 9), "poem_graph_stats")
+        return dict(zip(self.GRAPH_STAT_NAMES, [int(v) for v in out]))
 
     def enable_taps(self, flag=True):
         self._taps = bool(flag)
@@ -287,7 +299,7 @@ class Engine:
             if tuple(t.shape) != shape:
                 raise RuntimeError(f"{what} shape {tuple(t.shape)} != {shape} (cam_view_num sums to {BN} views, {B} samples)")
         offs = (ctypes.c_int32 * (B + 1))(*np.concatenate([[0], np.cumsum(views)]).astype(np.int32).tolist())
-        ws, need = self._ws(B, BN)
+        ws, need = self._ws(B, max(BN, B * c.max_views))
         out = torch.empty(c.nblocks, B, c.nquery, 3, dtype=torch.float32, device=self.device)
         pose = torch.empty(B, 48, dtype=torch.float32, device=self.device) if c.parametric else None
         betas = torch.empty(B, 10, dtype=torch.float32, device=self.device) if c.parametric else None

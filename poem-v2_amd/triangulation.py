@@ -10,9 +10,22 @@ import torch
 from . import hip
 
 
+_OFFS_CACHE = {}
+
+
 def _offsets(views, device):
-    offs = np.concatenate([[0], np.cumsum(np.asarray(views, dtype=np.int64))]).astype(np.int32)
-    return torch.from_numpy(offs).to(device)
+    """(B+1,) int32 view offsets on the device.  A repeating layout re-uses its device tensor; a new one is staged through
+    pinned memory and copied without blocking (a pageable H2D copy would hold the host until the stream has drained, i.e.
+    until the previous forward has finished -- the stall the head's own layout upload avoids, csrc/forward.cpp)."""
+    key = (tuple(int(v) for v in views), str(device))
+    hit = _OFFS_CACHE.get(key)
+    if hit is None:
+        offs = np.concatenate([[0], np.cumsum(np.asarray(key[0], dtype=np.int64))]).astype(np.int32)
+        hit = torch.from_numpy(offs).pin_memory().to(device, non_blocking=True)
+        if len(_OFFS_CACHE) >= 64:
+            _OFFS_CACHE.pop(next(iter(_OFFS_CACHE)))
+        _OFFS_CACHE[key] = hit
+    return hit
 
 
 def triangulate_reference_joints(uv, cam_intr, cam_extr, cam_view_num):

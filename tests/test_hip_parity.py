@@ -882,7 +882,8 @@ def test_full_size_batch_properties():
     eng = head._engine
     # ... and the hipGraph replay of the launch list against plain launches (first call of a layout captures, later calls replay)
     for name, val in (("chain_tile", 1), ("chain_tile", 2), ("chain_tile", 3), ("chain_tile", 0), ("tables_cached", 0), ("tables_cached", 1),
-                      ("graphs", 0), ("graphs", 1), ("graphs", 1),
+                      # (a key is captured at its second forward and replayed from the third: csrc/forward.cpp)
+                      ("graphs", 0), ("graphs", 1), ("graphs", 1), ("graphs", 1),
                       # the cross attention's split-key partials merged by the chain kernel that consumes them (default), by a
                       # combine launch, inside the attention kernel: the same merge arithmetic in chunk order, three places
                       ("chain_combine", 0), ("xattn_merge", 1), ("xattn_merge", 0), ("chain_combine", 1)):
@@ -897,6 +898,83 @@ def test_full_size_batch_properties():
     orc = run_oracle(cfg, w, consts, b2)["all_coords_preds"]
     mp = torch.norm(full[-1, :2, 21:].cpu() - orc[-1, :, 21:], dim=-1).mean(dim=1)
     assert float(mp.max()) < 1e-6, mp
+
+
+def test_ragged_stream_fresh_layout_every_batch_replays_one_graph():
+    """Row R1: the reference's collation hands the head a NEW view layout with every batch (collation_random_n_views,
+    lib/utils/collation.py:7-25; view counts drawn per sample, lib/data_wds/multiview_wds.py:86-95; evaluation at batch 2,
+    lib/opt.py:27-30 upstream).  300 distinct layouts through one head: every result equals the plain-launch path's bit for bit,
+    the whole stream is served by ONE captured graph per batch size (no capture, no instantiate, no blocking upload per
+    layout), and nothing accumulates: the process-wide count of parked graph execs does not move."""
+    import random
+    spec = dict(embed=128, nsample=4096, views=[2, 3], seed=71, parametric=False)
+    head = build_hip_head(spec, DEV)
+    rng = random.Random(7)
+    layouts, seen = [], set()
+    while len(layouts) < 300:
+        B = (2, 3, 3, 3, 3, 4, 4, 4, 4, 4)[len(layouts) % 10]      # three batch sizes interleaved (30 / 120 / 150 layouts)
+        v = tuple(min(max(1, int(round(rng.gauss(4, 2)))), 10) for _ in range(B))
+        if v not in seen:
+            seen.add(v)
+            layouts.append(list(v))
+    g = torch.Generator().manual_seed(5)
+    pool = torch.randn(40, 160, 16, 16, generator=g).to(DEV)
+    rj_all = (torch.tensor([0.0, 0.0, 0.6]) + 0.03 * torch.randn(4, 21, 3, generator=g)).to(DEV)
+    K = torch.tensor([[300.0, 0, 128.0], [0, 300.0, 128.0], [0, 0, 1]])
+    items = []
+    for v in layouts:
+        bn = sum(v)
+        extr = torch.cat([pk.inputs.ring_extrinsics(n, ring=10) for n in v], 0)
+        m = {"inp_img_shape": (256, 256), "cam_intr": K[None].repeat(bn, 1, 1).contiguous().to(DEV), "cam_extr": extr.contiguous().to(DEV),
+             "master_id": [0] * len(v), "cam_view_num": np.asarray(v, dtype=np.int64)}
+        items.append((pool[:bn], m, rj_all[:len(v)].contiguous()))
+    with torch.no_grad():
+        head(*max(items, key=lambda it: len(it[1]["cam_view_num"])))      # the grow-only workspace at its high-water mark (the
+        head(*items[0])                                                   # workspace pointer is part of a graph's key)
+        eng = head._engine
+        before = eng.graph_stats()
+        outs = [head(*it)["all_coords_preds"].clone() for it in items]
+        torch.cuda.synchronize()
+        after = eng.graph_stats()
+        eng.set_option("graphs", 0)
+        for it, want in zip(items, outs):
+            assert torch.equal(head(*it)["all_coords_preds"], want), it[1]["cam_view_num"]
+        eng.set_option("graphs", 1)
+    d = {k: after[k] - before[k] for k in after}
+    # three batch sizes -> at most three captures (each at the second sight of its key), at most three instantiations (fewer
+    # when a parked exec of an earlier head of this process is taken over); everything else is a replay
+    assert d["captures"] <= 3 and d["instantiations"] <= 3, d
+    assert d["replays"] >= 300 - 6 and d["plain_forwards"] <= 6, d
+    assert d["layout_uploads"] == 300 - 1 or d["layout_uploads"] == 300, d      # (items[0] was the layout already resident)
+    assert after["cached_execs"] <= 3 and after["parked_execs"] <= before["parked_execs"], (before, after)
+    assert after["exec_update_refusals"] == before["exec_update_refusals"], (before, after)
+
+
+def test_retired_graph_execs_are_reused_not_accumulated():
+    """Heads come and go (engine rebuilds after load_state_dict, test suites, periodic evaluation): a destroyed handle parks its
+    graph execs -- they cannot be destroyed on this runtime (csrc/handle.cpp) -- and the next capture of the same shape takes
+    one over through hipGraphExecUpdate.  Ten head life cycles must not grow the parked list beyond what one cycle leaves, and
+    the re-used execs must compute the same bits as fresh ones."""
+    import gc
+    spec = dict(embed=128, nsample=4096, views=[2, 3], seed=72, parametric=False)
+    cfg, w, consts, batch = case_setup(spec)
+    feat, metas, rj = batch_to(batch, DEV)
+    want, parked, stats = None, [], None
+    for cycle in range(10):
+        head = build_hip_head(spec, DEV)
+        with torch.no_grad():
+            for _ in range(3):
+                out = head(feat, metas, rj)["all_coords_preds"]
+        torch.cuda.synchronize()
+        stats = head._engine.graph_stats()
+        assert stats["replays"] >= 1, stats
+        want = out.clone() if want is None else want
+        assert torch.equal(out, want), cycle
+        del head, out
+        gc.collect()
+        parked.append(stats["parked_execs"])
+    assert stats["exec_reuses"] >= 8 or stats["exec_update_refusals"] == 0, stats
+    assert max(parked) <= parked[1] + 1, parked          # steady state after the first cycle
 
 
 def _full_size_properties(spec, n_oracle=1):

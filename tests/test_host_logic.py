@@ -108,6 +108,35 @@ def test_head_refuses_training():
         head(b["mlvl_feat"], b["img_metas"], b["reference_joints"])                  # train mode under no_grad (validation inside a training script)
 
 
+def test_engine_is_rebuilt_when_a_parameter_object_is_replaced(monkeypatch):
+    """The engine holds packed copies of the weights and raw pointers into the Parameters: any way a weight can change must
+    rebuild it -- in-place edits (version counter), load_state_dict, .data swaps, and a Parameter OBJECT being replaced
+    (load_state_dict(assign=True), `module.weight = nn.Parameter(...)`), which a cached list of Parameter objects cannot see."""
+    built = []
+
+    class FakeEngine:
+        def __init__(self, cfg, weights, *a):
+            built.append(float(weights["input_proj.weight"].flatten()[0]))
+
+    monkeypatch.setattr(hip, "Engine", FakeEngine)
+    head = pk.build_head(pk.configs.model_head_cfg("small"), data_preset=pk.CN({})).eval()
+    head._engine_for("cpu"); head._engine_for("cpu")
+    assert len(built) == 1
+    with torch.no_grad():
+        head.input_proj.weight.mul_(2.0)                                  # in place: version counter
+    head._engine_for("cpu")
+    assert len(built) == 2
+    head.input_proj.weight = torch.nn.Parameter(torch.full_like(head.input_proj.weight, 3.0))     # the object is replaced
+    head._engine_for("cpu")
+    assert len(built) == 3 and built[-1] == 3.0
+    sd = {k: torch.full_like(v, 5.0) for k, v in head.state_dict().items()}
+    head.load_state_dict(sd, assign=True)
+    head._engine_for("cpu")
+    assert len(built) == 4 and built[-1] == 5.0
+    head._engine_for("cpu")
+    assert len(built) == 4
+
+
 # ---- C ABI ------------------------------------------------------------------------------------------------------
 def _header_functions():
     txt = open(os.path.join(ROOT, "include", "poem_hip.h")).read()
