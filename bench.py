@@ -203,6 +203,25 @@ def fresh_layout_scope(head, dev, B, rule, steps, warmup=6):
             "graph_cache_after": {k2: g1[k2] for k2 in ("cached_execs", "parked_execs", "exec_reuses", "exec_update_refusals")}}
 
 
+def time_leg_streams(head, batches, steps, warmup, nstreams=2):
+    """Mean seconds per forward with consecutive forwards issued round-robin on ``nstreams`` torch streams: the head keeps
+    one engine (workspace, layout arrays, side streams, launch graphs) per stream, so forward k + 1 does not wait for
+    forward k and the two share the chip -- throughput of a small-batch evaluation loop, not the latency of a forward."""
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for i in range(warmup * nstreams):
+            with torch.cuda.stream(streams[i % nstreams]):
+                head(*batches[i % len(batches)][:3])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            with torch.cuda.stream(streams[i % nstreams]):
+                head(*batches[i % len(batches)][:3])
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` without a launcher: start the N ranks here (torch.distributed.run, one process per GPU,
     rendezvous on 127.0.0.1) instead of silently measuring one.  Refuses loudly when the box has fewer GPUs -- unless
@@ -659,10 +678,17 @@ def main():
                     lat = (time.perf_counter() - t0) / 10
                 small[name] = {"samples_per_s": n / sec, "ms_per_forward": sec * 1e3, "ms_per_forward_synced": lat * 1e3,
                                "views_total": int(sum(vws)), "frac_of_headline_per_sample_rate": (n / sec) / value}
+                if n <= 8:
+                    sec2 = time_leg_streams(head, b2, steps=max(20, 160 // n), warmup=5, nstreams=2)
+                    small[name]["two_streams"] = {"samples_per_s": n / sec2, "ms_per_forward_throughput": sec2 * 1e3,
+                                                  "frac_of_headline_per_sample_rate": (n / sec2) / value}
                 del b2
             small["note"] = ("POEM-medium head, 8 views (or ragged), batch B per forward, back-to-back forwards on resident inputs "
                              "(`ms_per_forward`; `_synced`: a device sync after every forward = latency incl. host enqueue); "
-                             "`frac_of_headline_per_sample_rate` = this batch's samples/s over the batch-32 headline's")
+                             "`frac_of_headline_per_sample_rate` = this batch's samples/s over the batch-32 headline's; "
+                             "`two_streams`: the same forwards issued alternately on two torch streams (one engine per stream, "
+                             "head.py): consecutive forwards overlap on the GPU -- the throughput of a small-batch evaluation loop; "
+                             "the latency of one forward is `ms_per_forward_synced`")
         except Exception as e:   # informational: never fail the bench line on it
             small["error"] = repr(e)[:200]
         res["small_batch_scope"] = small

@@ -116,7 +116,13 @@ struct DecoderRun {
     const int modes[6] = {1, 2, 1, 2, 0, 0};
     h->kv_presplit[i] = poem_gemm_split_applies(f.w[0], BS, C, C) != 0;      // split GEMM -> the K / V images are split too
     const bool anchored = tables && i == 0;
-    HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, anchored ? 4 : 6, outs, modes, sb));
+    if (!anchored && h->f1_split && C % 128 == 0) {
+      HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, 4, outs, modes, sb));
+      HIPCHK(poem_launch_gemm_segs(pt_feats, C, (const float*)f.w[0] + (size_t)4 * C * C, f.b[0] + 4 * C, BS, C, POEM_ACT_NONE, C, 2, outs + 4,
+                                   modes + 4, sb));
+    } else {
+      HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, anchored ? 4 : 6, outs, modes, sb));
+    }
     if (anchored) {
       // the vector cross attention of block 0 reads only the 32 anchor rows of (kc | vc): project just those (the same
       // fma chain per element as the full GEMM's rows)
@@ -126,6 +132,19 @@ struct DecoderRun {
     }
     if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));
     return POEM_OK;
+  }
+
+  // F1 of block i + 1 behind stage `at` of block i's cross attentions (poem_handle_s::bps_defer)
+  int defer_at() const {
+    if (!ov || !chain) return 0;
+    if (h->bps_defer >= 0) return h->bps_defer;
+    return 0;
+  }
+  int deferred_basis_point_side(int i, int at) {
+    if (defer_at() != at || i + 1 >= c.nblocks) return POEM_OK;
+    HIPCHK(hipEventRecord(h->ev_def[i], s));
+    HIPCHK(hipStreamWaitEvent(sb, h->ev_def[i], 0));
+    return basis_point_side(i + 1);
   }
 
   // ---- neighbours of block i >= 1 from xyz_i (block 0: the fixed anchors for both attentions -- Q2).  The large search
@@ -196,6 +215,7 @@ struct DecoderRun {
         a.pc_heads = c.heads; a.pc_chunks = pchunks; a.pc_nq = Q; a.pc_kc2 = pkc2;
       };
       HIPCHK(attention(q0, 2 * C, q_batch, p.y1[i], p.y1[i] + (size_t)BS * C));
+      if (const int rc = deferred_basis_point_side(i, 1); rc != POEM_OK) return rc;
       ChainArgs ca = chain_args(0);
       ca.x = p.ctx; ca.ldx = C;
       from_partials(ca);
@@ -204,6 +224,7 @@ struct DecoderRun {
       ca.w2 = (const float4*)h->P(a2 + 0); ca.b2 = h->R(a2 + 1); ca.n2 = 1; ca.y2 = p.qp; ca.ldy2 = C;
       HIPCHK(poem_launch_chain(&ca, C, s));
       HIPCHK(attention(p.qp, C, Q, p.y1[i] + (size_t)2 * BS * C, p.y1[i] + (size_t)3 * BS * C));
+      if (const int rc = deferred_basis_point_side(i, 2); rc != POEM_OK) return rc;
       ChainArgs cb = chain_args(0);
       cb.x = p.ctx; cb.ldx = C;
       from_partials(cb);
@@ -212,6 +233,7 @@ struct DecoderRun {
       // block 0 on the tables needs qg for every row and (kg | v) for the anchor rows only
       cb.w2 = (const float4*)h->fused[i].w[2]; cb.b2 = h->fused[i].b[2]; cb.n2 = (tables && i == 0) ? 1 : 3; cb.y2 = p.y3; cb.ldy2 = 3 * C;
       HIPCHK(poem_launch_chain(&cb, C, s));
+      if (const int rc = deferred_basis_point_side(i, 3); rc != POEM_OK) return rc;
       hidden = p.h_cross[i];
       ldh = C;
       if (tables && i == 0) return anchor_rows_f3(i);
@@ -372,8 +394,8 @@ struct DecoderRun {
   int run() {
     int rc = fork();
     if (rc != POEM_OK) return rc;
-    if (ov)          // the basis-point side of every block up front on its stream
-      for (int i = 0; i < c.nblocks; ++i)
+    if (ov)          // the basis-point side of every block up front on its stream (or block 0's only: defer_at())
+      for (int i = 0; i < (defer_at() ? 1 : c.nblocks); ++i)
         if ((rc = basis_point_side(i)) != POEM_OK) return rc;
     for (int i = 0; i < c.nblocks; ++i) {
       idx_s = idx_c = h->anchor_idx;       // block 0: the fixed anchors for both attentions (Q2)

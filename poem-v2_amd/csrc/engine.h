@@ -168,7 +168,17 @@ struct poem_handle_s {
   bool tables_pending = false;       // this forward built the tables on the side stream: consumers wait for ev_tab
   float* tab_mem = nullptr;
   float *c_canon_xyz = nullptr, *c_tab_g[2] = {}, *c_tab_p[2] = {};
-  hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {};
+  hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {}, ev_def[8] = {};
+  // When the basis-point side (F1) of block i + 1 is issued: 0 = every block's up front, beside block 0 (large batches: the
+  // matrix pipe is the limit either way); 1 / 2 / 3 = behind block i's first / second cross attention / its chain -- a small
+  // batch leaves most CUs idle there, and block 0's own cross attention no longer shares the chip with the later blocks' GEMMs;
+  // -1 = by batch size (decoder.cpp)
+  int bps_defer = -1;
+  bool gemm_xcd_map = true;  // panel GEMM: XCD-aware block map (gemm.hip PanelSegs::xcd_map); part of the graph key
+  // F1 of blocks >= 1 as two launches -- the four attention images (4C columns) and the vector cross attention's (k | v) rows
+  // (2C columns): 8 and 4 panels divide an XCD's 32 CUs evenly (12 do not), so both take the XCD-aware map
+  bool f1_split = true;
+  bool gemm_kslab = true;    // K >= 512 Linears on the K-slab kernel (gemm.hip); part of the graph key
   bool overlap = true;
   // Per-view index arrays (view_offsets | view_sample | pe_index) live in handle-owned device memory and are re-uploaded
   // only when the batch's view layout changes: a pageable H2D copy blocks the host until the stream reaches it, i.e.

@@ -190,7 +190,7 @@ struct HeadRun {
     if (!h->graphs || h->graph_broken || !fused_fe || h->prof_on || h->tables_pending || !h->cap_stream) return 0;
     const std::vector<int64_t> key = {B, plan_views, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
                                       h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
-                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch};
+                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, h->gemm_xcd_map, h->f1_split, h->gemm_kslab};
     poem_handle_s::GraphEntry* hit = nullptr;
     for (auto& g : h->graph_cache)
       if (g.key == key) { hit = &g; break; }
@@ -259,7 +259,7 @@ struct HeadRun {
     uint64_t v = (uint64_t)c.embed | (uint64_t)c.nblocks << 12 | (uint64_t)c.parametric << 16 | (uint64_t)h->anchor_tables << 17 |
                  (uint64_t)h->chains << 18 | (uint64_t)h->chain_combine << 19 | (uint64_t)h->knn_early << 20 | (uint64_t)h->overlap << 21 |
                  (uint64_t)h->xattn_merge << 22 | (uint64_t)h->tables_cached << 23 | (uint64_t)h->small_batch << 24 |
-                 (uint64_t)(h->precision & 3) << 26 | (uint64_t)c.heads << 28 | (uint64_t)(c.nsample / 32) << 36;
+                 (uint64_t)(h->precision & 3) << 26 | (uint64_t)((h->bps_defer + 1) & 7) << 44 | (uint64_t)h->f1_split << 47 | (uint64_t)c.heads << 28 | (uint64_t)(c.nsample / 32) << 36;
     return v;
   }
 };

@@ -296,6 +296,163 @@ extern "C" hipError_t poem_launch_gemm2(const float* X, int ldx, const void* Wp,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// K-slab GEMM (round 4; the Linears of POEM-huge, K = 1024 / 4096, on 6-33 K rows): the whole-K W panel of the panel kernel
+// below does not fit LDS there (one 32-column tile = 128 KB at K = 1024), and the operands-from-L2 kernel above ran those
+// shapes at 0.27 of the matrix pipe -- 800 wave tiles for 1024 SIMDs, one chunk of prefetch against an L2 / MALL round trip.
+// Here a block of 8 waves owns 8 * MT * 32 rows x NT * 32 columns and walks K in SLABS of SKC k-chunks: the slab's NT * SKC
+// weight fragments are staged through LDS once per block (double-buffered: the next slab's loads are in flight during the
+// current slab's MFMAs, one barrier per slab) and read by all eight waves as conflict-free ds_read_b128; only the X
+// fragments come through the vector memory path, one chunk ahead.  Two blocks per CU (64 KB each) = four waves per SIMD.
+// The k-order of every output element's fma chain is the panel kernel's and gemm2's: bit-identical results.
+template <int MT, int NT, int SKC>
+__global__ __launch_bounds__(512, 2) void gemm_kslab_kernel(const float* __restrict__ X, int ldx, const float4* __restrict__ Wp,
+                                                            const float* __restrict__ bias, const float* __restrict__ R, int ldr,
+                                                            float* __restrict__ Y, int ldy, int M, int N, int K, int act,
+                                                            int act_split, int act2) {
+  constexpr int FRAGS = NT * SKC;                  // 1 KiB fragments per slab
+  constexpr int PER = FRAGS / 8;                   // fragments each wave copies per slab
+  static_assert(FRAGS % 8 == 0, "a slab is dealt to the eight waves");
+  extern __shared__ __attribute__((aligned(16))) float4 ws[];      // 2 x FRAGS x 64 float4
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int KC = K >> 3, nslab = KC / SKC;
+  // column blocks fastest: the blocks that share an X row range are neighbours in launch order (same L2 / MALL lines)
+  const int ncb = N / (32 * NT);
+  const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;
+  const int mt0 = (rb * 8 + wv) * MT;
+  const float4* wsrc = Wp + (size_t)(cb * NT) * KC * 64 + lane;
+  const __amdgpu_buffer_rsrc_t xrs = frag_rsrc(X, 0xffffffffu);
+  unsigned xo[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) xo[i] = (unsigned)min((mt0 + i) * 32 + r, M - 1) * (unsigned)(ldx * 4) + 16u * h;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[i][n] = zero16();
+
+  float4 stage[PER];
+  // fragment f = wv * PER + j of a slab: column tile f / SKC, chunk f % SKC
+#define KS_FETCH(SL)                                                                                     \
+  _Pragma("unroll") for (int j = 0; j < PER; ++j) {                                                      \
+    const int f_ = wv * PER + j;                                                                         \
+    stage[j] = wsrc[((size_t)(f_ / SKC) * KC + (size_t)(SL) * SKC + f_ % SKC) * 64];                      \
+  }
+#define KS_COMMIT(BUF)                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < PER; ++j) ws[((BUF) * FRAGS + wv * PER + j) * 64 + lane] = stage[j];
+  KS_FETCH(0)
+  KS_COMMIT(0)
+  __syncthreads();
+  // X fragments: a ring of four chunks in flight (a chunk is only 4 * MT * NT MFMAs -- 512 cycles at MT = 1 -- against an
+  // L2 / MALL round trip of a few thousand), named registers so that nothing is rotated through copies
+  float4 a0[MT], a1[MT], a2[MT], a3[MT];
+#define KS_LOADA(A, KCI) { const int kq_ = min((KCI), KC - 1); _Pragma("unroll") for (int i = 0; i < MT; ++i) A[i] = frag_load(xrs, (int)xo[i], kq_ * 32); }
+#define KS_MMA(A, WB, KL)                                                                                \
+  {                                                                                                      \
+    float4 b_[NT];                                                                                       \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) b_[n] = (WB)[(n * SKC + (KL)) * 64 + lane];            \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                        \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                     \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][n] = mfma32((&A[i].x)[t], (&b_[n].x)[t], acc[i][n]); \
+  }
+  KS_LOADA(a0, 0) KS_LOADA(a1, 1) KS_LOADA(a2, 2)
+  static_assert(SKC % 4 == 0, "the ring is unrolled by four");
+  for (int sl = 0; sl < nslab; ++sl) {
+    const float4* wb = ws + (sl & 1) * FRAGS * 64;
+    KS_FETCH(min(sl + 1, nslab - 1))      // (unconditional: a conditional definition sends the staging registers to scratch)
+    __builtin_amdgcn_sched_barrier(0);
+    const int kc0 = sl * SKC;
+    for (int kl = 0; kl < SKC; kl += 4) {
+      KS_LOADA(a3, kc0 + kl + 3)
+      __builtin_amdgcn_sched_barrier(0);
+      KS_MMA(a0, wb, kl)
+      __builtin_amdgcn_sched_barrier(0);
+      KS_LOADA(a0, kc0 + kl + 4)
+      __builtin_amdgcn_sched_barrier(0);
+      KS_MMA(a1, wb, kl + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      KS_LOADA(a1, kc0 + kl + 5)
+      __builtin_amdgcn_sched_barrier(0);
+      KS_MMA(a2, wb, kl + 2)
+      __builtin_amdgcn_sched_barrier(0);
+      KS_LOADA(a2, kc0 + kl + 6)
+      __builtin_amdgcn_sched_barrier(0);
+      KS_MMA(a3, wb, kl + 3)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (sl + 1 < nslab) { KS_COMMIT((sl + 1) & 1) }
+    __syncthreads();
+  }
+#undef KS_FETCH
+#undef KS_COMMIT
+#undef KS_LOADA
+#undef KS_MMA
+  const int col0 = cb * NT * 32;
+  const int pact = (col0 >= act_split) ? act2 : act;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int col = col0 + n * 32 + r;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int row0 = (mt0 + i) * 32 + 4 * h;
+      if (row0 >= M) continue;
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        v[e] = acc[i][n][e] + bv;
+        if (pact == 1) v[e] = fmaxf(v[e], 0.f);
+        if (pact == 2) v[e] = gelu_erf(v[e]);
+      }
+      if (row0 + 28 < M) {          // whole tile in range (rows row0 + {0..3} + 8 {0..3})
+        float* yl = Y + (size_t)row0 * ldy + col;
+        if (R) {
+          const float* rl = R + (size_t)row0 * ldr + col;
+          float rr[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) rr[e] = rl[(size_t)((e & 3) + 8 * (e >> 2)) * ldr];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) yl[(size_t)((e & 3) + 8 * (e >> 2)) * ldy] = v[e] + rr[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) yl[(size_t)((e & 3) + 8 * (e >> 2)) * ldy] = v[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row0 + (e & 3) + 8 * (e >> 2);
+          if (row < M) Y[(size_t)row * ldy + col] = v[e] + (R ? R[(size_t)row * ldr + col] : 0.f);
+        }
+      }
+    }
+  }
+}
+
+// shapes the K-slab kernel takes: 64-column blocks, 128-deep slabs, 16-byte aligned rows within the 4 GiB of a buffer descriptor
+static bool kslab_applies(const float* X, int ldx, int M, int N, int K, int act_split) {
+  return K >= 512 && K % 128 == 0 && N % 64 == 0 && (act_split >= N || act_split % 64 == 0) && !((uintptr_t)X & 15) && ldx % 4 == 0 &&
+         (unsigned long long)M * ldx * 4ull < (1ull << 32) && M >= 512;
+}
+
+static hipError_t launch_gemm_kslab(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr, float* Y,
+                                    int ldy, int M, int N, int K, int act, int act_split, int act2, hipStream_t s) {
+  constexpr int NT = 2, SKC = 16;
+  const int mtiles = (M + 31) / 32, ncb = N / (32 * NT);
+  // 256-row blocks (MT = 1) unless 512-row blocks (MT = 2: half the LDS reads per MFMA) still give every CU two blocks
+  const bool mt2 = (long)((mtiles + 15) / 16) * ncb >= 2 * poem_device_cus();
+  const size_t lds = (size_t)2 * NT * SKC * 1024;
+  if (mt2) {
+    auto kern = gemm_kslab_kernel<2, NT, SKC>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(((mtiles + 15) / 16) * ncb)), dim3(512), lds, s, X, ldx, (const float4*)Wp, bias, R, ldr, Y, ldy,
+                       M, N, K, act, act_split, act2);
+  } else {
+    auto kern = gemm_kslab_kernel<1, NT, SKC>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(((mtiles + 7) / 8) * ncb)), dim3(512), lds, s, X, ldx, (const float4*)Wp, bias, R, ldr, Y, ldy,
+                       M, N, K, act, act_split, act2);
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Panel GEMM (the workhorse for K <= 512): one persistent block per CU keeps a W panel of NT column tiles x K resident
 // in LDS (fragment order, conflict-free ds_read_b128) and its 8 waves (2 per SIMD) stream row groups of MT x 32 rows:
 // the only global traffic of the main loop is the X operand (16-byte fragment loads, one chunk ahead), so L2 carries
@@ -315,6 +472,12 @@ struct PanelSegs {
   int mode[6];
   int seg_cols;
   int split_images;      // split variant only: write the K / V images as hi | lo f16 chunk operands (head dims 32 / 64)
+  // XCD-aware block -> (rows, panel) map (launch_panel_t sets it when the grid divides evenly): the blocks of XCD x = blockIdx % 8
+  // own the x-th eighth of the row groups and, among themselves, take every panel of those rows -- an X row tile is fetched
+  // from HBM once, by the first panel-block of the XCD that reaches it, and served from that XCD's L2 to the others.  With the
+  // plain map (panel = blockIdx % panels) the panel-blocks of a row range sit on all eight XCDs and each L2 fetches X for
+  // itself: 9.6x the algorithmic X traffic on the F1 GEMM (profiles/r03_pmc.json).
+  int xcd_map;
 };
 
 template <int NT, int MT, bool GELU, int OMODE, bool SPLIT = false>
@@ -322,7 +485,7 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
                                            const float* __restrict__ bias, const float* __restrict__ R, int ldr,
                                            float* __restrict__ Y, int ldy, int M, int K, int pact, int col0, int ycol0,
                                            int bip, int blocks_in_panel, const float* __restrict__ tile_scales = nullptr,
-                                           int scale_stride = 0, int split_images = 0) {
+                                           int scale_stride = 0, int split_images = 0, int part = 0, int nparts = 1) {
   constexpr int NWV = (SPLIT && !GELU) ? POEM_GS_WAVES : 8;      // split variant: 3 waves per SIMD (<= 170 VGPRs)
   const int KC = K >> 3;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -333,7 +496,9 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
 #pragma unroll
   for (int n = 0; n < NT; ++n) bv[n] = (bias && OMODE != 1) ? bias[col0 + n * 32 + r] : 0.f;
   const size_t lane_yo = (size_t)(4 * h) * ldy + r, lane_ro = (size_t)(4 * h) * ldr + r;
-  for (int rg = bip * NWV + wv; rg < rgroups; rg += blocks_in_panel * NWV) {
+  // (part / nparts: this block's share of the row groups -- the XCD's range under PanelSegs::xcd_map)
+  const int rg_lo = (int)((long)rgroups * part / nparts), rg_hi = (int)((long)rgroups * (part + 1) / nparts);
+  for (int rg = rg_lo + bip * NWV + wv; rg < rg_hi; rg += blocks_in_panel * NWV) {
     const int mt0 = rg * MT;
     // X fragments through the buffer descriptor: per-lane byte offset (row, half) computed once per row group, the
     // k-chunk offset is scalar -- no VALU address arithmetic inside the MFMA loop
@@ -561,8 +726,11 @@ __global__ __launch_bounds__((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512, 2) voi
   extern __shared__ __attribute__((aligned(16))) float4 wl[];   // NT * KC * 64 float4
   const int tid = threadIdx.x;
   const int panels = N / (32 * NT);
-  const int panel = blockIdx.x % panels, bip = blockIdx.x / panels;
-  const int blocks_in_panel = ((int)gridDim.x - panel + panels - 1) / panels;
+  const int xm = segs.xcd_map;
+  const int lb = xm ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;           // xcd_map: slot within the XCD
+  const int panel = lb % panels, bip = lb / panels;
+  const int blocks_in_panel = xm ? (int)(gridDim.x >> 3) / panels : ((int)gridDim.x - panel + panels - 1) / panels;
+  const int part = xm ? (int)(blockIdx.x & 7) : 0, nparts = xm ? 8 : 1;
   {
     const float4* src = Wp + (size_t)panel * NT * KC * 64;
     for (int i = tid; i < NT * KC * 64; i += NWV * 64) wl[i] = src[i];
@@ -572,7 +740,7 @@ __global__ __launch_bounds__((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512, 2) voi
   const int pact = (col0 >= act_split) ? act2 : act;
   if (segs.seg_cols == 0) {
     panel_rows<NT, MT, GELU, 0, SPLIT>(X, ldx, wl, bias, R, ldr, Y, ldy, M, K, pact, col0, col0, bip, blocks_in_panel,
-                                       tile_scales, scale_stride);
+                                       tile_scales, scale_stride, 0, part, nparts);
     return;
   }
   const int sidx = col0 / segs.seg_cols;
@@ -582,16 +750,20 @@ __global__ __launch_bounds__((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512, 2) voi
   // (the image modes exist in the activation-free instantiation only: the launcher sends segmented GEMMs there)
   if (!GELU && mode == 1)
     panel_rows<NT, MT, false, 1, SPLIT>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip,
-                                        blocks_in_panel, tile_scales, scale_stride, segs.split_images);
+                                        blocks_in_panel, tile_scales, scale_stride, segs.split_images, part, nparts);
   else if (!GELU && mode == 2)
     panel_rows<NT, MT, false, 2, SPLIT>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip,
-                                        blocks_in_panel, tile_scales, scale_stride, segs.split_images);
+                                        blocks_in_panel, tile_scales, scale_stride, segs.split_images, part, nparts);
   else
     panel_rows<NT, MT, GELU, 0, SPLIT>(X, ldx, wl, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, col0, ycol0, bip,
-                                       blocks_in_panel, tile_scales, scale_stride);
+                                       blocks_in_panel, tile_scales, scale_stride, 0, part, nparts);
 }
 
 static int poem_num_cus() { return poem_device_cus(); }
+static int g_kslab = 1;                            // A/B switch (poem_set_option "gemm_kslab"; process-wide, scheduling only)
+extern "C" void poem_gemm_kslab(int on) { g_kslab = on; }
+static int g_panel_xcd_map = 1;                    // A/B switch (poem_set_option "gemm_xcd_map"; process-wide, scheduling only)
+extern "C" void poem_gemm_xcd_map(int on) { g_panel_xcd_map = on; }
 
 template <int NT, int MT, bool GELU, bool SPLIT = false>
 static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr,
@@ -604,8 +776,13 @@ static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const 
   if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), 128 * 1024, optin); e != hipSuccess) return e;
   const int panels = N / (32 * NT);
   const int grid = std::max(poem_num_cus(), panels);
+  PanelSegs sg = segs;
+  // XCD-aware map: every XCD's blocks (grid / 8, one per CU) divide evenly over the panels and there is enough work for
+  // eight row ranges (rows of a range are dealt to (blocks per panel) x 8 waves x MT tiles)
+  const int mtiles = (M + 31) / 32;
+  sg.xcd_map = g_panel_xcd_map && grid % 8 == 0 && (grid / 8) % panels == 0 && mtiles >= 8 * ((grid / 8) / panels) * 8 * MT;
   hipLaunchKernelGGL(kern, dim3(grid), dim3((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512), lds, s, X, ldx, (const float4*)Wp, bias, R,
-                     ldr, Y, ldy, M, N, K, act, act_split, act2, segs, tile_scales, scale_stride);
+                     ldr, Y, ldy, M, N, K, act, act_split, act2, sg, tile_scales, scale_stride);
   return hipGetLastError();
 }
 
@@ -618,8 +795,12 @@ static hipError_t launch_gemm_split_impl(const float* X, int ldx, const void* Wp
   for (int c : {4, 2, 1})
     if (N % (32 * c) == 0 && (size_t)c * K * 128 <= 128 * 1024 && (act_split >= N || act_split % (32 * c) == 0) &&
         (!seg || segs.seg_cols % (32 * c) == 0)) { NT = c; break; }
-  // deep K leaves room for a single 32-column tile per panel, which re-reads X every 8 MFMAs: the operands-from-L2
-  // kernel is faster there (ffn output Linear, K = 4C)
+  // deep K leaves room for a single 32-column tile per panel, which re-reads X every 8 MFMAs: the K-slab kernel (weights
+  // staged through LDS slab by slab) takes those shapes -- POEM-huge's Linears, the K = 4C feed-forward output
+  const bool split_mode = g_explicit_split.img || (g_split_ctx.packed && (const char*)Wp >= g_split_ctx.packed &&
+                                                   (const char*)Wp < g_split_ctx.packed + g_split_ctx.bytes);
+  if (!seg && NT <= 1 && !split_mode && g_kslab && kslab_applies(X, ldx, M, N, K, act_split))
+    return launch_gemm_kslab(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s);
   if (!seg && NT == 1 && N >= 64 && K >= 512 && !(act_split < N && act2 != act)) NT = 0;
   if (NT == 0 || K % 8 || ((uintptr_t)X & 15) || ldx % 4 || (unsigned long long)M * ldx * 4ull >= (1ull << 32)) {
     if (seg || (act_split < N && act2 != act) || g_explicit_split.img) return hipErrorInvalidValue;

@@ -20,7 +20,7 @@ thread_local int g_last_hip_error = 0;
 namespace {
 struct CaptureKit {
   hipStream_t cap = nullptr, bps = nullptr, knn = nullptr;
-  hipEvent_t ev[5 + 24] = {};
+  hipEvent_t ev[5 + 32] = {};
 };
 std::mutex g_pool_mutex;
 std::map<int, std::vector<CaptureKit>> g_kit_pool;         // device id -> idle kits
@@ -31,7 +31,7 @@ int64_t g_exec_reuses = 0, g_exec_update_failures = 0;
 hipEvent_t** kit_event_slots(poem_handle_t h, hipEvent_t** out) {
   int n = 0;
   out[n++] = &h->ev_fork; out[n++] = &h->ev_join_bps; out[n++] = &h->ev_join_knn; out[n++] = &h->ev_tab; out[n++] = &h->ev_fork0;
-  for (int i = 0; i < 8; ++i) { out[n++] = &h->ev_bps[i]; out[n++] = &h->ev_xyz[i]; out[n++] = &h->ev_knn[i]; }
+  for (int i = 0; i < 8; ++i) { out[n++] = &h->ev_bps[i]; out[n++] = &h->ev_xyz[i]; out[n++] = &h->ev_knn[i]; out[n++] = &h->ev_def[i]; }
   return out;
 }
 
@@ -39,7 +39,7 @@ bool take_kit(poem_handle_t h) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   h->stream_device = dev;
-  hipEvent_t* slots[5 + 24];
+  hipEvent_t* slots[5 + 32];
   kit_event_slots(h, slots);
   {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
@@ -48,36 +48,36 @@ bool take_kit(poem_handle_t h) {
       const CaptureKit k = pool.back();
       pool.pop_back();
       h->cap_stream = k.cap; h->bps_stream = k.bps; h->knn_stream = k.knn;
-      for (int i = 0; i < 5 + 24; ++i) *slots[i] = k.ev[i];
+      for (int i = 0; i < 5 + 32; ++i) *slots[i] = k.ev[i];
       return true;
     }
   }
   bool ok = hipStreamCreateWithFlags(&h->bps_stream, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithFlags(&h->knn_stream, hipStreamNonBlocking) == hipSuccess &&
             hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) == hipSuccess;
-  for (int i = 0; i < 5 + 24; ++i) ok = ok && hipEventCreateWithFlags(slots[i], hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < 5 + 32; ++i) ok = ok && hipEventCreateWithFlags(slots[i], hipEventDisableTiming) == hipSuccess;
   return ok;
 }
 
 void return_kit(poem_handle_t h) {
-  hipEvent_t* slots[5 + 24];
+  hipEvent_t* slots[5 + 32];
   kit_event_slots(h, slots);
   bool whole = h->cap_stream && h->bps_stream && h->knn_stream;
-  for (int i = 0; i < 5 + 24; ++i) whole = whole && *slots[i] != nullptr;
+  for (int i = 0; i < 5 + 32; ++i) whole = whole && *slots[i] != nullptr;
   if (!whole) {                             // a partly created kit: nothing was captured on it
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->bps_stream) (void)hipStreamDestroy(h->bps_stream);
     if (h->knn_stream) (void)hipStreamDestroy(h->knn_stream);
-    for (int i = 0; i < 5 + 24; ++i) if (*slots[i]) (void)hipEventDestroy(*slots[i]);
+    for (int i = 0; i < 5 + 32; ++i) if (*slots[i]) (void)hipEventDestroy(*slots[i]);
   } else {
     CaptureKit k;
     k.cap = h->cap_stream; k.bps = h->bps_stream; k.knn = h->knn_stream;
-    for (int i = 0; i < 5 + 24; ++i) k.ev[i] = *slots[i];
+    for (int i = 0; i < 5 + 32; ++i) k.ev[i] = *slots[i];
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     g_kit_pool[h->stream_device].push_back(k);
   }
   h->cap_stream = h->bps_stream = h->knn_stream = nullptr;
-  for (int i = 0; i < 5 + 24; ++i) *slots[i] = nullptr;
+  for (int i = 0; i < 5 + 32; ++i) *slots[i] = nullptr;
 }
 
 void park_execs(poem_handle_t h) {
@@ -455,7 +455,11 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "knn_fma") h->knn_fma = value != 0;
   else if (k == "graphs") h->graphs = value != 0;
   else if (k == "graph_eager") h->graph_eager = value != 0;
+  else if (k == "gemm_xcd_map") { poem_gemm_xcd_map(value != 0); h->gemm_xcd_map = value != 0; }
+  else if (k == "f1_split") h->f1_split = value != 0;
+  else if (k == "gemm_kslab") { poem_gemm_kslab(value != 0); h->gemm_kslab = value != 0; }
   else if (k == "small_batch") h->small_batch = value;
+  else if (k == "bps_defer") { if (value < -1 || value > 3) return POEM_E_ARG; h->bps_defer = value; }
   else if (k == "chain_tile") { if (value < 0 || value > 3) return POEM_E_ARG; h->chain_tile = value; }
   else return POEM_E_ARG;
   return POEM_OK;

@@ -77,6 +77,8 @@ hipError_t poem_launch_cross_attention_merged(const float* q, int ldq, int q_bat
                                               int B, int NQ, int NK, int C, int heads, hipStream_t s);
 int poem_gemm_split_applies(const void* Wp, int M, int ldx, int K);
 void poem_gemm_split_images(int on);
+void poem_gemm_xcd_map(int on);
+void poem_gemm_kslab(int on);
 hipError_t poem_launch_vector_attention_split(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                               const int* idx, int shared_idx, const float* q, const float* k,
                                               const float* v, int nsrc, const float* wd1, const float* bd1,

@@ -61,7 +61,9 @@ class POEM_Generalized_Head(nn.Module):
         self._template_is_synthetic = True
         self.mano_layer = None    # callable (pose_aa (B,48), betas (B,10)) -> (verts (B,778,3), joints (B,21,3))
         self.max_views = int(cfg.get("MAX_VIEWS", 10))
-        self._engine = None
+        self._engine = None          # the engine of the most recent forward
+        self._engines = {}           # stream handle -> engine (see _engine_for)
+        self._options = {}
         self._engine_sig = None
 
     # ---- configuration of external inputs -------------------------------------------------------------------
@@ -70,7 +72,7 @@ class POEM_Generalized_Head(nn.Module):
         t = torch.as_tensor(template_xyz, dtype=torch.float32).reshape(799, 3)
         self.template = t.to(self.template.device)
         self._template_is_synthetic = False
-        self._engine = None
+        self._drop_engines()
 
     def set_mano_layer(self, fn):
         self.mano_layer = fn
@@ -82,10 +84,14 @@ class POEM_Generalized_Head(nn.Module):
                                          nblocks=self.transformer.layer_num, parametric=self.parametric_output)
         missing, unexpected = self.load_state_dict(live, strict=False)
         assert not unexpected, unexpected
-        self._engine = None
+        self._drop_engines()
         return ignored
 
     # ---- engine ------------------------------------------------------------------------------------------------
+    def _drop_engines(self):
+        self._engines.clear()
+        self._engine = None
+
     def _live_weights(self):
         sd = self.state_dict()
         shapes = live_key_shapes(self.embed_dims, self.in_channels, 799, self.transformer.layer_num,
@@ -102,26 +108,50 @@ class POEM_Generalized_Head(nn.Module):
         # `_parameters` dicts are cached and read directly: walking the module tree for its 199 parameters costs ~0.3 ms of
         # host time per forward -- more than enqueueing the whole step (a hipGraph replay); reading the dicts costs ~0.06 ms
         # and, unlike a cached list of Parameter objects, sees a Parameter that was REPLACED.
+        #   ONE ENGINE PER STREAM: an engine's workspace, layout arrays and side streams serve one forward at a time, in stream
+        # order.  A caller that alternates small batches over two (or more) torch streams -- the way to fill 256 CUs with batches
+        # of 2, the reference's evaluation batch -- gets one engine per stream, so consecutive forwards overlap on the GPU
+        # (scripts/eval_single.py --streams, bench.py small_batch_scope `two_streams`).  Same kernels, same bits.
         self._pcheck = getattr(self, "_pcheck", 0) + 1
         if getattr(self, "_plist", None) is None or self._pcheck % 256 == 0:
             self._plist = [m._parameters for m in self.modules()]      # (the module set itself: refreshed every 256 forwards)
         sig = (str(device),) + tuple((id(p), p.data_ptr(), p._version) for d in self._plist for p in d.values() if p is not None)
-        if self._engine is None or self._engine_sig != sig:
+        if self._engine_sig != sig:
+            self._engines.clear()
+            self._engine = None
+            self._engine_sig = sig
+        skey = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+        eng = self._engines.get(skey)
+        if eng is None:
+            if len(self._engines) >= self.MAX_STREAM_ENGINES:
+                self._engines.pop(next(iter(self._engines)))
             t = self.transformer
             cfg = hip.make_config(self.embed_dims, in_channels=self.in_channels, nsample=self.nsample, nquery=799,
                                   heads=t.num_attention_heads, nblocks=t.layer_num, parametric=self.parametric_output,
                                   max_views=self.max_views, radius=self.radius, ln_eps=t.layer_norm_eps,
                                   feat_h=self._feat_hw[0], feat_w=self._feat_hw[1])
             bps, anchor, aidx = hip.load_assets(self.nsample)
-            self._engine = hip.Engine(cfg, self._live_weights(), bps, anchor, aidx, self.template, device)
-            self._engine_sig = sig
+            eng = hip.Engine(cfg, self._live_weights(), bps, anchor, aidx, self.template, device)
+            self._engines[skey] = eng
             if self._precision != "fp32":
-                self._engine.set_precision(self._precision)
+                eng.set_precision(self._precision)
             if not self._anchor_tables:
-                self._engine.set_anchor_tables(False)
+                eng.set_anchor_tables(False)
             if not self._chains:
-                self._engine.set_chains(False)
-        return self._engine
+                eng.set_chains(False)
+            for k, v in self._options.items():
+                eng.set_option(k, v)
+        self._engine = eng
+        return eng
+
+    MAX_STREAM_ENGINES = 4
+
+    def set_option(self, name, value):
+        """A/B switch of the library by name (include/poem_hip.h poem_set_option) on every engine of this head."""
+        self._options[name] = int(value)
+        for eng in self._engines.values():
+            eng.set_option(name, int(value))
+        return self
 
     _anchor_tables = True
 
@@ -130,8 +160,8 @@ class POEM_Generalized_Head(nn.Module):
         of both vector attentions once per forward (default) or, ``False``, per sample exactly as the reference evaluates
         them (include/poem_hip.h poem_set_anchor_tables)."""
         self._anchor_tables = bool(flag)
-        if self._engine is not None:
-            self._engine.set_anchor_tables(flag)
+        for eng in self._engines.values():
+            eng.set_anchor_tables(flag)
         return self
 
     _chains = True
@@ -140,8 +170,8 @@ class POEM_Generalized_Head(nn.Module):
         """Query-side Linears / residuals / LayerNorms of a block as LDS-resident row-tile chains (default) or one launch per
         operator (include/poem_hip.h poem_set_chains)."""
         self._chains = bool(flag)
-        if self._engine is not None:
-            self._engine.set_chains(flag)
+        for eng in self._engines.values():
+            eng.set_chains(flag)
         return self
 
     _precision = "fp32"
@@ -152,8 +182,8 @@ class POEM_Generalized_Head(nn.Module):
         if mode not in hip.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(hip.PRECISIONS)}")
         self._precision = mode
-        if self._engine is not None:
-            self._engine.set_precision(mode)
+        for eng in self._engines.values():
+            eng.set_precision(mode)
         return self
 
     _feat_hw = (16, 16)
@@ -185,11 +215,11 @@ class POEM_Generalized_Head(nn.Module):
         assert mlvl_feat.shape[1] == self.in_channels
         if tuple(mlvl_feat.shape[-2:]) != self._feat_hw:
             self._feat_hw = tuple(int(v) for v in mlvl_feat.shape[-2:])
-            self._engine = None
+            self._drop_engines()
         views = np.asarray(img_metas["cam_view_num"]).astype(np.int64)
         if views.max() > self.max_views:
             self.max_views = int(views.max())
-            self._engine = None
+            self._drop_engines()
         if self._template_is_synthetic and not getattr(self, "_warned", False):
             warnings.warn("POEM_Generalized_Head: using the synthetic hand template (MANO assets absent); "
                           "call set_template() with ManoLayer's zero-pose output for real checkpoints")

@@ -49,23 +49,43 @@ CASES = {
                       ln_spread=0.3),
     "medium_hot": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False,
                        gain=2.5, ln_spread=0.3),
-    # round 3.  (i) the same hot cases with the reference's neighbour search rounding its distances the way pytorch3d's
-    # CUDA kernel does (fma-contracted accumulation, ref_harness.KNN_FMA): what a near-tie at rank 32 costs when the third
-    # party rounds differently from the CPU path; (ii) a conditioning sweep of the medium case (gain 1 / 2.5 / 4 / 6, same
-    # seed and views: "medium_hot" is its gain-2.5 point)
-    "small_hot_fma": dict(model="small", embed=128, nsample=4096, views=[3, 2], seed=21, parametric=False, full=False, gain=2.5,
-                          ln_spread=0.3, knn_fma=True),
-    "medium_hot_fma": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False,
-                           gain=2.5, ln_spread=0.3, knn_fma=True),
+    # conditioning sweep of the medium case (gain 1 / 2.5 / 4 / 6, same seed and views: "medium_hot" is its gain-2.5 point)
     "medium_g1": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False, gain=1.0,
                       ln_spread=0.3),
     "medium_g4": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False, gain=4.0,
                       ln_spread=0.3),
     "medium_g6": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False, gain=6.0,
                       ln_spread=0.3),
-    "medium_g4_fma": dict(model="medium", embed=256, nsample=4096, views=[8, 4], seed=22, parametric=False, full=False, gain=4.0,
+    # round 4.  The reference's neighbour search under BOTH roundings of the third party's distance on a case where the
+    # rounding DECIDES a neighbour set: pytorch3d's CPU kernel ((dx*dx + dy*dy) + dz*dz) vs its CUDA kernel
+    # fma(dz, dz, fma(dy, dy, dx*dx)) (ref_harness.KNN_FMA).  Seed 152 was found by tests/golden/find_fma_case.py (a near-tie
+    # at rank 32 of a block-1 self search); run_tie_pair() asserts that the two reference runs really differ.  (Round 3's
+    # small_hot_fma / medium_hot_fma / medium_g4_fma were bit-identical to their non-fma twins -- no near-tie -- and are gone.)
+    "small_tie": dict(model="small", embed=128, nsample=4096, views=[3, 2], seed=152, parametric=False, full=False, gain=2.5,
+                      ln_spread=0.3),
+    "small_tie_fma": dict(model="small", embed=128, nsample=4096, views=[3, 2], seed=152, parametric=False, full=False, gain=2.5,
                           ln_spread=0.3, knn_fma=True),
+    # hot weights at the c4 model (POEM-large): gain 2.5 / sqrt(2) -- the Linears sum over twice the channels of the medium model,
+    # so the same operating point (max |xyz| ~ 1 m, O(1) coordinate updates per block) sits at a lower gain
+    "large_hot": dict(model="large", embed=512, nsample=4096, views=[5, 3], seed=23, parametric=False, full=False, gain=1.8,
+                      ln_spread=0.3),
 }
+
+
+def check_tie_pair():
+    """The point of the small_tie / small_tie_fma pair: the reference's OWN runs under the two roundings pick different
+    neighbour sets somewhere (else the pair tests nothing -- round 3's *_fma fixtures were such duplicates)."""
+    a, b = (np.load(os.path.join(HERE, n + ".npz")) for n in ("small_tie", "small_tie_fma"))
+    diff = {}
+    for k in ("b1.idx_self", "b1.idx_cross", "b2.idx_self", "b2.idx_cross"):
+        sa, sb = np.sort(a["tap." + k], axis=-1), np.sort(b["tap." + k], axis=-1)
+        diff[k] = int((sa != sb).any(axis=-1).sum())
+    assert sum(diff.values()) >= 1, f"the two roundings picked identical neighbour sets: {diff}"
+    assert diff["b1.idx_self"] + diff["b1.idx_cross"] >= 1, diff      # already in block 1, i.e. on bit-identical coordinates
+    assert (a["tap.b0.xyz"] == b["tap.b0.xyz"]).all()
+    d = float(np.abs(a["all_coords_preds"] - b["all_coords_preds"]).max())
+    print(f"tie pair: neighbour sets that differ {diff}; max |all_coords_preds difference| = {d:.3e} m")
+    return diff
 
 
 def make_cwd(nsample):
@@ -82,7 +102,8 @@ def make_cwd(nsample):
     return d
 
 
-def run_case(name, spec):
+def run_reference(spec):
+    """The reference's own head on the case's seeded inputs -> (outputs, stage taps, the seeded state dict)."""
     CN, build_head = rh.setup()
     cfg, y = rh.load_head_cfg(CN, spec["model"])
     C = spec["embed"]
@@ -164,7 +185,11 @@ def run_case(name, spec):
         rh.KNN_FMA = False
         os.chdir(ROOT)
         shutil.rmtree(cwd, ignore_errors=True)
+    return out, taps, sd
 
+
+def run_case(name, spec):
+    out, taps, sd = run_reference(spec)
     blob = hashlib.sha256()
     for k, v in sd.items():
         blob.update(k.encode())
@@ -450,3 +475,5 @@ if __name__ == "__main__":
             run_openpose()
         else:
             run_case(n, CASES[n])
+    if "small_tie" in which or "small_tie_fma" in which:
+        check_tie_pair()

@@ -51,7 +51,7 @@ def test_release_shapes(name):
         assert _maxdiff(out["pred_shape"], z["pred_shape"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["small_hot", "medium_hot"])
+@pytest.mark.parametrize("name", ["small_hot", "medium_hot", "large_hot"])
 def test_hot_weights_oracle_vs_reference(name):
     """Non-benign weights (block Linears x2.5, LayerNorm gains spread 0.3: coordinate updates ~1 normalised unit per block,
     neighbour sets of blocks 1, 2 far from the template's).  The restatement must stay at round-off distance from the
@@ -77,7 +77,7 @@ def test_hot_weights_oracle_vs_reference(name):
         assert err.max() < 1e-6, (layer, err)                    # the 1e-3 mm bar, every layer, every sample
 
 
-ROUND3 = ["small_hot_fma", "medium_hot_fma", "medium_g1", "medium_g4", "medium_g4_fma", "medium_g6"]
+ROUND3 = ["medium_g1", "medium_g4", "medium_g6"]
 
 
 @pytest.mark.parametrize("name", ROUND3)

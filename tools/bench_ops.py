@@ -47,6 +47,22 @@ def gemm_cases():
         print(line, flush=True)
 
 
+def kslab_cases():
+    """POEM-huge's Linears (M = B * 799 query rows or B * 4096 basis-point rows, K = 1024 / 4096): the K-slab kernel (default
+    dispatch of poem_gemm) against the operands-from-L2 kernel (poem_gemm_ex) it replaces there."""
+    for (M, N, K) in [(6392, 1024, 1024), (6392, 2048, 1024), (6392, 3072, 1024), (6392, 5120, 1024), (6392, 1024, 4096),
+                      (32768, 1024, 1024), (12784, 512, 2048)]:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev) / math.sqrt(K)
+        b = torch.randn(N, device=dev)
+        wp = hip.pack_linear(w)
+        fl = 2.0 * M * N * K
+        t0 = timeit(lambda: hip.gemm(x, wp, N, bias=b))
+        t1 = timeit(lambda: hip.gemm_ex(x, wp, M, N, K, bias=b))
+        print(f"M={M:6d} N={N:5d} K={K:5d}  kslab {t0*1e3:8.1f}us {fl/t0/1e9:6.1f}TF ({fl/t0/1e9/157.3:.2f})  |  gemm2 {t1*1e3:8.1f}us "
+              f"{fl/t1/1e9:6.1f}TF ({fl/t1/1e9/157.3:.2f})", flush=True)
+
+
 def vecattn_case(B=32, Q=799, NS=4096, C=256):
     import poem_oracle as po
     g = torch.Generator().manual_seed(0)
@@ -107,4 +123,4 @@ if __name__ == "__main__":
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     which = sys.argv[1:] or ["gemm"]
     for w in which:
-        {"gemm": gemm_cases, "vecattn": vecattn_case, "attn": attn_case, "knn": knn_case, "decode": decode_case}[w]()
+        {"gemm": gemm_cases, "kslab": kslab_cases, "vecattn": vecattn_case, "attn": attn_case, "knn": knn_case, "decode": decode_case}[w]()

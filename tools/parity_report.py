@@ -12,8 +12,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 import torch  # noqa: E402
 from util import batch_to, build_hip_head, case_setup, load_golden, run_oracle, stage_report  # noqa: E402
 
-names = sys.argv[1:] or ["small", "medium", "large", "huge", "ragged", "mediummano", "small_hot", "medium_hot", "small_hot_fma",
-                         "medium_hot_fma", "medium_g1", "medium_g4", "medium_g4_fma", "medium_g6"]
+names = sys.argv[1:] or ["small", "medium", "large", "huge", "ragged", "mediummano", "small_hot", "medium_hot", "large_hot", "medium_g1", "medium_g4", "medium_g6"]
 curve = []
 for name in names:
     z, meta = load_golden(name)

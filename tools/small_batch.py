@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE")
+    ap.add_argument("--streams", type=int, default=1, help="issue consecutive forwards round-robin on this many torch streams")
     ap.add_argument("--sync-each", action="store_true", help="also time with a device sync after every forward (latency)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -46,8 +47,11 @@ def main():
             head(*batches[0][:3])
         for kv in args.option:
             k_, v_ = kv.split("=")
-            head._engine.set_option(k_, int(v_))
-        sec = bench.time_leg(head, batches, steps=args.steps, warmup=args.warmup)
+            head.set_option(k_, int(v_))
+        if args.streams > 1:
+            sec = bench.time_leg_streams(head, batches, steps=args.steps, warmup=args.warmup, nstreams=args.streams)
+        else:
+            sec = bench.time_leg(head, batches, steps=args.steps, warmup=args.warmup)
         rec = {"ms_per_forward": sec * 1e3, "samples_per_s": B / sec, "views_total": int(sum(views))}
         if args.sync_each:
             with torch.no_grad():
