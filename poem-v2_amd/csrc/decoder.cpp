@@ -290,6 +290,7 @@ struct DecoderRun {
       HIPCHK(poem_launch_vector_attention_anchored(p.ident, p.y3, p.anch_kv[0], p.anch_kv[0] + C, 32, h->P(vsb + 10), p.tab_g[0],
                                                    p.tab_p[0], p.rs, B, Q, C, 3 * C, 2 * C, 2 * C, s));
     } else {
+      poem_vecattn_one_query_blocks(h->va_p1);
       HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
                                           h->R(vsb + 5), h->P(vsb + 6), h->R(vsb + 7), h->fused[i].w[5], h->R(vsb + 9),
                                           h->P(vsb + 10), h->R(vsb + 11), p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, 1, s));
@@ -323,6 +324,7 @@ struct DecoderRun {
       HIPCHK(poem_launch_vector_attention_anchored(p.ident, p.qc, p.anch_kv[1], p.anch_kv[1] + C, 32, h->P(vcb + 10), p.tab_g[1],
                                                    p.tab_p[1], p.rc, B, Q, C, C, 2 * C, 2 * C, s));
     } else {
+      poem_vecattn_one_query_blocks(h->va_p1);
       HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
                                           p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4), h->R(vcb + 5), h->P(vcb + 6),
                                           h->R(vcb + 7), h->fused[i].w[6], h->R(vcb + 9), h->P(vcb + 10), h->R(vcb + 11), p.rc, B,

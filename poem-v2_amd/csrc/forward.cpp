@@ -127,6 +127,9 @@ struct HeadRun {
       HIPCHK(poem_launch_invert_extr(cam_extr, inv, BN, s));
       HIPCHK(poem_launch_project_table(h->bps, p.centre, p.view_sample, cam_intr, inv, p.ptab, nullptr, BN, C, c.feat_h, c.feat_w, S,
                                        img_w, img_h, s));
+    } else {      // operator front end: the projection (the caller's cameras) here, the sampling inside the body
+      HIPCHK(poem_launch_project_uv(h->bps, p.centre, p.view_sample, cam_intr, cam_extr, p.uv + (size_t)BN * S * 2, p.uv, BN, c.feat_h,
+                                    c.feat_w, S, img_w, img_h, s));
     }
     return POEM_OK;
   }
@@ -155,8 +158,7 @@ struct HeadRun {
       HIPCHK(poem_launch_gemm(X, ldx, h->P(wi), h->R(bi), nullptr, 0, Y, ldy, M, N, K, act, st));
       return POEM_OK;
     };
-    HIPCHK(poem_launch_project_sample(p.x, h->bps, p.centre, p.view_sample, cam_intr, cam_extr, p.uv + (size_t)BN * S * 2, p.uv, p.g,
-                                      BN, C, c.feat_h, c.feat_w, S, img_w, img_h, st));
+    HIPCHK(poem_launch_grid_sample(p.x, p.uv, p.g, BN, C, c.feat_h, c.feat_w, S, st));
     // merge MLP 0 on the Q1 rows == the (BN*S, C) row-major view of g's memory
     int rc = gemm(p.g, C, T_M00_W, T_M00_B, p.h1, C, BN * S, C, C, POEM_ACT_RELU);
     if (rc == POEM_OK) rc = gemm(p.h1, C, T_M02_W, T_M02_B, p.h2, C / 2, BN * S, C / 2, C, POEM_ACT_NONE);
@@ -187,10 +189,12 @@ struct HeadRun {
   // by a destroyed handle is re-used through hipGraphExecUpdate before a new one is instantiated (handle.cpp: execs are never
   // destroyed).  -> 1 replayed, 0 not eligible / not yet captured / capture failed (plain launches), < 0 error.
   int replay(void* workspace, float* pose_aa, float* betas) {
-    if (!h->graphs || h->graph_broken || !fused_fe || h->prof_on || h->tables_pending || !h->cap_stream) return 0;
-    const std::vector<int64_t> key = {B, plan_views, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
+    if (!h->graphs || h->graph_broken || h->prof_on || h->tables_pending || !h->cap_stream) return 0;
+    // (the operator front end -- embed widths the fused sampling kernels do not take, POEM-huge -- sizes its launches by the
+    //  batch's own view total: that total joins the key there)
+    const std::vector<int64_t> key = {B, plan_views, fused_fe ? -1 : BN, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
                                       h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
-                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, h->gemm_xcd_map, h->f1_split, h->gemm_kslab};
+                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, h->gemm_xcd_map, h->f1_split, h->gemm_kslab, h->va_p1};
     poem_handle_s::GraphEntry* hit = nullptr;
     for (auto& g : h->graph_cache)
       if (g.key == key) { hit = &g; break; }
@@ -217,7 +221,7 @@ struct HeadRun {
       }
       ++h->graph_captures;
       if (ok) {
-        exec = poem_reuse_graph_exec(graph, graph_shape());
+        exec = poem_reuse_graph_exec(graph, graph_shape_of(c, key));
         if (!exec) {
           ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
           ++h->graph_instantiations;
@@ -238,7 +242,7 @@ struct HeadRun {
         poem_park_graph_exec(h->graph_cache[lru].exec, h->graph_cache[lru].shape);      // (not destroyed: handle.cpp)
         h->graph_cache.erase(h->graph_cache.begin() + lru);
       }
-      h->graph_cache.push_back({key, exec, 0, graph_shape()});
+      h->graph_cache.push_back({key, exec, 0, graph_shape_of(c, key)});
       hit = &h->graph_cache.back();
     }
     hit->stamp = ++h->graph_clock;
@@ -253,14 +257,17 @@ struct HeadRun {
     return 1;
   }
 
-  // what decides the TOPOLOGY of the captured body (node count and kinds): a retired exec is offered for update only to a
-  // graph of the same shape
-  uint64_t graph_shape() const {
-    uint64_t v = (uint64_t)c.embed | (uint64_t)c.nblocks << 12 | (uint64_t)c.parametric << 16 | (uint64_t)h->anchor_tables << 17 |
-                 (uint64_t)h->chains << 18 | (uint64_t)h->chain_combine << 19 | (uint64_t)h->knn_early << 20 | (uint64_t)h->overlap << 21 |
-                 (uint64_t)h->xattn_merge << 22 | (uint64_t)h->tables_cached << 23 | (uint64_t)h->small_batch << 24 |
-                 (uint64_t)(h->precision & 3) << 26 | (uint64_t)((h->bps_defer + 1) & 7) << 44 | (uint64_t)h->f1_split << 47 | (uint64_t)c.heads << 28 | (uint64_t)(c.nsample / 32) << 36;
-    return v;
+  // What a retired exec must share with a fresh capture to be offered for update: the model shape and the WHOLE key except the
+  // workspace pointer -- batch size and switches pick kernel instantiations and optional launches (the debug taps keep the
+  // last block's feed-forward alive), and the runtime refuses an update whose nodes changed kind or function.
+  static uint64_t graph_shape_of(const poem_config_t& c, const std::vector<int64_t>& key) {
+    uint64_t v = 1469598103934665603ull;
+    auto mix = [&](uint64_t x) { v = (v ^ x) * 1099511628211ull; };
+    mix((uint64_t)c.embed); mix((uint64_t)c.nblocks); mix((uint64_t)c.heads); mix((uint64_t)c.nsample); mix((uint64_t)c.nquery);
+    mix((uint64_t)c.in_channels); mix((uint64_t)c.feat_h * 65536u + (uint64_t)c.feat_w); mix((uint64_t)c.max_views);
+    for (size_t i = 0; i < key.size(); ++i)
+      if (i != 3) mix((uint64_t)key[i]);          // [3] = the workspace pointer
+    return v ? v : 1;
   }
 };
 

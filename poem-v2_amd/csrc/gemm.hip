@@ -295,6 +295,20 @@ extern "C" hipError_t poem_launch_gemm2(const float* X, int ldx, const void* Wp,
   return launch_gemm2_t<1, 1>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, in_pa, out_pa, s);
 }
 
+// Per-segment outputs of a fused-N GEMM (panel and K-slab kernels; the output modes are described at the panel kernel)
+struct PanelSegs {
+  float* ptr[6];
+  int mode[6];
+  int seg_cols;
+  int split_images;      // split variant only: write the K / V images as hi | lo f16 chunk operands (head dims 32 / 64)
+  // XCD-aware block -> (rows, panel) map (launch_panel_t sets it when the grid divides evenly): the blocks of XCD x = blockIdx % 8
+  // own the x-th eighth of the row groups and, among themselves, take every panel of those rows -- an X row tile is fetched
+  // from HBM once, by the first panel-block of the XCD that reaches it, and served from that XCD's L2 to the others.  With the
+  // plain map (panel = blockIdx % panels) the panel-blocks of a row range sit on all eight XCDs and each L2 fetches X for
+  // itself: 9.6x the algorithmic X traffic on the F1 GEMM (profiles/r03_pmc.json).
+  int xcd_map;
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // K-slab GEMM (round 4; the Linears of POEM-huge, K = 1024 / 4096, on 6-33 K rows): the whole-K W panel of the panel kernel
 // below does not fit LDS there (one 32-column tile = 128 KB at K = 1024), and the operands-from-L2 kernel above ran those
@@ -304,20 +318,17 @@ extern "C" hipError_t poem_launch_gemm2(const float* X, int ldx, const void* Wp,
 // current slab's MFMAs, one barrier per slab) and read by all eight waves as conflict-free ds_read_b128; only the X
 // fragments come through the vector memory path, one chunk ahead.  Two blocks per CU (64 KB each) = four waves per SIMD.
 // The k-order of every output element's fma chain is the panel kernel's and gemm2's: bit-identical results.
-template <int MT, int NT, int SKC>
-__global__ __launch_bounds__(512, 2) void gemm_kslab_kernel(const float* __restrict__ X, int ldx, const float4* __restrict__ Wp,
-                                                            const float* __restrict__ bias, const float* __restrict__ R, int ldr,
-                                                            float* __restrict__ Y, int ldy, int M, int N, int K, int act,
-                                                            int act_split, int act2) {
+// (OMODE: 0 row-major, 1 attention K image -- operands swapped in the MFMA, lane = row --, 2 attention V image; see PanelSegs)
+template <int MT, int NT, int SKC, int OMODE>
+__device__ __forceinline__ void kslab_body(const float* __restrict__ X, int ldx, const float4* __restrict__ Wp,
+                                           const float* __restrict__ bias, const float* __restrict__ R, int ldr,
+                                           float* __restrict__ Y, int ldy, int M, int K, int pact, int cb, int rb, int ycol0) {
   constexpr int FRAGS = NT * SKC;                  // 1 KiB fragments per slab
   constexpr int PER = FRAGS / 8;                   // fragments each wave copies per slab
   static_assert(FRAGS % 8 == 0, "a slab is dealt to the eight waves");
   extern __shared__ __attribute__((aligned(16))) float4 ws[];      // 2 x FRAGS x 64 float4
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
   const int KC = K >> 3, nslab = KC / SKC;
-  // column blocks fastest: the blocks that share an X row range are neighbours in launch order (same L2 / MALL lines)
-  const int ncb = N / (32 * NT);
-  const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;
   const int mt0 = (rb * 8 + wv) * MT;
   const float4* wsrc = Wp + (size_t)(cb * NT) * KC * 64 + lane;
   const __amdgpu_buffer_rsrc_t xrs = frag_rsrc(X, 0xffffffffu);
@@ -352,7 +363,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kslab_kernel(const float* __restr
     _Pragma("unroll") for (int n = 0; n < NT; ++n) b_[n] = (WB)[(n * SKC + (KL)) * 64 + lane];            \
     _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                        \
       _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                     \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i][n] = mfma32((&A[i].x)[t], (&b_[n].x)[t], acc[i][n]); \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                   \
+          acc[i][n] = OMODE == 1 ? mfma32((&b_[n].x)[t], (&A[i].x)[t], acc[i][n]) : mfma32((&A[i].x)[t], (&b_[n].x)[t], acc[i][n]); \
   }
   KS_LOADA(a0, 0) KS_LOADA(a1, 1) KS_LOADA(a2, 2)
   static_assert(SKC % 4 == 0, "the ring is unrolled by four");
@@ -387,10 +399,47 @@ __global__ __launch_bounds__(512, 2) void gemm_kslab_kernel(const float* __restr
 #undef KS_LOADA
 #undef KS_MMA
   const int col0 = cb * NT * 32;
-  const int pact = (col0 >= act_split) ? act2 : act;
+  if (OMODE == 1) {     // D[n][m]: lane = row, register e = channel 8 (e >> 2) + 4 h + (e & 3) of column tile n (panel kernel, mode 1)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if ((mt0 + i) * 32 >= M) break;
+      float4* yp = reinterpret_cast<float4*>(Y) + ((size_t)(mt0 + i) * (ldy >> 3) + (ycol0 >> 3)) * 64 + lane;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v = make_float4(acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
+          if (bias) {
+            const float4 bb = *reinterpret_cast<const float4*>(bias + col0 + n * 32 + 8 * g + 4 * h);
+            v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+          }
+          if (pact == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          yp[(size_t)(n * 4 + g) * 64] = v;
+        }
+    }
+    return;
+  }
+  if (OMODE == 2) {     // registers 4g .. 4g+3 of a lane = four consecutive rows of one column = one float4 of the V image
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const float bv = bias ? bias[col0 + n * 32 + r] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if ((mt0 + i) * 32 >= M) break;
+        float4* yp = reinterpret_cast<float4*>(Y) + ((size_t)(mt0 + i) * (ldy >> 5) + (ycol0 >> 5) + n) * 256 + lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v = make_float4(acc[i][n][4 * g] + bv, acc[i][n][4 * g + 1] + bv, acc[i][n][4 * g + 2] + bv, acc[i][n][4 * g + 3] + bv);
+          if (pact == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          yp[(size_t)g * 64] = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    const int col = col0 + n * 32 + r;
+    const int col = col0 + n * 32 + r, ycol = ycol0 + n * 32 + r;
     const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -404,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kslab_kernel(const float* __restr
         if (pact == 2) v[e] = gelu_erf(v[e]);
       }
       if (row0 + 28 < M) {          // whole tile in range (rows row0 + {0..3} + 8 {0..3})
-        float* yl = Y + (size_t)row0 * ldy + col;
+        float* yl = Y + (size_t)row0 * ldy + ycol;
         if (R) {
           const float* rl = R + (size_t)row0 * ldr + col;
           float rr[16];
@@ -420,11 +469,32 @@ __global__ __launch_bounds__(512, 2) void gemm_kslab_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = row0 + (e & 3) + 8 * (e >> 2);
-          if (row < M) Y[(size_t)row * ldy + col] = v[e] + (R ? R[(size_t)row * ldr + col] : 0.f);
+          if (row < M) Y[(size_t)row * ldy + ycol] = v[e] + (R ? R[(size_t)row * ldr + col] : 0.f);
         }
       }
     }
   }
+}
+
+template <int MT, int NT, int SKC>
+__global__ __launch_bounds__(512, 2) void gemm_kslab_kernel(const float* __restrict__ X, int ldx, const float4* __restrict__ Wp,
+                                                            const float* __restrict__ bias, const float* __restrict__ R, int ldr,
+                                                            float* __restrict__ Y, int ldy, int M, int N, int K, int act,
+                                                            int act_split, int act2, PanelSegs segs) {
+  // column blocks fastest: the blocks that share an X row range are neighbours in launch order (same L2 / MALL lines)
+  const int ncb = N / (32 * NT);
+  const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;
+  const int col0 = cb * NT * 32;
+  const int pact = (col0 >= act_split) ? act2 : act;
+  if (segs.seg_cols == 0) {
+    kslab_body<MT, NT, SKC, 0>(X, ldx, Wp, bias, R, ldr, Y, ldy, M, K, pact, cb, rb, col0);
+    return;
+  }
+  const int sidx = col0 / segs.seg_cols, ycol0 = col0 - sidx * segs.seg_cols, mode = segs.mode[sidx];      // (block-uniform)
+  float* ys = segs.ptr[sidx];
+  if (mode == 1) kslab_body<MT, NT, SKC, 1>(X, ldx, Wp, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, cb, rb, ycol0);
+  else if (mode == 2) kslab_body<MT, NT, SKC, 2>(X, ldx, Wp, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, cb, rb, ycol0);
+  else kslab_body<MT, NT, SKC, 0>(X, ldx, Wp, bias, nullptr, 0, ys, segs.seg_cols, M, K, pact, cb, rb, ycol0);
 }
 
 // shapes the K-slab kernel takes: 64-column blocks, 128-deep slabs, 16-byte aligned rows within the 4 GiB of a buffer descriptor
@@ -434,7 +504,7 @@ static bool kslab_applies(const float* X, int ldx, int M, int N, int K, int act_
 }
 
 static hipError_t launch_gemm_kslab(const float* X, int ldx, const void* Wp, const float* bias, const float* R, int ldr, float* Y,
-                                    int ldy, int M, int N, int K, int act, int act_split, int act2, hipStream_t s) {
+                                    int ldy, int M, int N, int K, int act, int act_split, int act2, const PanelSegs& segs, hipStream_t s) {
   constexpr int NT = 2, SKC = 16;
   const int mtiles = (M + 31) / 32, ncb = N / (32 * NT);
   // 256-row blocks (MT = 1) unless 512-row blocks (MT = 2: half the LDS reads per MFMA) still give every CU two blocks
@@ -443,11 +513,11 @@ static hipError_t launch_gemm_kslab(const float* X, int ldx, const void* Wp, con
   if (mt2) {
     auto kern = gemm_kslab_kernel<2, NT, SKC>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(((mtiles + 15) / 16) * ncb)), dim3(512), lds, s, X, ldx, (const float4*)Wp, bias, R, ldr, Y, ldy,
-                       M, N, K, act, act_split, act2);
+                       M, N, K, act, act_split, act2, segs);
   } else {
     auto kern = gemm_kslab_kernel<1, NT, SKC>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(((mtiles + 7) / 8) * ncb)), dim3(512), lds, s, X, ldx, (const float4*)Wp, bias, R, ldr, Y, ldy,
-                       M, N, K, act, act_split, act2);
+                       M, N, K, act, act_split, act2, segs);
   }
   return hipGetLastError();
 }
@@ -467,18 +537,6 @@ static hipError_t launch_gemm_kslab(const float* X, int ldx, const void* Wp, con
 //   2  V image for attn.hip: plain formulation, registers 4g..4g+3 of a lane are four consecutive rows of one column
 //      = one float4 of the image -> 1 KiB stores
 // The image modes need M % 32 == 0 and carry no residual.
-struct PanelSegs {
-  float* ptr[6];
-  int mode[6];
-  int seg_cols;
-  int split_images;      // split variant only: write the K / V images as hi | lo f16 chunk operands (head dims 32 / 64)
-  // XCD-aware block -> (rows, panel) map (launch_panel_t sets it when the grid divides evenly): the blocks of XCD x = blockIdx % 8
-  // own the x-th eighth of the row groups and, among themselves, take every panel of those rows -- an X row tile is fetched
-  // from HBM once, by the first panel-block of the XCD that reaches it, and served from that XCD's L2 to the others.  With the
-  // plain map (panel = blockIdx % panels) the panel-blocks of a row range sit on all eight XCDs and each L2 fetches X for
-  // itself: 9.6x the algorithmic X traffic on the F1 GEMM (profiles/r03_pmc.json).
-  int xcd_map;
-};
 
 template <int NT, int MT, bool GELU, int OMODE, bool SPLIT = false>
 __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx, const float4* __restrict__ wl,
@@ -799,8 +857,8 @@ static hipError_t launch_gemm_split_impl(const float* X, int ldx, const void* Wp
   // staged through LDS slab by slab) takes those shapes -- POEM-huge's Linears, the K = 4C feed-forward output
   const bool split_mode = g_explicit_split.img || (g_split_ctx.packed && (const char*)Wp >= g_split_ctx.packed &&
                                                    (const char*)Wp < g_split_ctx.packed + g_split_ctx.bytes);
-  if (!seg && NT <= 1 && !split_mode && g_kslab && kslab_applies(X, ldx, M, N, K, act_split))
-    return launch_gemm_kslab(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, s);
+  if (NT <= 1 && !split_mode && g_kslab && kslab_applies(X, ldx, M, N, K, act_split) && (!seg || (segs.seg_cols % 64 == 0 && M % 32 == 0)))
+    return launch_gemm_kslab(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s);
   if (!seg && NT == 1 && N >= 64 && K >= 512 && !(act_split < N && act2 != act)) NT = 0;
   if (NT == 0 || K % 8 || ((uintptr_t)X & 15) || ldx % 4 || (unsigned long long)M * ldx * 4ull >= (1ull << 32)) {
     if (seg || (act_split < N && act2 != act) || g_explicit_split.img) return hipErrorInvalidValue;

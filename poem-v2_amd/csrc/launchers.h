@@ -32,6 +32,10 @@ hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, const float* b
 hipError_t poem_launch_project_sample(const float* x, const float* bps, const float* centre, const int* view_sample,
                                       const float* intr, const float* extr, float* inv_scratch, float* uv, float* g,
                                       int views, int C, int fh, int fw, int S, int img_w, int img_h, hipStream_t s);
+hipError_t poem_launch_project_uv(const float* bps, const float* centre, const int* view_sample, const float* intr,
+                                  const float* extr, float* inv_scratch, float* uv, int views, int fh, int fw, int S, int img_w,
+                                  int img_h, hipStream_t s);
+hipError_t poem_launch_grid_sample(const float* x, const float* uv, float* g, int views, int C, int fh, int fw, int S, hipStream_t s);
 hipError_t poem_launch_merge_reduce(const float* h2, const int* offs, float* m, int B, int S, int HALF, hipStream_t s);
 hipError_t poem_launch_merge_finalize(const float* g, const float* y, const int* offs, float* out, int B, int S, int C,
                                       hipStream_t s);
@@ -79,6 +83,7 @@ int poem_gemm_split_applies(const void* Wp, int M, int ldx, int K);
 void poem_gemm_split_images(int on);
 void poem_gemm_xcd_map(int on);
 void poem_gemm_kslab(int on);
+void poem_vecattn_one_query_blocks(int on);
 hipError_t poem_launch_vector_attention_split(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                               const int* idx, int shared_idx, const float* q, const float* k,
                                               const float* v, int nsrc, const float* wd1, const float* bd1,

@@ -103,43 +103,46 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
 // and stages their K feature rows in LDS ONCE (80 KB at K = 160) instead of every channel tile's wave streaming them from
 // L2 with dependent 4-byte loads; wave w computes channel tiles w, w + NW, ... x 128 pixels with the packed weight
 // fragments as A (1 KiB wave loads) and conflict-free LDS row reads as B.  Same k-ordered fma chain per output element.
-template <int NW>
+// PT = 32-pixel tiles per block: 4 (128 pixels, 80 KB of LDS at K = 160) or, when that leaves most CUs without a block -- a
+// forward of one or two samples is 16-32 such blocks --, 1 (32 pixels, 20 KB: four times the blocks, a quarter of the latency).
+template <int NW, int PT>
 __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __restrict__ feat, const float4* __restrict__ Wp,
                                                              const float* __restrict__ bias, const float* __restrict__ table,
                                                              const int* __restrict__ pe_index, float* __restrict__ x,
                                                              float* __restrict__ xt, int views, int K, int C, int hw) {
-  extern __shared__ __attribute__((aligned(16))) float ftile[];    // K * 128
+  extern __shared__ __attribute__((aligned(16))) float ftile[];    // K * 32 * PT
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int pgroups = hw / 128;
+  constexpr int PX = 32 * PT, F4 = PX / 4;      // pixels per block, float4 per staged feature row
+  const int pgroups = hw / PX;
   const int v = blockIdx.x / pgroups, pg = blockIdx.x % pgroups;
   const int KC = K >> 3, ctiles = C / 32;
   {
     // all of a thread's loads in flight before the first LDS store (a load-store loop waited for every load in turn: ten
     // trips to HBM in a row at the head of every forward)
-    const float* src = feat + (size_t)v * K * hw + pg * 128;
+    const float* src = feat + (size_t)v * K * hw + pg * PX;
     constexpr int STG = 6;
-    for (int i0 = tid; i0 < K * 32; i0 += STG * NW * 64) {
+    for (int i0 = tid; i0 < K * F4; i0 += STG * NW * 64) {
       float4 buf[STG];
 #pragma unroll
       for (int u = 0; u < STG; ++u) {
-        const int i = min(i0 + u * NW * 64, K * 32 - 1);
-        buf[u] = *reinterpret_cast<const float4*>(src + (size_t)(i >> 5) * hw + 4 * (i & 31));
+        const int i = min(i0 + u * NW * 64, K * F4 - 1);
+        buf[u] = *reinterpret_cast<const float4*>(src + (size_t)(i / F4) * hw + 4 * (i % F4));
       }
 #pragma unroll
       for (int u = 0; u < STG; ++u) {
         const int i = i0 + u * NW * 64;
-        if (i < K * 32) reinterpret_cast<float4*>(ftile)[i] = buf[u];
+        if (i < K * F4) reinterpret_cast<float4*>(ftile)[i] = buf[u];
       }
     }
   }
   __syncthreads();
   const float* tab = table ? table + (size_t)pe_index[v] * C * hw : nullptr;
-  const float* fb = ftile + (4 * h) * 128 + r;
+  const float* fb = ftile + (4 * h) * PX + r;
   for (int ct = wv; ct < ctiles; ct += NW) {
     const float4* wp = Wp + (size_t)ct * KC * 64 + lane;
-    f32x16 acc[4];
+    f32x16 acc[PT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    for (int t = 0; t < PT; ++t) acc[t] = zero16();
     // weight fragments four chunks ahead (a chunk is 16 MFMAs = 1024 cycles: less than a trip to HBM / Infinity Cache, which
     // is where the first kernel of a forward finds them)
     float4 a[4];
@@ -154,9 +157,9 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __res
           a[u] = wp[(size_t)min(kc + 4, KC - 1) * 64];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const float* row = fb + (kc * 8 + t) * 128;
+            const float* row = fb + (kc * 8 + t) * PX;
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[pt] = mfma32((&ac.x)[t], row[pt * 32], acc[pt]);
+            for (int pt = 0; pt < PT; ++pt) acc[pt] = mfma32((&ac.x)[t], row[pt * 32], acc[pt]);
           }
         }
       }
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __res
       const int c = ct * 32 + mfma_row(i, h);
       const float bv = bias ? bias[c] : 0.f;
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) {
-        const int p = pg * 128 + pt * 32 + r;
+      for (int pt = 0; pt < PT; ++pt) {
+        const int p = pg * PX + pt * 32 + r;
         float val = acc[pt][i] + bv;
         if (tab) val += tab[(size_t)c * hw + p];
         acc[pt][i] = val;
@@ -176,8 +179,8 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __res
     }
     if (xt) {
 #pragma unroll
-      for (int pt = 0; pt < 4; ++pt) {
-        float* dst = xt + ((size_t)v * hw + pg * 128 + pt * 32 + r) * C + ct * 32 + 4 * h;
+      for (int pt = 0; pt < PT; ++pt) {
+        float* dst = xt + ((size_t)v * hw + pg * PX + pt * 32 + r) * C + ct * 32 + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(acc[pt][4 * g], acc[pt][4 * g + 1], acc[pt][4 * g + 2], acc[pt][4 * g + 3]);
@@ -191,9 +194,15 @@ extern "C" hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, con
                                           hipStream_t s) {
   const int ctiles = (C + 31) / 32;
   if (hw % 128 == 0 && C % 32 == 0 && K % 8 == 0 && (size_t)K * 512 <= 96 * 1024 && ((uintptr_t)feat & 15) == 0) {
-    const size_t lds = (size_t)K * 512;
     const int nw = ctiles >= 8 ? 8 : 4;
-    auto kern = nw == 8 ? conv1x1_lds_kernel<8> : conv1x1_lds_kernel<4>;
+    if (views * (hw / 128) * 2 <= poem_device_cus()) {      // few views: 32-pixel blocks (same fma chain per output element)
+      auto kern = nw == 8 ? conv1x1_lds_kernel<8, 1> : conv1x1_lds_kernel<4, 1>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(views * (hw / 32))), dim3(nw * 64), (size_t)K * 128, s, feat, (const float4*)Wp, bias, table,
+                         pe_index, x, xt, views, K, C, hw);
+      return hipGetLastError();
+    }
+    const size_t lds = (size_t)K * 512;
+    auto kern = nw == 8 ? conv1x1_lds_kernel<8, 4> : conv1x1_lds_kernel<4, 4>;
     static std::atomic<unsigned long long> optin[2];
     if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), 96 * 1024, optin[nw == 8]); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)(views * (hw / 128))), dim3(nw * 64), lds, s, feat, (const float4*)Wp, bias, table,
@@ -308,6 +317,24 @@ __global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restric
 
 extern "C" hipError_t poem_launch_invert_extr(const float* extr, float* inv, int views, hipStream_t s) {
   hipLaunchKernelGGL(invert_extr_kernel, dim3((views + 63) / 64), dim3(64), 0, s, extr, inv, views);
+  return hipGetLastError();
+}
+
+// The two halves of poem_launch_project_sample for the whole-path sequence (forward.cpp): the projection reads the CALLER's
+// camera tensors and stays outside the captured body; the sampling reads workspace memory only.
+extern "C" hipError_t poem_launch_project_uv(const float* bps, const float* centre, const int* view_sample, const float* intr,
+                                             const float* extr, float* inv_scratch, float* uv, int views, int fh, int fw, int S,
+                                             int img_w, int img_h, hipStream_t s) {
+  hipLaunchKernelGGL(invert_extr_kernel, dim3((views + 63) / 64), dim3(64), 0, s, extr, inv_scratch, views);
+  hipLaunchKernelGGL(project_kernel, dim3((S + 255) / 256, views), dim3(256), 0, s, bps, centre, view_sample, intr,
+                     inv_scratch, uv, views, S, fw, fh, 1.0f / (float)img_w, 1.0f / (float)img_h);
+  return hipGetLastError();
+}
+extern "C" hipError_t poem_launch_grid_sample(const float* x, const float* uv, float* g, int views, int C, int fh, int fw, int S,
+                                              hipStream_t s) {
+  constexpr int CG = 8;
+  hipLaunchKernelGGL((grid_sample_kernel<CG>), dim3((C + CG - 1) / CG, views), dim3(256), CG * fh * fw * sizeof(float),
+                     s, x, uv, g, C, fh, fw, S);
   return hipGetLastError();
 }
 

@@ -552,6 +552,12 @@ static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s, int mode = 0) {
   return a.composed ? launch_va_t<C, P, NW, MINW, true>(a, s) : launch_va_t<C, P, NW, MINW, false>(a, s);
 }
 
+// One-query blocks for the full kernel (MODE 0) at embed 256 (A/B: poem_set_option "va_p1"; the table modes keep the query
+// groups their images are laid out for): twice the items, half the work each -- a batch of two leaves the busiest CU with 7
+// queries instead of 8; costs twice the weight traffic from L2 per query.
+static thread_local int g_va_p1 = 0;
+extern "C" void poem_vecattn_one_query_blocks(int on) { g_va_p1 = on; }
+
 // queries per block of the instantiation that serves embed width C (the table images are laid out per query group)
 static int va_group_size(int C) { return C == 128 ? 4 : (C >= 512 ? 1 : 2); }
 
@@ -560,7 +566,9 @@ static hipError_t dispatch_va(const VecAttnArgs& a, int C, hipStream_t s, int mo
     case 32: return launch_va<32, 2, 1, 1>(a, s, mode);
     case 64: return launch_va<64, 2, 2, 1>(a, s, mode);
     case 128: return launch_va<128, 4, 4, 2>(a, s, mode);
-    case 256: return launch_va<256, 2, 4, 2>(a, s, mode);
+    case 256:
+      if (mode == 0 && g_va_p1 && a.composed) return launch_va_t<256, 1, 4, 4, true>(a, s);
+      return launch_va<256, 2, 4, 2>(a, s, mode);
     case 512: return launch_va<512, 1, 4, 2>(a, s, mode);
     case 1024: return launch_va<1024, 1, 8, 2>(a, s, mode);   // 8 waves x 4 channel tiles: 2 waves per SIMD, no spills (4 x 8 tiles spilled 158 VGPRs)
     default: return hipErrorInvalidValue;

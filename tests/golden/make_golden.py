@@ -58,12 +58,13 @@ CASES = {
                       ln_spread=0.3),
     # round 4.  The reference's neighbour search under BOTH roundings of the third party's distance on a case where the
     # rounding DECIDES a neighbour set: pytorch3d's CPU kernel ((dx*dx + dy*dy) + dz*dz) vs its CUDA kernel
-    # fma(dz, dz, fma(dy, dy, dx*dx)) (ref_harness.KNN_FMA).  Seed 152 was found by tests/golden/find_fma_case.py (a near-tie
-    # at rank 32 of a block-1 self search); run_tie_pair() asserts that the two reference runs really differ.  (Round 3's
+    # fma(dz, dz, fma(dy, dy, dx*dx)) (ref_harness.KNN_FMA).  Seed 1113 was found by tests/golden/find_fma_case.py (one hit in
+    # ~1100 reference runs: a near-tie at rank 32 of a block-1 cross search, on the reference's own coordinates);
+    # check_tie_pair() asserts that the two reference runs really differ.  (Round 3's
     # small_hot_fma / medium_hot_fma / medium_g4_fma were bit-identical to their non-fma twins -- no near-tie -- and are gone.)
-    "small_tie": dict(model="small", embed=128, nsample=4096, views=[3, 2], seed=152, parametric=False, full=False, gain=2.5,
+    "small_tie": dict(model="small", embed=128, nsample=4096, views=[3, 2], seed=1113, parametric=False, full=False, gain=2.5,
                       ln_spread=0.3),
-    "small_tie_fma": dict(model="small", embed=128, nsample=4096, views=[3, 2], seed=152, parametric=False, full=False, gain=2.5,
+    "small_tie_fma": dict(model="small", embed=128, nsample=4096, views=[3, 2], seed=1113, parametric=False, full=False, gain=2.5,
                           ln_spread=0.3, knn_fma=True),
     # hot weights at the c4 model (POEM-large): gain 2.5 / sqrt(2) -- the Linears sum over twice the channels of the medium model,
     # so the same operating point (max |xyz| ~ 1 m, O(1) coordinate updates per block) sits at a lower gain

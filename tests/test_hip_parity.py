@@ -441,7 +441,7 @@ def test_release_shape_stage_taps_vs_reference(name):
         assert float((ref[0] - ref[1]).abs().max()) > 0.01           # metres: the layers really move the mesh
 
 
-@pytest.mark.parametrize("name", ["medium_g1", "medium_g4", "medium_g6"])
+@pytest.mark.parametrize("name", ["medium_g1", "medium_g4", "medium_g6", "small_tie", "small_tie_fma"])
 def test_conditioning_sweep_and_cuda_rounding_vs_reference(name):
     """Round-3 fixtures (tests/test_oracle_golden.py has the CPU side).  medium_g{1,4,6} + medium_hot = the same case at
     gains 1 / 2.5 / 4 / 6 of the block Linears; *_fma = the reference's neighbour search rounding its distances like
@@ -484,7 +484,12 @@ def test_conditioning_sweep_and_cuda_rounding_vs_reference(name):
         # a run without flips; the neighbour attribution above is what remains checkable (profiles/r03_parity.txt has the numbers).
         if gain > 4 and flips:
             continue
+        # (the same one step earlier: a run with the OTHER rounding than the fixture's whose near-tie did flip -- small_tie_fma
+        #  under the default rounding -- has block-2 rows that gathered the flipped row; stage bars for the matching rounding only)
+        mismatched = bool(fma) != bool(spec.get("knn_fma")) and flips > 0
         for key, st in rep["stages"].items():
+            if mismatched:
+                break
             assert st["clean_rows"] > 0.9, (key, st)
             assert st["path_clean"] <= stage_tol * max(st["scale"], 1.0), (fma, key, st)
             assert st["path_clean"] <= 6 * st["oracle_clean"] + 2.4e-7 * max(st["scale"], 1.0), (fma, key, st)
@@ -496,6 +501,21 @@ def test_conditioning_sweep_and_cuda_rounding_vs_reference(name):
                 assert mp_hip < 1e-6, (fma, layer, mp_hip)
     eng.set_option("knn_fma", 0)
     eng.enable_taps(False)
+
+
+def test_tie_pair_poem_knn_reproduces_each_rounding_of_the_reference_run():
+    """The pair of reference runs that differ by the third party's distance rounding (tests/test_oracle_golden.py
+    test_tie_pair_...): poem_knn (CPU-kernel rounding) / poem_knn_ex(fma_contract) on the coordinates each run's searches saw
+    must return that run's recorded neighbours -- every query, no attribution -- and the other rounding must not."""
+    from test_oracle_golden import tie_pair_searches
+    wrong = 0
+    for fma, blk, which, xyz, src, want in tie_pair_searches():
+        got = hip.knn(xyz.to(DEV), src.to(DEV), fma=fma).cpu().long()
+        assert torch.equal(torch.sort(got, -1).values, torch.sort(want, -1).values), (fma, blk, which)
+        assert float((got == want).float().mean()) > 0.999, (fma, blk, which)       # same ORDER too, up to exactly tied distances
+        other = hip.knn(xyz.to(DEV), src.to(DEV), fma=not fma).cpu().long()
+        wrong += int((torch.sort(other, -1).values != torch.sort(want, -1).values).any(-1).sum())
+    assert wrong >= 2, wrong
 
 
 @pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano"])

@@ -77,7 +77,7 @@ def test_hot_weights_oracle_vs_reference(name):
         assert err.max() < 1e-6, (layer, err)                    # the 1e-3 mm bar, every layer, every sample
 
 
-ROUND3 = ["medium_g1", "medium_g4", "medium_g6"]
+ROUND3 = ["medium_g1", "medium_g4", "medium_g6", "small_tie", "small_tie_fma"]
 
 
 @pytest.mark.parametrize("name", ROUND3)
@@ -103,18 +103,65 @@ def test_conditioning_sweep_and_cuda_rounding_oracle_vs_reference(name):
         rep = stage_report(z, spec, lambda n, shape, dt=None: taps[n], taps)
         gain = spec.get("gain", 1.0)
         stage_tol = 2e-6 if gain <= 2.5 else (1e-5 if gain <= 4 else 5e-5)
-        for key, st in rep["stages"].items():
-            assert st["path_clean"] <= stage_tol * max(st["scale"], 1.0), (key, st)
+        flips = 0
         for key, nb in rep["neighbours"].items():
             assert nb["set_equal"] >= 0.995, (key, nb)
+            flips += len(nb["flips"])
             for b, q, gap in nb["flips"]:
                 assert gap < 1e-5, (key, b, q, gap)
+        # run with the OTHER rounding than the fixture's and a set did flip (small_tie_fma under the CPU rounding): the flipped
+        # query's features differ by O(1e-2) and block 2 gathers that row into its neighbours' rows -- the stage bars hold for
+        # the matching rounding only; the flip is attributed above and the mesh bar below still holds
+        mismatched = bool(fma) != bool(spec.get("knn_fma")) and flips > 0
+        for key, st in rep["stages"].items():
+            if not mismatched:
+                assert st["path_clean"] <= stage_tol * max(st["scale"], 1.0), (key, st)
+        if name == "small_tie_fma":
+            assert (flips > 0) == (not fma), (fma, flips)        # the matching rounding reproduces every set, the other one does not
         got = out["all_coords_preds"].numpy()
         err = max(float(np.linalg.norm(got[l, :, 21:] - ref[l, :, 21:], axis=-1).mean(axis=1).max()) for l in range(3))
         assert err < max(1e-6, 1e-5 * scale), (fma, err, scale)
         results[fma] = err
     if spec.get("gain", 1.0) <= 2.5:
         assert max(results.values()) < 1e-6, results             # the 1e-3 mm bar holds up to the hot operating point
+
+
+def tie_pair_searches():
+    """The searches the reference ran in the small_tie / small_tie_fma pair, with the coordinates it ran them on:
+    -> [(fma, block, which, query_xyz, src_xyz, recorded idx)].  pt_xyz is an elementwise fp32 function of the inputs and equal
+    in the reference and the restatement bit for bit (checked on the fixture's stored rows)."""
+    out = []
+    for name in ("small_tie", "small_tie_fma"):
+        z, meta = load_golden(name)
+        spec = meta["spec"]
+        cfg, w, consts, batch = case_setup(spec)
+        pt_xyz = ((consts["bps"][None] + batch["reference_joints"][:, 9:10]) - batch["reference_joints"][:, 9:10]) / cfg.radius
+        assert np.array_equal(pt_xyz[:, ::64].numpy(), z["tap.pt_xyz"])
+        for blk in (1, 2):
+            xyz = torch.from_numpy(z[f"tap.b{blk - 1}.xyz"])
+            for which, src in (("self", xyz), ("cross", pt_xyz)):
+                out.append((bool(spec.get("knn_fma")), blk, which, xyz, src, torch.from_numpy(z[f"tap.b{blk}.idx_{which}"].astype(np.int64))))
+    return out
+
+
+def test_tie_pair_the_reference_itself_depends_on_the_third_partys_rounding():
+    """small_tie / small_tie_fma: the reference's OWN head on one seeded case with pytorch3d's two distance roundings (CPU kernel
+    / CUDA kernel).  Unlike round 3's *_fma fixtures -- bit-identical to their twins, so every test on them re-tested the twin --
+    this pair differs: one block-1 cross search resolves a near-tie at rank 32 differently, and the outputs move by 0.15 mm.
+    The restatement's neighbour search must reproduce EACH run's recorded index sets from the coordinates that run saw, with
+    that run's rounding -- every query, no attribution -- and must NOT reproduce them with the other rounding."""
+    za, zb = load_golden("small_tie")[0], load_golden("small_tie_fma")[0]
+    diff = {k: int((np.sort(za["tap." + k], -1) != np.sort(zb["tap." + k], -1)).any(-1).sum())
+            for k in ("b1.idx_self", "b1.idx_cross", "b2.idx_self", "b2.idx_cross")}
+    assert diff["b1.idx_cross"] >= 1 and np.array_equal(za["tap.b0.xyz"], zb["tap.b0.xyz"]), diff
+    assert float(np.abs(za["all_coords_preds"] - zb["all_coords_preds"]).max()) > 1e-5           # metres: the flip reaches the mesh
+    wrong = 0
+    for fma, blk, which, xyz, src, want in tie_pair_searches():
+        got = po.knn_indices(xyz, src, 32, fma)
+        assert torch.equal(torch.sort(got, -1).values, torch.sort(want, -1).values), (fma, blk, which)
+        other = po.knn_indices(xyz, src, 32, not fma)
+        wrong += int((torch.sort(other, -1).values != torch.sort(want, -1).values).any(-1).sum())
+    assert wrong >= 2, wrong            # the block-1 cross search of each run is mis-reproduced by the other rounding
 
 
 def near_tie_points(seed=12, B=2, NQ=200, NS=4096):
