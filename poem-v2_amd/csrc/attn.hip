@@ -498,25 +498,103 @@ __global__ __launch_bounds__(256 * W, W) void xattn_stream_kernel(const float* _
     t /= chunks;
     const int head = t % heads, b = t / heads;
     const int qrow = min(qt * 32 + r, NQ - 1);
-    float4 qf[KC];
+    // The query fragment (KC float4 per lane: 128 registers at head dim 256): in registers for head dim 64; in LDS for the
+    // wide heads (a wave's own KC KB, fragment order, conflict-free ds_read_b128 right in front of the MFMAs that use it) --
+    // the registers it frees are what the four-group ring below is made of.
+    constexpr bool QLDS = NGK >= 2;
+    extern __shared__ __attribute__((aligned(16))) float4 xs_q[];      // QLDS: (waves of the block) x KC x 64
+    float4* qs = xs_q + (size_t)wv * KC * 64 + lane;
+    float4 qf[QLDS ? 1 : KC];
     {
       const float* qp = q + ((size_t)b * qbr + qrow) * ldq + head * DH + 4 * h;
+      if constexpr (QLDS) {
+        constexpr int QB = 8;
 #pragma unroll
-      for (int kc = 0; kc < KC; ++kc) qf[kc] = *reinterpret_cast<const float4*>(qp + 8 * kc);
+        for (int k0 = 0; k0 < KC; k0 += QB) {
+          float4 t[QB];
+#pragma unroll
+          for (int u = 0; u < QB; ++u) t[u] = *reinterpret_cast<const float4*>(qp + 8 * (k0 + u));
+#pragma unroll
+          for (int u = 0; u < QB; ++u) qs[(k0 + u) * 64] = t[u];
+        }
+      } else {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) qf[kc] = *reinterpret_cast<const float4*>(qp + 8 * kc);
+      }
     }
     const int kt0 = ch * tpc;
     const int ktile_bytes = C * 128;
     int koff = __builtin_amdgcn_readfirstlane((b * nkt + kt0) * ktile_bytes + head * KC * 1024);
     int voff = __builtin_amdgcn_readfirstlane((b * nkt + kt0) * ktile_bytes + ((head * DH) / 32) * 4096);
-    float4 ring[2][8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ring[0][e] = frag_load(krs, loff, koff + e * 1024);
-    __builtin_amdgcn_sched_barrier(0);
     f32x16 o[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) o[d] = zero16();
     float m_ref = -INFINITY, nbias = 0.f, l_run = 0.f;
-
+    if constexpr (NGK >= 2) {
+      // Head dims 128 / 256 (round 4): ONE wave per SIMD (the query fragment and the output tiles alone are 192 / 256 registers),
+      // so nothing hides a load but the wave's own distance to it -- and one 8 KB group ahead is 32 MFMAs = 0.85 us, less than
+      // an L2 / MALL round trip under load (POEM-huge: 0.36 of the matrix pipe).  Ring of FOUR groups, three in flight: the
+      // 2 NGK groups of a tile (K groups, then V pairs) are 4 or 8, so every group's slot is a compile-time constant.
+      float4 ring[4][8];
+      // group n of the current tile: K group n | V pair n - NGK | the NEXT tile's K group n - 2 NGK | its V pair n - 3 NGK
+#define XS_LOAD(N, ADV)                                                                                        \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                            \
+        ring[(N) & 3][e] = (N) < NGK ? frag_load(krs, loff, koff + ((N) * 8 + e) * 1024)                       \
+                         : (N) < 2 * NGK ? frag_load(vrs, loff, voff + (((N) - NGK) * 8 + e) * 1024)           \
+                         : (N) < 3 * NGK ? frag_load(krs, loff, koff + (ADV) + (((N) - 2 * NGK) * 8 + e) * 1024) \
+                                         : frag_load(vrs, loff, voff + (ADV) + (((N) - 3 * NGK) * 8 + e) * 1024);
+      XS_LOAD(0, 0) XS_LOAD(1, 0) XS_LOAD(2, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      for (int kt = 0; kt < tpc; ++kt) {
+        // keep the CU's waves on the same K/V GROUP: a tile is 32 / 64 KB here -- more than the 32 KB L1 --, so waves that drift
+        // by a tile each fetch their own copy from L2 (4 x 64 KB per tile-time and CU = 9.6 TB/s chip-wide at full MFMA rate:
+        // the kernel ran at the L2's pace, 0.38 of the matrix pipe).  A barrier per tile, loads issued group by group right
+        // behind it: the four waves' requests for a line arrive together.
+        if (map) __builtin_amdgcn_s_barrier();
+        const int adv = (kt + 1 < tpc) ? ktile_bytes : 0;
+        // two score accumulators (even / odd k-steps), added once per tile: with one wave per SIMD a chain of 128 MFMAs on ONE
+        // accumulator pays the dependent-issue latency 128 times and nobody else is there to fill it
+        f32x16 s = zero16(), s1 = zero16();
+#pragma unroll
+        for (int g = 0; g < NGK; ++g) {
+          XS_LOAD(g + 3, adv)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float4 a = ring[g & 3][e];
+            const float4 bq = qs[(g * 8 + e) * 64];
+            s = mfma32(a.x, bq.x, s);
+            s1 = mfma32(a.y, bq.y, s1);
+            s = mfma32(a.z, bq.z, s);
+            s1 = mfma32(a.w, bq.w, s1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] += s1[i];
+        POEM_SOFTMAX_TILE(DT)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < NGV; ++v) {
+          XS_LOAD(NGK + v + 3, adv)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd)
+              o[2 * v + dd] = mfma32((&ring[(NGK + v) & 3][dd * 4 + (i >> 2)].x)[i & 3], s[i], o[2 * v + dd]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        koff += adv;
+        voff += adv;
+      }
+#undef XS_LOAD
+    } else {
+    float4 ring[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ring[0][e] = frag_load(krs, loff, koff + e * 1024);
+    __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < tpc; ++kt) {
       if (map && (kt & 3) == 0 && kt) __builtin_amdgcn_s_barrier();   // keep the CU's waves on the same K/V tiles (see xattn_kernel)
       const int adv = (kt + 1 < tpc) ? ktile_bytes : 0;
@@ -560,6 +638,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_stream_kernel(const float* _
         __builtin_amdgcn_sched_barrier(0);
       }
       voff += adv;
+    }
     }
     l_run = half_sum(l_run);
     float4* po = part_o + (size_t)item * (DT * 4) * 64 + lane;
@@ -719,7 +798,12 @@ extern "C" hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, 
   if (ctx) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
 #define POEM_XSTREAM(D, WV)                                                                                        \
-  hipLaunchKernelGGL((xattn_stream_kernel<D, WV>), dim3(grid), dim3(256 * WV), 0, s, q, ldq, qbr, (const float4*)kimg,   \
+  {                                                                                                                \
+    static std::atomic<unsigned long long> optin_{0};                                                              \
+    if (hipError_t e_ = poem_optin_lds(reinterpret_cast<const void*>(xattn_stream_kernel<D, WV>), (size_t)4 * WV * (D / 8) * 1024, optin_); \
+        e_ != hipSuccess) return e_;                                                                               \
+  }                                                                                                                \
+  hipLaunchKernelGGL((xattn_stream_kernel<D, WV>), dim3(grid), dim3(256 * WV), (size_t)4 * WV * (D / 8) * 1024, s, q, ldq, qbr, (const float4*)kimg,   \
                      (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map);           \
   if (ctx) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)

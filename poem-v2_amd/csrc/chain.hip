@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain_ke
     const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(W, (unsigned)n * CC4);
     for (int pass = 0; pass < n; ++pass) {
       f32x16 acc[TPW][P];
-      lds_gemm<KCH, XSP, P, TPW, true>(wrs, __builtin_amdgcn_readfirstlane((pass * NTILE + tile0) * KCH * 1024), KCH * 1024, X, acc, lane);
+      lds_gemm<KCH, XSP, P, TPW, true, TPW * P == 1>(wrs, __builtin_amdgcn_readfirstlane((pass * NTILE + tile0) * KCH * 1024), KCH * 1024, X, acc, lane);
       add_bias(acc, bias + pass * C, 0);
       to_global(acc, Y, ld, pass * C, row0);
     }
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain_ke
     if (KIND != 3) {
       // ---- stage 1: first Linear + bias + residual [+ LayerNorm] -> y1 and back into X0
       f32x16 acc[TPW][P];
-      lds_gemm<KCH, XSP, P, TPW, true>(frag_rsrc(A.w1, CC4), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, acc, lane);
+      lds_gemm<KCH, XSP, P, TPW, true, TPW * P == 1>(frag_rsrc(A.w1, CC4), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, acc, lane);
       add_bias(acc, A.b1, 0);
       add_rows(acc, A.res, A.ldres, A.res_mod, row0);
       if (KIND == 0) layer_norm(acc, A.ln_g, A.ln_b, A.eps);
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain_ke
       // ---- kind D1.  reg_branch: u = relu(f Wreg0^T + b) (over f in X0: f is in HBM already), xyz' = xyz + u Wreg2^T + b
       {
         f32x16 u[TPW][P];
-        lds_gemm<KCH, XSP, P, TPW, true>(f4rs, __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, u, lane);
+        lds_gemm<KCH, XSP, P, TPW, true, TPW * P == 1>(f4rs, __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, u, lane);
         add_bias(u, A.bf4, 1);
         __syncthreads();                        // every wave is done reading f
         to_lds(u, X0);
@@ -289,15 +289,15 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain_ke
 #pragma unroll 1
     for (int sl = 0; sl < 4; ++sl) {
       f32x16 t[TPW][P];
-      lds_gemm<KCH, XSP, P, TPW, true>(f4rs, __builtin_amdgcn_readfirstlane(((1 + sl) * NTILE + tile0) * KCH * 1024), KCH * 1024, X0, t, lane);
+      lds_gemm<KCH, XSP, P, TPW, true, TPW * P == 1>(f4rs, __builtin_amdgcn_readfirstlane(((1 + sl) * NTILE + tile0) * KCH * 1024), KCH * 1024, X0, t, lane);
       add_bias(t, A.bf4 + (1 + sl) * C, 2);
       __syncthreads();                        // readers of X1 (the previous slab's contraction)
       to_lds(t, X1);
       __syncthreads();
       // tile t of the (C x 4C) image spans 4 KCH chunks: slab sl starts sl * KCH chunks in
       const int wb = __builtin_amdgcn_readfirstlane(tile0 * 4 * KCH * 1024 + sl * KCH * 1024);
-      if (sl == 0) lds_gemm<KCH, XSP, P, TPW, true>(wors, wb, 4 * KCH * 1024, X1, o, lane);
-      else lds_gemm<KCH, XSP, P, TPW, false>(wors, wb, 4 * KCH * 1024, X1, o, lane);
+      if (sl == 0) lds_gemm<KCH, XSP, P, TPW, true, TPW * P == 1>(wors, wb, 4 * KCH * 1024, X1, o, lane);
+      else lds_gemm<KCH, XSP, P, TPW, false, TPW * P == 1>(wors, wb, 4 * KCH * 1024, X1, o, lane);
     }
     add_bias(o, A.bout, 0);
     // residual f from X0 (lane = row, registers = channels: conflict-free reads)

@@ -54,14 +54,7 @@ __device__ __forceinline__ void gemm16(const __amdgpu_buffer_rsrc_t wrs, int wba
 #pragma unroll
       for (int u = 0; u < RU; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  float4 a0[T16], a1[T16], a2[T16], a3[T16];
   float xa[2][RU], xb[2][RU];
-#define C16_LOADW(A, KCI)                                                                                     \
-  {                                                                                                           \
-    const int kq_ = min((KCI), KCH - 1);                                                                      \
-    _Pragma("unroll") for (int t = 0; t < T16; ++t)                                                           \
-        A[t] = frag_load(wrs, (t & 1) ? loff1 : loff0, wbase + (t >> 1) * tile_stride + kq_ * 1024);          \
-  }
 #define C16_READX(XR, KCI)                                                                                    \
   {                                                                                                           \
     const int kq_ = min((KCI), KCH - 1);                                                                      \
@@ -79,6 +72,39 @@ __device__ __forceinline__ void gemm16(const __amdgpu_buffer_rsrc_t wrs, int wba
     _Pragma("unroll") for (int u = 0; u < RU; ++u)                                                            \
       _Pragma("unroll") for (int t = 0; t < T16; ++t) acc[t][u] = mfma16(w2_[t], XR[1][u], acc[t][u]);        \
   }
+  if constexpr (RU * T16 <= 2 && KCH % 8 == 0) {
+    // small tiles (one or two units of 16 rows: a chunk is 2 RU T16 MFMAs of 32 cycles -- 128 to 256 cycles): weight fragments
+    // seven chunks ahead, as lds_gemm.h does for its small tiles and for the same reason (a small batch's tile is a latency chain)
+    float4 ar[8][T16];
+#define C16_LOADR(D, KCI)                                                                                     \
+    {                                                                                                         \
+      const int kq_ = min((KCI), KCH - 1);                                                                    \
+      _Pragma("unroll") for (int t = 0; t < T16; ++t)                                                         \
+          ar[D][t] = frag_load(wrs, (t & 1) ? loff1 : loff0, wbase + (t >> 1) * tile_stride + kq_ * 1024);    \
+    }
+#pragma unroll
+    for (int d = 0; d < 7; ++d) C16_LOADR(d, d)
+    C16_READX(xa, 0)
+#pragma unroll 1
+    for (int kc = 0; kc < KCH; kc += 8) {
+      C16_LOADR(7, kc + 7) C16_READX(xb, kc + 1) C16_MMA(ar[0], xa)
+      C16_LOADR(0, kc + 8) C16_READX(xa, kc + 2) C16_MMA(ar[1], xb)
+      C16_LOADR(1, kc + 9) C16_READX(xb, kc + 3) C16_MMA(ar[2], xa)
+      C16_LOADR(2, kc + 10) C16_READX(xa, kc + 4) C16_MMA(ar[3], xb)
+      C16_LOADR(3, kc + 11) C16_READX(xb, kc + 5) C16_MMA(ar[4], xa)
+      C16_LOADR(4, kc + 12) C16_READX(xa, kc + 6) C16_MMA(ar[5], xb)
+      C16_LOADR(5, kc + 13) C16_READX(xb, kc + 7) C16_MMA(ar[6], xa)
+      C16_LOADR(6, kc + 14) C16_READX(xa, kc + 8) C16_MMA(ar[7], xb)
+    }
+#undef C16_LOADR
+  } else {
+  float4 a0[T16], a1[T16], a2[T16], a3[T16];
+#define C16_LOADW(A, KCI)                                                                                     \
+  {                                                                                                           \
+    const int kq_ = min((KCI), KCH - 1);                                                                      \
+    _Pragma("unroll") for (int t = 0; t < T16; ++t)                                                           \
+        A[t] = frag_load(wrs, (t & 1) ? loff1 : loff0, wbase + (t >> 1) * tile_stride + kq_ * 1024);          \
+  }
   C16_LOADW(a0, 0)
   C16_READX(xa, 0)
   C16_LOADW(a1, 1)
@@ -89,6 +115,7 @@ __device__ __forceinline__ void gemm16(const __amdgpu_buffer_rsrc_t wrs, int wba
     C16_LOADW(a0, kc + 4) C16_READX(xa, kc + 2) C16_MMA(a1, xb)
     C16_LOADW(a1, kc + 5) C16_READX(xb, kc + 3) C16_MMA(a2, xa)
     C16_LOADW(a2, kc + 6) C16_READX(xa, kc + 4) C16_MMA(a3, xb)
+  }
   }
 #undef C16_LOADW
 #undef C16_READX

@@ -178,7 +178,9 @@ struct poem_handle_s {
   // F1 of blocks >= 1 as two launches -- the four attention images (4C columns) and the vector cross attention's (k | v) rows
   // (2C columns): 8 and 4 panels divide an XCD's 32 CUs evenly (12 do not), so both take the XCD-aware map
   bool f1_split = true;
-  int va_p1 = 0;             // one-query blocks of the full vector attention: 0 off, 1 on, 2 = when B * Q <= 4 x CUs x 2 (A/B)
+  // one-query blocks of the full vector attention (vecattn.hip): -1 = for small batches (B * Q <= 16 x CUs: the busiest CU gets
+  // 7 queries instead of 8 at B = 2; measured B = 1 / 2 / 4 -0.7 / -1.7 / -2.0 %), 0 never, 1 / 2 always (3 / 2 waves per SIMD); same bits
+  int va_p1 = -1;
   bool gemm_kslab = true;    // K >= 512 Linears on the K-slab kernel (gemm.hip); part of the graph key
   bool overlap = true;
   // Per-view index arrays (view_offsets | view_sample | pe_index) live in handle-owned device memory and are re-uploaded

@@ -8,7 +8,8 @@ namespace {
 
 // D[c'][j] (+)= sum_k W[c'][k0 + k] X[k][j] for this wave's TPW tiles; KCH = K / 8 chunks, tile t of the image starts at
 // t * tile_stride bytes, the contraction at byte k0.  Same two-stage software pipeline as vecattn.hip's chain_gemm.
-template <int KCH, int XSP, int P, int TPW, bool INIT0>
+// DEEP: weight fragments seven chunks ahead instead of three (small tiles of the chain kernels; see below).
+template <int KCH, int XSP, int P, int TPW, bool INIT0, bool DEEP = false>
 __device__ __forceinline__ void lds_gemm(const __amdgpu_buffer_rsrc_t wrs, int wbase, int tile_stride, const float* __restrict__ X,
                                          f32x16 (&acc)[TPW][P], int lane) {
   static_assert(KCH % 2 == 0, "K must be a multiple of 16");
@@ -51,6 +52,33 @@ __device__ __forceinline__ void lds_gemm(const __amdgpu_buffer_rsrc_t wrs, int w
     CH_MMA(A, 1, x1, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x1, (KCI) + 1, 1) __builtin_amdgcn_sched_barrier(0); \
     CH_MMA(A, 2, x2, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x2, (KCI) + 1, 2) __builtin_amdgcn_sched_barrier(0); \
     CH_MMA(A, 3, x3, false) __builtin_amdgcn_sched_barrier(0); CH_READX(x3, (KCI) + 1, 3) __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DEEP && KCH % 8 == 0) {
+      // one or two MFMAs per k-step: a chunk is 256 / 512 cycles of MFMAs, far less than an L2 round trip -- weight fragments
+      // SEVEN chunks ahead (ring of eight; round 3: three ahead).  A chain tile on a small batch is a latency chain -- one tile
+      // per CU, nothing else to switch to -- and with three chunks in flight every GEMM phase waited ~0.2 us per chunk for its
+      // weights (chain kind D2 at a batch of 2: 97 us for 17 us of MFMAs).  32 VGPRs at TPW = 1.
+      float4 ar[8][TPW];
+#define CH_LOADR(D, KCI)                                                                  \
+      {                                                                                   \
+        const int kq_ = min((KCI), KCH - 1);                                              \
+        _Pragma("unroll") for (int tp = 0; tp < TPW; ++tp) ar[D][tp] = frag_load(wrs, loff, wbase + tp * tile_stride + kq_ * 1024); \
+      }
+#pragma unroll
+      for (int d = 0; d < 7; ++d) CH_LOADR(d, d)
+      CH_READX(x0, 0, 0) CH_READX(x1, 0, 1) CH_READX(x2, 0, 2) CH_READX(x3, 0, 3)
+      __builtin_amdgcn_sched_barrier(0);
+#define CH_STEP8(D, KCI, INIT)                                                            \
+      CH_LOADR(((D) + 7) & 7, (KCI) + 7) __builtin_amdgcn_sched_barrier(0); CH_CHUNK4(ar[D], (KCI), INIT)
+      CH_STEP8(0, 0, INIT0) CH_STEP8(1, 1, false) CH_STEP8(2, 2, false) CH_STEP8(3, 3, false)
+      CH_STEP8(4, 4, false) CH_STEP8(5, 5, false) CH_STEP8(6, 6, false) CH_STEP8(7, 7, false)
+      for (int kc = 8; kc < KCH; kc += 8) {
+        CH_STEP8(0, kc, false) CH_STEP8(1, kc + 1, false) CH_STEP8(2, kc + 2, false) CH_STEP8(3, kc + 3, false)
+        CH_STEP8(4, kc + 4, false) CH_STEP8(5, kc + 5, false) CH_STEP8(6, kc + 6, false) CH_STEP8(7, kc + 7, false)
+      }
+#undef CH_STEP8
+#undef CH_LOADR
+      return;
+    }
     if constexpr (KCH % 4 == 0) {
       // one or two MFMAs per k-step: a chunk is 256 / 512 cycles of MFMAs, less than an L2 round trip -- weight fragments
       // three chunks ahead (ring of four) instead of one; no extra registers at the kernels' peaks

@@ -566,9 +566,13 @@ static hipError_t dispatch_va(const VecAttnArgs& a, int C, hipStream_t s, int mo
     case 32: return launch_va<32, 2, 1, 1>(a, s, mode);
     case 64: return launch_va<64, 2, 2, 1>(a, s, mode);
     case 128: return launch_va<128, 4, 4, 2>(a, s, mode);
-    case 256:
-      if (mode == 0 && g_va_p1 && a.composed) return launch_va_t<256, 1, 4, 4, true>(a, s);
+    case 256: {
+      // (-1: small batches only -- fewer than 16 queries per CU)
+      const int g_va_p1 = ::g_va_p1 >= 0 ? ::g_va_p1 : ((long)a.B * a.Q <= 16L * poem_device_cus() ? 1 : 0);
+      if (mode == 0 && g_va_p1 == 1 && a.composed) return launch_va_t<256, 1, 4, 3, true>(a, s);
+      if (mode == 0 && g_va_p1 == 2 && a.composed) return launch_va_t<256, 1, 4, 2, true>(a, s);
       return launch_va<256, 2, 4, 2>(a, s, mode);
+    }
     case 512: return launch_va<512, 1, 4, 2>(a, s, mode);
     case 1024: return launch_va<1024, 1, 8, 2>(a, s, mode);   // 8 waves x 4 channel tiles: 2 waves per SIMD, no spills (4 x 8 tiles spilled 158 VGPRs)
     default: return hipErrorInvalidValue;
