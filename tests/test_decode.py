@@ -125,12 +125,12 @@ def test_conv1x1_upsample2_operator(cin, cout, r):
     ref = torch.einsum("oc,vchw->vohw", w.double(), up) + b.double()[None, :, None, None]
     wp = hip.pack_linear(w.to(DEV))
     y8 = torch.empty(views, cout, r, r, device=DEV)
-    hip.check(hip.lib().poem_input_proj(hip.ptr(x.to(DEV)), wp.data_ptr(), hip.ptr(b.to(DEV)), None, None, hip.ptr(y8), views, cin,
+    xd, bd = x.to(DEV), b.to(DEV)       # (named: a temporary's block goes back to the allocator while the launch still reads it)
+    hip.check(hip.lib().poem_input_proj(hip.ptr(xd), wp.data_ptr(), hip.ptr(bd), None, None, hip.ptr(y8), views, cin,
                                         cout, r * r, hip.stream()), "poem_input_proj")
     two = pk.decode.upsample2_concat_pad(y8, None, 2 * r, 2 * r, 0)
     assert _md(two, ref) < 2e-5
     one = torch.full((views, cout, 2 * r, 2 * r), float("nan"), device=DEV)
-    xd, bd = x.to(DEV), b.to(DEV)
     rc = hip.lib().poem_conv1x1_upsample2(hip.ptr(xd), wp.data_ptr(), hip.ptr(bd), hip.ptr(one), views, cin, cout, r, r, hip.stream())
     if r != 8:
         assert rc == hip.POEM_E_UNSUPPORTED
