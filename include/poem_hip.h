@@ -154,10 +154,10 @@ int poem_set_chains(poem_handle_t h, int enable);
  * does not exist; 0 = the operator sequence (poem_project_sample, poem_gemm x4, poem_merge_reduce / _finalize), same
  * results to fp32 round-off (the cross-view dot products reduce in another order); "chain_combine" (default 1, chain mode,
  * 4 heads): the chain kernel behind a cross attention merges the attention's split-key partials while it fills its tile
- * instead of a separate combine launch writing the context rows (bit-identical); "xattn_merge" (default 0, fp32 mode, head
+ * instead of a separate combine launch writing the context rows (bit-identical); "xattn_merge" (default -1 = for batches of one or two samples; fp32 mode, head
  * dim 64, 4096 keys): the cross attention kernel merges its four split-key partials through LDS and writes the context rows
- * itself -- no partials in HBM, "chain_combine" then has nothing to do (bit-identical; measured 0.5 % slower end to end,
- * hence off); "tables_first" (default 1): the fused
+ * itself -- no partials in HBM, "chain_combine" then has nothing to do (bit-identical; at batch 32 0.5 % slower end to end,
+ * at batch 1 / 2 2-3 % faster); "tables_first" (default 1): the fused
  * sampling kernel is ordered behind the block-0 anchor-table build of the neighbour-search stream (a CU that hosts a table
  * block takes one sampling block instead of two; results unaffected); "graphs" (default 1): replay the launch list of a
  * forward as a hipGraph, keyed by (batch size, workspace, options) -- NOT by the view layout; "graph_eager" (default 0): capture

@@ -366,7 +366,9 @@ extern "C" hipError_t poem_launch_chain16(const ChainArgs* a, int C, hipStream_t
 //   * kinds A / C / D1 (two co-resident blocks per CU): from 3 units of 16 rows per CU on, the 16x16x4 kernel with its
 //     16-row granularity and a CU's share split over two co-resident blocks (chain16.hip); below that a tile would be 1-2
 //     units, where every MFMA needs a fresh weight fragment from L2 -- the 32-row tiles of this file spread a small batch
-//     almost as widely and stream half the weight bytes per row;
+//     almost as widely and stream half the weight bytes per row; round 4: ONE unit per CU (B <= 5 at 799 queries) goes to the
+//     16x16x4 kernel again -- with its ring of eight weight fragments a one-unit tile is the shortest latency chain
+//     (B = 1 / 2 / 5: -2.7 / -0.6 / -0.6 % of the forward; two units per CU: the 32-row tiles still win);
 //   * kind D2 (two activation tiles: one block per CU at 64 rows): chain16 while a CU's share is one tile of <= 3 units,
 //     the 32- / 64-row kernel with chain_tile_p's height above (its second tile of a CU starts without a new block).
 // Any choice gives the same bits.
@@ -375,7 +377,7 @@ extern "C" hipError_t poem_launch_chain(const ChainArgs* a, int C, hipStream_t s
   if (a->tile_p == 3) return poem_launch_chain16(a, C, s);
   if (a->tile_p == 0) {
     const int U = (a->M + 15) / 16, per_cu = (U + std::min(cus, U) - 1) / std::min(cus, U);
-    if (a->kind == 3 ? per_cu <= 3 : per_cu >= 3) return poem_launch_chain16(a, C, s);
+    if (a->kind == 3 ? per_cu <= 3 : (per_cu >= 3 || per_cu == 1)) return poem_launch_chain16(a, C, s);
   }
   const int p = chain_tile_p(a->M, cus, a->tile_p);
   switch (C) {

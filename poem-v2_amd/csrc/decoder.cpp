@@ -134,6 +134,8 @@ struct DecoderRun {
     return POEM_OK;
   }
 
+  bool merge_in_attention() const { return h->xattn_merge >= 0 ? h->xattn_merge != 0 : B <= 2; }
+
   // F1 of block i + 1 behind stage `at` of block i's cross attentions (poem_handle_s::bps_defer)
   int defer_at() const {
     if (!ov || !chain) return 0;
@@ -203,7 +205,7 @@ struct DecoderRun {
       float pkc2 = 0.f;
       poem_cross_attention_partials(B, Q, S, C, c.heads, p.attn_scratch, &part_o, &part_ml, &pchunks, &pkc2);
       // the kernel merges the partials itself where it can (attn.hip MERGE); else the chain does while it fills its tile
-      const bool merged = h->xattn_merge && poem_cross_attention_merges(S, C, c.heads) != 0;
+      const bool merged = merge_in_attention() && poem_cross_attention_merges(S, C, c.heads) != 0;
       const bool comb = !merged && h->chain_combine && poem_chain_combines(C, c.heads, pchunks) != 0;
       auto attention = [&](const float* q, int ldq, int qb, const float* kimg, const float* vimg) -> hipError_t {
         if (merged) return poem_launch_cross_attention_merged(q, ldq, qb, kimg, vimg, p.ctx, B, Q, S, C, c.heads, s);
@@ -253,7 +255,7 @@ struct DecoderRun {
       }
       if (ov && a == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
       if (h->precision == POEM_PRECISION_SPLIT_F16X3_ALL) poem_cross_attention_split(h->kv_presplit[i] ? 2 : 1);
-      if (h->precision == POEM_PRECISION_FP32 && h->xattn_merge && poem_cross_attention_merges(S, C, c.heads))
+      if (h->precision == POEM_PRECISION_FP32 && merge_in_attention() && poem_cross_attention_merges(S, C, c.heads))
         HIPCHK(poem_launch_cross_attention_merged(qptr, ldq, Q, p.y1[i] + (size_t)(2 * a) * BS * C, p.y1[i] + (size_t)(2 * a + 1) * BS * C,
                                                   p.ctx, B, Q, S, C, c.heads, s));
       else

@@ -138,7 +138,9 @@ struct poem_handle_s {
   // xattn_kernel MERGE; fp32 mode, head dim 64, 4096 keys): no partials in HBM, chain kind A fills its tile from ctx.
   // Bit-identical; default OFF: measured 0.5 % slower end to end (the attention +27 us per launch -- four K/V chunk
   // streams per CU instead of one overflow the 32 KB L1 -- against -12 us per chain launch; LABNOTES R3.5)
-  bool xattn_merge = false;
+  // (round 4: -1 = for batches of one or two samples, where the attention is one round of items either way and the chain behind
+  //  it is a latency chain whose fill shrinks from four partials to one row: B = 1 / 2 -2.1 / -3.0 %, B = 4 +0.5 %)
+  int xattn_merge = -1;
   bool knn_early = true;     // chain mode: issue block i+1's neighbour searches right behind block i's coordinate update
   // hipGraph replay of the step's launch list (everything between the four kernels that read the caller's inputs and the
   // one that writes the caller's output touches workspace / handle memory only): captured once per (batch, view layout,

@@ -449,7 +449,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "knn_early") h->knn_early = value != 0;
   else if (k == "fused_sampling") h->fused_sampling = value != 0;
   else if (k == "chain_combine") h->chain_combine = value != 0;
-  else if (k == "xattn_merge") h->xattn_merge = value != 0;
+  else if (k == "xattn_merge") { if (value < -1 || value > 1) return POEM_E_ARG; h->xattn_merge = value; }
   else if (k == "tables_first") h->tables_first = value != 0;
   else if (k == "tables_cached") h->tables_cached = value != 0;
   else if (k == "knn_fma") h->knn_fma = value != 0;
