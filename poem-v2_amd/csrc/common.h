@@ -97,3 +97,49 @@ __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + e
 // zero-filled for rows >= N.  One wave-wide 1 KiB load yields the operand of four consecutive MFMA k-steps
 // for a 32-row tile: k-step t of chunk kc multiplies channels (8kc+t | 8kc+4+t) held by the two half-waves.
 static inline size_t packed_linear_floats(int N, int K) { return (size_t)((N + 31) / 32) * (size_t)(K / 8) * 64 * 4; }
+
+// ---- shared by the input kernels of the whole path (misc.hip prep_xyz_kernel, sample.hip invert_extr_kernel, merge.hip
+// input_tables_kernel) --------------------------------------------------------------------------------------------------------
+// inverse of a camera->master 4x4: fp64 Gauss-Jordan with partial pivoting, rounded to fp32 (torch.linalg.inv's role, collation.py:56-61)
+__device__ inline void invert4x4(const float* __restrict__ m, float* __restrict__ out) {
+  double a[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) { a[i][j] = (double)m[i * 4 + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < 4; ++c) {
+    int piv = c;
+    double best = fabs(a[c][c]);
+    for (int i = c + 1; i < 4; ++i) if (fabs(a[i][c]) > best) { best = fabs(a[i][c]); piv = i; }
+    if (piv != c) for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+    const double inv = 1.0 / a[c][c];
+    for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+    for (int i = 0; i < 4; ++i) if (i != c) {
+      const double f = a[i][c];
+      for (int j = 0; j < 8; ++j) a[i][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i * 4 + j] = (float)a[i][4 + j];
+}
+
+// element i of the coordinate normalisation (see prep_xyz_kernel): centre = reference_joints[:, 9]; pt_xyz = ((bps + c) - c) / radius;
+// query_xyz = ((c + template) - c) / radius, evaluated exactly the reference's way
+__device__ inline void poem_prep_xyz_elem(long i, const float* __restrict__ ref_joints, const float* __restrict__ bps,
+                                          const float* __restrict__ tmpl, float* __restrict__ centre, float* __restrict__ pt_xyz,
+                                          float* __restrict__ query_xyz, int B, int S, int Q, float radius) {
+  const long n_pt = (long)B * S * 3, n_q = (long)B * Q * 3;
+  if (i < n_pt) {
+    const int d = (int)(i % 3), s = (int)((i / 3) % S), b = (int)(i / (3L * S));
+    const float c = ref_joints[((size_t)b * 21 + 9) * 3 + d];
+    const float w = __fadd_rn(bps[s * 3 + d], c);
+    pt_xyz[i] = __fdiv_rn(__fsub_rn(w, c), radius);
+  } else if (i < n_pt + n_q) {
+    const long k = i - n_pt;
+    const int d = (int)(k % 3), qq = (int)((k / 3) % Q), b = (int)(k / (3L * Q));
+    const float c = ref_joints[((size_t)b * 21 + 9) * 3 + d];
+    const float w = __fadd_rn(c, tmpl[qq * 3 + d]);
+    query_xyz[k] = __fdiv_rn(__fsub_rn(w, c), radius);
+  } else if (i < n_pt + n_q + 3L * B) {
+    const long k = i - n_pt - n_q;
+    const int d = (int)(k % 3), b = (int)(k / 3);
+    centre[k] = ref_joints[((size_t)b * 21 + 9) * 3 + d];
+  }
+}

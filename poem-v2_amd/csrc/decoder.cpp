@@ -61,6 +61,7 @@ struct DecoderRun {
   const float* anchor = nullptr;
   int shared = 0;
   bool knn_issued[9] = {};
+  bool anchor_from_y3 = false;      // block 0 on the tables: (kg | v) of the anchor rows are rows of p.y3 (small batches)
 
   DecoderRun(poem_handle_t h_, Plan& p_, const float* feats_in, const float* pt_xyz_, const float* pt_feats_, int B_, float* pose,
              float* bet, hipStream_t s_, bool template_queries)
@@ -233,12 +234,15 @@ struct DecoderRun {
       cb.w1 = (const float4*)h->P(a2 + 6); cb.b1 = h->R(a2 + 7); cb.res = p.h_attn; cb.ldres = C; cb.res_mod = 0;
       cb.ln_g = h->R(a2 + 8); cb.ln_b = h->R(a2 + 9); cb.y1 = p.h_cross[i]; cb.ldy1 = C;
       // block 0 on the tables needs qg for every row and (kg | v) for the anchor rows only
-      cb.w2 = (const float4*)h->fused[i].w[2]; cb.b2 = h->fused[i].b[2]; cb.n2 = (tables && i == 0) ? 1 : 3; cb.y2 = p.y3; cb.ldy2 = 3 * C;
+      // (a small batch lets the chain project all three for every row -- two more GEMM phases on tiles that are latency chains
+      //  anyway -- and block 0's vector self attention picks its 32 anchor rows out of them: no gather + 32-row GEMM launches)
+      anchor_from_y3 = tables && i == 0 && h->small_batch && (long)BQ <= 16L * poem_device_cu_count();
+      cb.w2 = (const float4*)h->fused[i].w[2]; cb.b2 = h->fused[i].b[2]; cb.n2 = (tables && i == 0 && !anchor_from_y3) ? 1 : 3; cb.y2 = p.y3; cb.ldy2 = 3 * C;
       HIPCHK(poem_launch_chain(&cb, C, s));
       if (const int rc = deferred_basis_point_side(i, 3); rc != POEM_OK) return rc;
       hidden = p.h_cross[i];
       ldh = C;
-      if (tables && i == 0) return anchor_rows_f3(i);
+      if (tables && i == 0 && !anchor_from_y3) return anchor_rows_f3(i);
       return POEM_OK;
     }
     // operator sequence: query projection, attention, out-proj + residual, LayerNorm -- twice; then F3
@@ -289,6 +293,10 @@ struct DecoderRun {
                                                 3 * C, 3 * C, 3 * C, s));
     } else if (tables && i == 0) {
       if (ov && h->tables_pending) HIPCHK(hipStreamWaitEvent(s, h->ev_tab, 0));
+      if (anchor_from_y3)      // keys / values straight from the rows the chain projected: neighbour j = query row anchor_idx[j] (Q2)
+        HIPCHK(poem_launch_vector_attention_anchored(h->anchor_idx, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->P(vsb + 10), p.tab_g[0], p.tab_p[0],
+                                                     p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, s));
+      else
       HIPCHK(poem_launch_vector_attention_anchored(p.ident, p.y3, p.anch_kv[0], p.anch_kv[0] + C, 32, h->P(vsb + 10), p.tab_g[0],
                                                    p.tab_p[0], p.rs, B, Q, C, 3 * C, 2 * C, 2 * C, s));
     } else {

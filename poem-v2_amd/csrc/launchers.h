@@ -24,7 +24,11 @@ hipError_t poem_launch_project_table(const float* bps, const float* centre, cons
                                      const float* inv_extr, void* tab, float* uv, int views, int C, int fh, int fw, int S,
                                      int img_w, int img_h, hipStream_t s);
 hipError_t poem_launch_view_layout(const ViewLayoutArgs* a, hipStream_t s);
+hipError_t poem_launch_input_tables(const float* bps, const float* ref_joints, const float* tmpl, const int* view_sample,
+                                    const float* intr, const float* extr, void* tab, float* centre, float* pt_xyz, float* query_xyz,
+                                    int views, int B, int S, int Q, int fh, int fw, int img_w, int img_h, float radius, hipStream_t s);
 hipError_t poem_launch_sample_merge(const SampleMergeArgs* a, int C, hipStream_t s);
+int poem_device_cu_count(void);
 hipError_t poem_launch_merge_tail(const MergeTailArgs* a, int C, hipStream_t s);
 hipError_t poem_launch_invert_extr(const float* extr, float* inv, int views, hipStream_t s);
 hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, const float* bias, const float* table,

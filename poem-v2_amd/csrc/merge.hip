@@ -353,6 +353,60 @@ __global__ void project_table_kernel(const float* __restrict__ bps, const float*
                      __uint_as_float((unsigned)(cy1 * fw + cx0) | ((unsigned)(cy1 * fw + cx1) << 16)), 0.f, 0.f);
 }
 
+// The three small input kernels of a forward in ONE launch (round 4: each is a 5-7 us link of a small batch's latency chain):
+// rows blockIdx.y < views are project_table_kernel with the view's inverse extrinsic computed by the block itself (invert4x4, the
+// same fp64 elimination) and the sample's centre read from reference_joints; the rows behind them are prep_xyz_kernel's elements.
+__global__ void input_tables_kernel(const float* __restrict__ bps, const float* __restrict__ ref_joints, const float* __restrict__ tmpl,
+                                    const int* __restrict__ view_sample, const float* __restrict__ intr,
+                                    const float* __restrict__ extr, float4* __restrict__ tab, float* __restrict__ centre,
+                                    float* __restrict__ pt_xyz, float* __restrict__ query_xyz, int views, int B, int S, int Q, int fw,
+                                    int fh, float inv_w, float inv_h, float radius) {
+  if ((int)blockIdx.y >= views) {
+    const long i = ((long)(blockIdx.y - views) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    poem_prep_xyz_elem(i, ref_joints, bps, tmpl, centre, pt_xyz, query_xyz, B, S, Q, radius);
+    return;
+  }
+  __shared__ float Tinv[16];
+  __shared__ float ctr[3];
+  if (threadIdx.x == 0) invert4x4(extr + (size_t)blockIdx.y * 16, Tinv);
+  if (threadIdx.x >= 64 && threadIdx.x < 67) ctr[threadIdx.x - 64] = ref_joints[((size_t)view_sample[blockIdx.y] * 21 + 9) * 3 + (threadIdx.x - 64)];
+  __syncthreads();
+  float* const uv = nullptr;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = blockIdx.y;
+  if (s >= S) return;
+  const float* c = ctr;
+  const float px = bps[s * 3 + 0] + c[0], py = bps[s * 3 + 1] + c[1], pz = bps[s * 3 + 2] + c[2];
+  const float* T = Tinv;
+  const float cx = fmaf(T[2], pz, fmaf(T[1], py, T[0] * px)) + T[3];
+  const float cy = fmaf(T[6], pz, fmaf(T[5], py, T[4] * px)) + T[7];
+  const float cz = fmaf(T[10], pz, fmaf(T[9], py, T[8] * px)) + T[11];
+  const float* K = intr + (size_t)v * 9;
+  const float qx = fmaf(K[2], cz, fmaf(K[1], cy, K[0] * cx));
+  const float qy = fmaf(K[5], cz, fmaf(K[4], cy, K[3] * cx));
+  float qz = fmaf(K[8], cz, fmaf(K[7], cy, K[6] * cx));
+  if (fabsf(qz) < 1e-7f) qz = 1e-7f;
+  const float u = qx / qz, w = qy / qz;
+  const float gx = u * inv_w * 2.0f - 1.0f, gy = w * inv_h * 2.0f - 1.0f;
+  const float ix = ((gx + 1.0f) * (float)fw - 1.0f) / 2.0f;
+  const float iy = ((gy + 1.0f) * (float)fh - 1.0f) / 2.0f;
+  if (uv) reinterpret_cast<float2*>(uv)[(size_t)v * S + s] = make_float2(ix, iy);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx0, wy1 = iy - fy0;
+  const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+  const bool vx0 = x0 >= 0 && x0 < fw, vx1 = x1 >= 0 && x1 < fw, vy0 = y0 >= 0 && y0 < fh, vy1 = y1 >= 0 && y1 < fh;
+  const float w_nw = (vx0 && vy0) ? wx0 * wy0 : 0.f, w_ne = (vx1 && vy0) ? wx1 * wy0 : 0.f;
+  const float w_sw = (vx0 && vy1) ? wx0 * wy1 : 0.f, w_se = (vx1 && vy1) ? wx1 * wy1 : 0.f;
+  const int cx0 = min(max(x0, 0), fw - 1), cx1 = min(max(x1, 0), fw - 1);
+  const int cy0 = min(max(y0, 0), fh - 1), cy1 = min(max(y1, 0), fh - 1);
+  float4* o = tab + ((size_t)v * S + s) * 2;
+  o[0] = make_float4(w_nw, w_ne, w_sw, w_se);
+  o[1] = make_float4(__uint_as_float((unsigned)(cy0 * fw + cx0) | ((unsigned)(cy0 * fw + cx1) << 16)),
+                     __uint_as_float((unsigned)(cy1 * fw + cx0) | ((unsigned)(cy1 * fw + cx1) << 16)), 0.f, 0.f);
+}
+
+
 static int cu_count() { return poem_device_cus(); }
 
 template <int C, int P, int NW>
@@ -390,6 +444,18 @@ extern "C" hipError_t poem_launch_project_table(const float* bps, const float* c
                                                 int S, int img_w, int img_h, hipStream_t s) {
   hipLaunchKernelGGL(project_table_kernel, dim3((S + 255) / 256, views), dim3(256), 0, s, bps, centre, view_sample, intr, inv_extr,
                      (float4*)tab, uv, views, S, fw, fh, 1.0f / (float)img_w, 1.0f / (float)img_h, C);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t poem_launch_input_tables(const float* bps, const float* ref_joints, const float* tmpl, const int* view_sample,
+                                               const float* intr, const float* extr, void* tab, float* centre, float* pt_xyz,
+                                               float* query_xyz, int views, int B, int S, int Q, int fh, int fw, int img_w, int img_h,
+                                               float radius, hipStream_t s) {
+  const unsigned gx = (unsigned)((S + 255) / 256);
+  const long total = (long)B * S * 3 + (long)B * Q * 3 + 3L * B;
+  const unsigned prep_rows = (unsigned)((total + (long)gx * 256 - 1) / ((long)gx * 256));
+  hipLaunchKernelGGL(input_tables_kernel, dim3(gx, (unsigned)views + prep_rows), dim3(256), 0, s, bps, ref_joints, tmpl, view_sample, intr,
+                     extr, (float4*)tab, centre, pt_xyz, query_xyz, views, B, S, Q, fw, fh, 1.0f / (float)img_w, 1.0f / (float)img_h, radius);
   return hipGetLastError();
 }
 

@@ -9,24 +9,7 @@
 __global__ void prep_xyz_kernel(const float* __restrict__ ref_joints, const float* __restrict__ bps,
                                 const float* __restrict__ tmpl, float* __restrict__ centre, float* __restrict__ pt_xyz,
                                 float* __restrict__ query_xyz, int B, int S, int Q, float radius) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long n_pt = (long)B * S * 3, n_q = (long)B * Q * 3;
-  if (i < n_pt) {
-    const int d = (int)(i % 3), s = (int)((i / 3) % S), b = (int)(i / (3L * S));
-    const float c = ref_joints[((size_t)b * 21 + 9) * 3 + d];
-    const float w = __fadd_rn(bps[s * 3 + d], c);
-    pt_xyz[i] = __fdiv_rn(__fsub_rn(w, c), radius);
-  } else if (i < n_pt + n_q) {
-    const long k = i - n_pt;
-    const int d = (int)(k % 3), qq = (int)((k / 3) % Q), b = (int)(k / (3L * Q));
-    const float c = ref_joints[((size_t)b * 21 + 9) * 3 + d];
-    const float w = __fadd_rn(c, tmpl[qq * 3 + d]);
-    query_xyz[k] = __fdiv_rn(__fsub_rn(w, c), radius);
-  } else if (i < n_pt + n_q + 3L * B) {
-    const long k = i - n_pt - n_q;
-    const int d = (int)(k % 3), b = (int)(k / 3);
-    centre[k] = ref_joints[((size_t)b * 21 + 9) * 3 + d];
-  }
+  poem_prep_xyz_elem((long)blockIdx.x * blockDim.x + threadIdx.x, ref_joints, bps, tmpl, centre, pt_xyz, query_xyz, B, S, Q, radius);
 }
 
 extern "C" hipError_t poem_launch_prep_xyz(const float* ref_joints, const float* bps, const float* tmpl, float* centre,
@@ -251,3 +234,5 @@ extern "C" hipError_t poem_launch_view_layout(const ViewLayoutArgs* a, hipStream
   hipLaunchKernelGGL(view_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *a);
   return hipGetLastError();
 }
+
+extern "C" int poem_device_cu_count(void) { return poem_device_cus(); }

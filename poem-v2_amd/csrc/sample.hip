@@ -226,25 +226,6 @@ extern "C" hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, con
 // upstream) down to the un-normalised sampling coordinates of grid_sample(align_corners=False):
 //   T = inv(cam_extr[v]) (fp64 Gauss-Jordan, rounded to fp32);  p = T_R (bps + centre) + T_t;  q = K p;
 //   z = |q_z| < 1e-7 ? 1e-7 : q_z;  uv = q_xy / z;  grid = uv * (1/res) * 2 - 1;  ix = ((grid_x + 1) * W - 1) / 2.
-__device__ void invert4x4(const float* __restrict__ m, float* __restrict__ out) {
-  double a[4][8];
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) { a[i][j] = (double)m[i * 4 + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
-  for (int c = 0; c < 4; ++c) {
-    int piv = c;
-    double best = fabs(a[c][c]);
-    for (int i = c + 1; i < 4; ++i) if (fabs(a[i][c]) > best) { best = fabs(a[i][c]); piv = i; }
-    if (piv != c) for (int j = 0; j < 8; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
-    const double inv = 1.0 / a[c][c];
-    for (int j = 0; j < 8; ++j) a[c][j] *= inv;
-    for (int i = 0; i < 4; ++i) if (i != c) {
-      const double f = a[i][c];
-      for (int j = 0; j < 8; ++j) a[i][j] -= f * a[c][j];
-    }
-  }
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i * 4 + j] = (float)a[i][4 + j];
-}
-
 __global__ void invert_extr_kernel(const float* __restrict__ extr, float* __restrict__ inv, int views) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v < views) invert4x4(extr + (size_t)v * 16, inv + (size_t)v * 16);
