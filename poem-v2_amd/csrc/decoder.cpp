@@ -124,14 +124,15 @@ struct DecoderRun {
     } else {
       HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, anchored ? 4 : 6, outs, modes, sb));
     }
+    if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));      // the cross attentions wait for the K / V images only
     if (anchored) {
       // the vector cross attention of block 0 reads only the 32 anchor rows of (kc | vc): project just those (the same
-      // fma chain per element as the full GEMM's rows)
+      // fma chain per element as the full GEMM's rows); its own event: the first cross attention does not wait for them
       HIPCHK(poem_launch_gather_anchor_rows(pt_feats, C, h->anchor_idx, S, p.anch_x[1], B, C, p.ident, sb));
       HIPCHK(poem_launch_gemm(p.anch_x[1], C, (const float*)f.w[0] + (size_t)4 * C * C, f.b[0] + 4 * C, nullptr, 0,
                               p.anch_kv[1], 2 * C, B * 32, 2 * C, C, POEM_ACT_NONE, sb));
+      if (ov) HIPCHK(hipEventRecord(h->ev_xyz[0], sb));    // (ev_xyz[0]: block 0 has no neighbour search to use it for)
     }
-    if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));
     return POEM_OK;
   }
 
@@ -171,13 +172,18 @@ struct DecoderRun {
     ldh = 2 * C; hidden_mod = 0; q_batch = Q;
     q0 = p.qeqp + C;
     if (tables && i == 0) {
-      // every sample's block-0 query features are the learned embedding table: F2 on its Q rows, once
-      HIPCHK(poem_launch_gemm_split(h->R(T_QEMB), C, h->fused[i].w[1], h->fused[i].b[1], nullptr, 0, p.qeqp0, 2 * C, Q, 2 * C, C,
-                                    POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, s));
+      // every sample's block-0 query features are the learned embedding table: F2 on its Q rows, once -- at poem_create (the
+      // handle's copy; same launch, same inputs: bit-identical), or here when the per-forward tables are asked for
+      const float* qe0 = p.qeqp0;
+      if (h->tables_cached && h->c_qeqp0 && h->precision == POEM_PRECISION_FP32)
+        qe0 = h->c_qeqp0;
+      else
+        HIPCHK(poem_launch_gemm_split(h->R(T_QEMB), C, h->fused[i].w[1], h->fused[i].b[1], nullptr, 0, p.qeqp0, 2 * C, Q, 2 * C, C,
+                                      POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, s));
       if (chain) {       // ... and read by every sample in place: queries with batch stride 0, residual rows modulo Q
-        hidden = p.qeqp0; hidden_mod = Q; q0 = p.qeqp0 + C; q_batch = 0;
+        hidden = qe0; hidden_mod = Q; q0 = qe0 + C; q_batch = 0;
       } else {
-        HIPCHK(poem_launch_broadcast(p.qeqp0, p.qeqp, (long)Q * 2 * C, B, s));
+        HIPCHK(poem_launch_broadcast(qe0, p.qeqp, (long)Q * 2 * C, B, s));
       }
     } else if (!(chain && i > 0)) {    // (chain mode: block i-1's last chain already wrote p.qeqp)
       HIPCHK(poem_launch_gemm_split(feats, C, h->fused[i].w[1], h->fused[i].b[1], nullptr, 0, p.qeqp, 2 * C, BQ, 2 * C, C,
@@ -296,9 +302,11 @@ struct DecoderRun {
       if (anchor_from_y3)      // keys / values straight from the rows the chain projected: neighbour j = query row anchor_idx[j] (Q2)
         HIPCHK(poem_launch_vector_attention_anchored(h->anchor_idx, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->P(vsb + 10), p.tab_g[0], p.tab_p[0],
                                                      p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, s));
-      else
+      else {
+      if (ov) HIPCHK(hipStreamWaitEvent(s, h->ev_xyz[0], 0));      // p.ident is written on the basis-point stream (basis_point_side(0))
       HIPCHK(poem_launch_vector_attention_anchored(p.ident, p.y3, p.anch_kv[0], p.anch_kv[0] + C, 32, h->P(vsb + 10), p.tab_g[0],
                                                    p.tab_p[0], p.rs, B, Q, C, 3 * C, 2 * C, 2 * C, s));
+      }
     } else {
       poem_vecattn_one_query_blocks(h->va_p1);
       HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
@@ -331,6 +339,7 @@ struct DecoderRun {
                                                 p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4), h->R(vcb + 5), sw.w[0],
                                                 h->R(vcb + 7), sw.w[1], sw.w[2], sw.scales, p.rc, B, Q, C, C, C, C, s));
     } else if (tables && i == 0) {
+      if (ov) HIPCHK(hipStreamWaitEvent(s, h->ev_xyz[0], 0));      // the anchor rows of (kc | vc), basis_point_side(0)
       HIPCHK(poem_launch_vector_attention_anchored(p.ident, p.qc, p.anch_kv[1], p.anch_kv[1] + C, 32, h->P(vcb + 10), p.tab_g[1],
                                                    p.tab_p[1], p.rc, B, Q, C, C, 2 * C, 2 * C, s));
     } else {

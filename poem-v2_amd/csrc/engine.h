@@ -170,6 +170,9 @@ struct poem_handle_s {
   bool tables_pending = false;       // this forward built the tables on the side stream: consumers wait for ev_tab
   float* tab_mem = nullptr;
   float *c_canon_xyz = nullptr, *c_tab_g[2] = {}, *c_tab_p[2] = {};
+  // block 0's F2 on the anchor-table path acts on the learned query embedding, the same Q rows for every sample: a function of the
+  // weights only -- folded at poem_create like the tables (round 4; it was a 45-75 us GEMM in front of the first cross attention)
+  float* c_qeqp0 = nullptr;
   hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {}, ev_def[8] = {};
   // When the basis-point side (F1) of block i + 1 is issued: 0 = every block's up front, beside block 0 (large batches: the
   // matrix pipe is the limit either way); 1 / 2 / 3 = behind block i's first / second cross attention / its chain -- a small

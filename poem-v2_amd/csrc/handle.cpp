@@ -398,7 +398,8 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   {   // block-0 anchor tables (see poem_handle_s::tables_cached): handle-owned, built here once
     const size_t tf = poem_vector_attention_table_floats(cfg->nquery, C);
     const size_t cx = align_up((size_t)cfg->nquery * 3, 64);
-    if (hipMalloc((void**)&h->tab_mem, (cx + 4 * tf) * sizeof(float)) != hipSuccess) {
+    const size_t qf = align_up((size_t)cfg->nquery * 2 * C, 64);
+    if (hipMalloc((void**)&h->tab_mem, (cx + 4 * tf + qf) * sizeof(float)) != hipSuccess) {
       g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
     }
     h->c_canon_xyz = h->tab_mem;
@@ -410,6 +411,11 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
     }
     rc = build_anchor_tables(h, tp, s, true);
     if (rc != POEM_OK) { poem_destroy(h); return rc; }
+    h->c_qeqp0 = h->tab_mem + cx + 4 * tf;
+    if (poem_launch_gemm_split(h->R(T_QEMB), C, h->fused[0].w[1], h->fused[0].b[1], nullptr, 0, h->c_qeqp0, 2 * C, cfg->nquery, 2 * C, C,
+                               POEM_ACT_NONE, 2 * C, POEM_ACT_NONE, s) != hipSuccess) {
+      g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
+    }
   }
   *out = h;
   return POEM_OK;
