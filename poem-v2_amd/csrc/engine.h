@@ -159,7 +159,10 @@ struct poem_handle_s {
   static constexpr size_t GRAPH_CAP = 12;
   // counters (poem_graph_stats)
   int64_t graph_captures = 0, graph_instantiations = 0, graph_replays = 0, plain_forwards = 0, layout_uploads = 0;
-  int small_batch = 1;       // small-batch launch shapes (decoder.cpp); part of the graph key
+  // launch-count / dependency shortcuts, one bit each (A/B; all bit-identical): 1 = one input launch (coordinates + inverse extrinsics
+  // + projection table) and no embedding broadcast where block 0 runs on the tables; 2 = block 0's anchor keys / values out of the
+  // chain's rows (small batches); 4 = block 0's F1 as two launches, the first attention waiting for its own (K | V) only
+  int small_batch = 3;
   int knn_fma = 0;           // neighbour distances with the fma contraction of pytorch3d's CUDA kernel (knn.hip); default: the CPU path's rounding
   int chain_tile = 0;        // chain row-tile height: 0 = per launch (chain.hip chain_tile_p), 1 = 32 rows, 2 = 64 rows (A/B)
   // The block-0 anchor tables are functions of the handle's constants only (template, anchors, weights): like the folded

@@ -121,7 +121,7 @@ struct HeadRun {
     fused_fe = h->fused_sampling && h->precision == POEM_PRECISION_FP32 && poem_sample_merge_supported(C, S, HW) != 0;
     HIPCHK(poem_launch_conv1x1(mlvl_feat, h->P(T_INPROJ_W), h->R(T_INPROJ_B), h->pe_table, p.pe_index,
                                (fused_fe && !h->taps) ? nullptr : p.x, fused_fe ? p.xt : nullptr, BN, c.in_channels, C, HW, s));
-    if (fused_fe && h->small_batch) {      // coordinates, inverted extrinsics and the projection table in one launch (merge.hip)
+    if (fused_fe && (h->small_batch & 1)) {      // coordinates, inverted extrinsics and the projection table in one launch (merge.hip)
       HIPCHK(poem_launch_input_tables(h->bps, reference_joints, h->tmpl, p.view_sample, cam_intr, cam_extr, p.ptab, p.centre, p.pt_xyz,
                                       p.xyz[0], BN, B, S, Q, c.feat_h, c.feat_w, img_w, img_h, c.radius, s));
       return POEM_OK;
@@ -182,7 +182,7 @@ struct HeadRun {
     if (prof_fe) HIPCHK(hipEventRecord(h->prof_ev[2 * prof_slot + 1], st));
     // query_feat_embedding for every sample -- read only where block 0 does not run on the anchor tables (there F2 is evaluated
     // once on the embedding table's own Q rows, decoder.cpp query_projection)
-    if (!(h->anchor_tables && h->precision == POEM_PRECISION_FP32 && h->small_batch))
+    if (!(h->anchor_tables && h->precision == POEM_PRECISION_FP32 && (h->small_batch & 1)))
       HIPCHK(poem_launch_broadcast(h->R(T_QEMB), p.feats0, (long)Q * C, B, st));
     return run_decoder(h, p, p.feats0, p.pt_xyz, p.bps_feat, B, pose_dst, betas_dst, st, true);
   }

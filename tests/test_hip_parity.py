@@ -924,11 +924,21 @@ def test_full_size_batch_properties():
                       ("graphs", 0), ("graphs", 1), ("graphs", 1), ("graphs", 1),
                       # the cross attention's split-key partials merged by the chain kernel that consumes them (default), by a
                       # combine launch, inside the attention kernel: the same merge arithmetic in chunk order, three places
-                      ("chain_combine", 0), ("xattn_merge", 1), ("xattn_merge", 0), ("chain_combine", 1)):
+                      ("chain_combine", 0), ("xattn_merge", 1), ("xattn_merge", 0), ("chain_combine", 1),
+                      # round 4: the launch-count / dependency shortcuts (one input launch, no dead embedding broadcast, block 0's F1 as
+                      # two launches, anchor rows out of the chain's rows), the XCD-aware panel map, the split F1, one-query blocks
+                      ("small_batch", 0), ("small_batch", 1), ("gemm_xcd_map", 0), ("gemm_xcd_map", 1), ("f1_split", 0), ("f1_split", 1),
+                      ("va_p1", 1), ("va_p1", 2), ("va_p1", -1), ("bps_defer", 2), ("bps_defer", 0)):
         eng.set_option(name, val)
         with torch.no_grad():
             again = head(feat, metas, rj)["all_coords_preds"]
         assert torch.equal(again, full), (name, val)
+    # the same on a batch of two, where the small-batch shortcuts are the ones in use
+    two = sub([9, 20])
+    for name, val in (("small_batch", 0), ("small_batch", 1), ("xattn_merge", 0), ("xattn_merge", -1), ("va_p1", 0), ("va_p1", -1),
+                      ("chain_tile", 1), ("chain_tile", 0), ("graphs", 0), ("graphs", 1)):
+        eng.set_option(name, val)
+        assert torch.equal(sub([9, 20]), two), (name, val)
     # oracle on 2 samples of the big batch
     b2 = dict(mlvl_feat=batch["mlvl_feat"][:16], reference_joints=batch["reference_joints"][:2],
               img_metas=dict(batch["img_metas"], cam_intr=batch["img_metas"]["cam_intr"][:16],
