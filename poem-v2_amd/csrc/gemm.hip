@@ -481,9 +481,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kslab_kernel(const float* __restr
                                                             const float* __restrict__ bias, const float* __restrict__ R, int ldr,
                                                             float* __restrict__ Y, int ldy, int M, int N, int K, int act,
                                                             int act_split, int act2, PanelSegs segs) {
-  // column blocks fastest: the blocks that share an X row range are neighbours in launch order (same L2 / MALL lines)
+  // column blocks fastest: the blocks that share an X row range are neighbours in the logical order.  Logical order = XCD-major:
+  // workgroups go round-robin over the eight XCDs, so the blocks of XCD x take the x-th eighth of the logical range -- a
+  // contiguous run of row blocks with all their column blocks: an X row block is fetched from HBM by ONE XCD (with the plain
+  // order every XCD holds some column blocks of every row block: 8x the X traffic -- 8.6 GB for POEM-huge's front-end Linear)
   const int ncb = N / (32 * NT);
-  const int cb = blockIdx.x % ncb, rb = blockIdx.x / ncb;
+  const int nb = (int)gridDim.x;
+  const int lb = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int cb = lb % ncb, rb = lb / ncb;
   const int col0 = cb * NT * 32;
   const int pact = (col0 >= act_split) ? act2 : act;
   if (segs.seg_cols == 0) {
