@@ -161,7 +161,16 @@ int poem_set_chains(poem_handle_t h, int enable);
  * sampling kernel is ordered behind the block-0 anchor-table build of the neighbour-search stream (a CU that hosts a table
  * block takes one sampling block instead of two; results unaffected); "graphs" (default 1): replay the launch list of a
  * forward as a hipGraph, keyed by (batch size, workspace, options) -- NOT by the view layout; "graph_eager" (default 0): capture
- * at the first forward of a key instead of the second.  Unknown names return POEM_E_ARG. */
+ * at the first forward of a key instead of the second.
+ * Round 4, all bit-identical: "gemm_xcd_map" (default 1; process-wide): panel GEMM blocks of one XCD own a row range and all its
+ * column panels (csrc/gemm.hip); "f1_split" (default 1): the basis-point GEMM of blocks >= 1 as a 4C- and a 2C-column launch;
+ * "gemm_kslab" (default 1; process-wide): K >= 512 Linears on the K-slab kernel; "bps_defer" (default 0): 1 / 2 / 3 = the
+ * basis-point GEMM of block i+1 behind block i's first / second cross attention / its chain instead of up front; "va_p1"
+ * (default -1 = small batches): one-query blocks of the full vector attention (0 never, 1 / 2 always with 3 / 2 waves per SIMD);
+ * "xattn_merge" -1 / 0 / 1 as above; "small_batch" (default 3), a bit mask of launch-count / dependency shortcuts: 1 = one input
+ * launch (coordinates + inverse extrinsics + projection table) and no query-embedding broadcast where block 0 runs on the anchor
+ * tables, 2 = block 0's anchor keys / values read out of the rows its chain projects (batches of <= 5 samples), 4 = block 0's
+ * basis-point GEMM as two launches (measured 1 % slower: off).  Unknown names return POEM_E_ARG. */
 int poem_set_option(poem_handle_t h, const char* name, int value);
 /* Block-0 anchor tables of poem_head_forward (default on, fp32 mode).  In the first decoder block every query's
  * neighbours are the 32 fixed anchors (anchor_points, lib/models/bricks/point_transformers.py:10-32) and every sample's

@@ -1024,6 +1024,29 @@ def test_head_on_two_streams_keeps_one_engine_per_stream():
         assert torch.equal(g, w_)
 
 
+def test_view_layout_arrays_for_any_ragged_batch():
+    """The CSR arrays of a ragged batch are built on the device from offsets carried in a kernel's argument segment
+    (csrc/misc.hip view_layout_kernel): through the whole path, batches at the edges of that route -- one sample, one view each,
+    max_views each, a batch larger than the head has seen -- give the same results as the same samples run one by one (the
+    per-sample runs use the trivial layout [0, n])."""
+    import random
+    spec = dict(embed=128, nsample=4096, views=[1], seed=74, parametric=False)
+    head = build_hip_head(spec, DEV)
+    rng = random.Random(3)
+    for views in ([1], [10], [1] * 7, [10] * 3, [rng.randint(1, 10) for _ in range(13)], [2, 1, 10, 1, 3]):
+        cfg, w, consts, batch = case_setup(dict(spec, views=views, seed=200 + len(views)))
+        feat, metas, rj = batch_to(batch, DEV)
+        with torch.no_grad():
+            full = head(feat, metas, rj)["all_coords_preds"]
+            offs = np.concatenate([[0], np.cumsum(views)])
+            for i in sorted({0, len(views) // 2, len(views) - 1}):
+                rows = torch.arange(int(offs[i]), int(offs[i + 1])).to(DEV)
+                m = dict(metas, cam_intr=metas["cam_intr"][rows].contiguous(), cam_extr=metas["cam_extr"][rows].contiguous(),
+                         cam_view_num=np.asarray([views[i]]), master_id=[0])
+                one = head(feat[rows].contiguous(), m, rj[i:i + 1].contiguous())["all_coords_preds"]
+                assert torch.equal(one[:, 0], full[:, i]), (views, i)
+
+
 def test_retired_graph_execs_are_reused_not_accumulated():
     """Heads come and go (engine rebuilds after load_state_dict, test suites, periodic evaluation): a destroyed handle parks its
     graph execs -- they cannot be destroyed on this runtime (csrc/handle.cpp) -- and the next capture of the same shape takes
