@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_stream_kernel(const float* _
     if constexpr (NGK >= 2) {
       // Head dims 128 / 256 (round 4): ONE wave per SIMD (the query fragment and the output tiles alone are 192 / 256 registers),
       // so nothing hides a load but the wave's own distance to it -- and one 8 KB group ahead is 32 MFMAs = 0.85 us, less than
-      // an L2 / MALL round trip under load (POEM-huge: 0.36 of the matrix pipe).  Ring of FOUR groups, three in flight: the
+      // an L2 / MALL round trip under load.  Ring of FOUR groups, three in flight: the
       // 2 NGK groups of a tile (K groups, then V pairs) are 4 or 8, so every group's slot is a compile-time constant.
       float4 ring[4][8];
       // group n of the current tile: K group n | V pair n - NGK | the NEXT tile's K group n - 2 NGK | its V pair n - 3 NGK
@@ -546,15 +546,9 @@ __global__ __launch_bounds__(256 * W, W) void xattn_stream_kernel(const float* _
       XS_LOAD(0, 0) XS_LOAD(1, 0) XS_LOAD(2, 0)
       __builtin_amdgcn_sched_barrier(0);
       for (int kt = 0; kt < tpc; ++kt) {
-        // keep the CU's waves on the same K/V GROUP: a tile is 32 / 64 KB here -- more than the 32 KB L1 --, so waves that drift
-        // by a tile each fetch their own copy from L2 (4 x 64 KB per tile-time and CU = 9.6 TB/s chip-wide at full MFMA rate:
-        // the kernel ran at the L2's pace, 0.38 of the matrix pipe).  A barrier per tile, loads issued group by group right
-        // behind it: the four waves' requests for a line arrive together.
-        if (map) __builtin_amdgcn_s_barrier();
+        if (map && (kt & 3) == 0 && kt) __builtin_amdgcn_s_barrier();   // keep the CU's waves on the same K/V tiles (see xattn_kernel)
         const int adv = (kt + 1 < tpc) ? ktile_bytes : 0;
-        // two score accumulators (even / odd k-steps), added once per tile: with one wave per SIMD a chain of 128 MFMAs on ONE
-        // accumulator pays the dependent-issue latency 128 times and nobody else is there to fill it
-        f32x16 s = zero16(), s1 = zero16();
+        f32x16 s = zero16();
 #pragma unroll
         for (int g = 0; g < NGK; ++g) {
           XS_LOAD(g + 3, adv)
@@ -564,14 +558,12 @@ __global__ __launch_bounds__(256 * W, W) void xattn_stream_kernel(const float* _
             const float4 a = ring[g & 3][e];
             const float4 bq = qs[(g * 8 + e) * 64];
             s = mfma32(a.x, bq.x, s);
-            s1 = mfma32(a.y, bq.y, s1);
+            s = mfma32(a.y, bq.y, s);
             s = mfma32(a.z, bq.z, s);
-            s1 = mfma32(a.w, bq.w, s1);
+            s = mfma32(a.w, bq.w, s);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] += s1[i];
         POEM_SOFTMAX_TILE(DT)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
