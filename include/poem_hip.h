@@ -169,8 +169,8 @@ int poem_set_chains(poem_handle_t h, int enable);
  * (default -1 = small batches): one-query blocks of the full vector attention (0 never, 1 / 2 always with 3 / 2 waves per SIMD);
  * "xattn_merge" -1 / 0 / 1 as above; "small_batch" (default 3), a bit mask of launch-count / dependency shortcuts: 1 = one input
  * launch (coordinates + inverse extrinsics + projection table) and no query-embedding broadcast where block 0 runs on the anchor
- * tables, 2 = block 0's anchor keys / values read out of the rows its chain projects (batches of <= 5 samples), 4 = block 0's
- * basis-point GEMM as two launches (measured 1 % slower: off).  Unknown names return POEM_E_ARG. */
+ * tables, 2 = block 0's anchor keys / values read out of the rows its chain projects (batches of <= 5 samples).
+ * Unknown names return POEM_E_ARG. */
 int poem_set_option(poem_handle_t h, const char* name, int value);
 /* Block-0 anchor tables of poem_head_forward (default on, fp32 mode).  In the first decoder block every query's
  * neighbours are the 32 fixed anchors (anchor_points, lib/models/bricks/point_transformers.py:10-32) and every sample's

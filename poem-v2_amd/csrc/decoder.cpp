@@ -61,7 +61,6 @@ struct DecoderRun {
   const float* anchor = nullptr;
   int shared = 0;
   bool knn_issued[9] = {};
-  bool kv2_event = false;           // block 0's second pair of attention images has its own event (ev_knn[0])
   bool anchor_from_y3 = false;      // block 0 on the tables: (kg | v) of the anchor rows are rows of p.y3 (small batches)
 
   DecoderRun(poem_handle_t h_, Plan& p_, const float* feats_in, const float* pt_xyz_, const float* pt_feats_, int B_, float* pose,
@@ -122,19 +121,10 @@ struct DecoderRun {
       HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, 4, outs, modes, sb));
       HIPCHK(poem_launch_gemm_segs(pt_feats, C, (const float*)f.w[0] + (size_t)4 * C * C, f.b[0] + 4 * C, BS, C, POEM_ACT_NONE, C, 2, outs + 4,
                                    modes + 4, sb));
-    } else if (anchored && ov && (h->small_batch & 4)) {
-      // block 0 is the one block whose F1 sits on the critical path (nothing of the query side can start before its first
-      // attention has keys): the first attention's (K | V) images as their own launch, the second attention's behind them
-      HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, 2, outs, modes, sb));
-      HIPCHK(hipEventRecord(h->ev_bps[i], sb));
-      HIPCHK(poem_launch_gemm_segs(pt_feats, C, (const float*)f.w[0] + (size_t)2 * C * C, f.b[0] + 2 * C, BS, C, POEM_ACT_NONE, C, 2, outs + 2,
-                                   modes + 2, sb));
-      HIPCHK(hipEventRecord(h->ev_knn[0], sb));            // (ev_knn[0]: block 0 has no neighbour search to use it for)
-      kv2_event = true;
     } else {
       HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, anchored ? 4 : 6, outs, modes, sb));
     }
-    if (ov && !(kv2_event && i == 0)) HIPCHK(hipEventRecord(h->ev_bps[i], sb));      // the cross attentions wait for the K / V images only
+    if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));      // the cross attentions wait for the K / V images only
     if (anchored) {
       // the vector cross attention of block 0 reads only the 32 anchor rows of (kc | vc): project just those (the same
       // fma chain per element as the full GEMM's rows); its own event: the first cross attention does not wait for them
@@ -242,7 +232,6 @@ struct DecoderRun {
       ca.ln_g = h->R(a1 + 8); ca.ln_b = h->R(a1 + 9); ca.y1 = p.h_attn; ca.ldy1 = C;
       ca.w2 = (const float4*)h->P(a2 + 0); ca.b2 = h->R(a2 + 1); ca.n2 = 1; ca.y2 = p.qp; ca.ldy2 = C;
       HIPCHK(poem_launch_chain(&ca, C, s));
-      if (kv2_event && i == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[0], 0));      // the second attention's images (basis_point_side(0))
       HIPCHK(attention(p.qp, C, Q, p.y1[i] + (size_t)2 * BS * C, p.y1[i] + (size_t)3 * BS * C));
       if (const int rc = deferred_basis_point_side(i, 2); rc != POEM_OK) return rc;
       ChainArgs cb = chain_args(0);
@@ -275,7 +264,6 @@ struct DecoderRun {
         ldq = C;
       }
       if (ov && a == 0) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
-      if (kv2_event && i == 0 && a == 1) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[0], 0));
       if (h->precision == POEM_PRECISION_SPLIT_F16X3_ALL) poem_cross_attention_split(h->kv_presplit[i] ? 2 : 1);
       if (h->precision == POEM_PRECISION_FP32 && merge_in_attention() && poem_cross_attention_merges(S, C, c.heads))
         HIPCHK(poem_launch_cross_attention_merged(qptr, ldq, Q, p.y1[i] + (size_t)(2 * a) * BS * C, p.y1[i] + (size_t)(2 * a + 1) * BS * C,

@@ -161,7 +161,8 @@ struct poem_handle_s {
   int64_t graph_captures = 0, graph_instantiations = 0, graph_replays = 0, plain_forwards = 0, layout_uploads = 0;
   // launch-count / dependency shortcuts, one bit each (A/B; all bit-identical): 1 = one input launch (coordinates + inverse extrinsics
   // + projection table) and no embedding broadcast where block 0 runs on the tables; 2 = block 0's anchor keys / values out of the
-  // chain's rows (small batches); 4 = block 0's F1 as two launches, the first attention waiting for its own (K | V) only
+  // chain's rows (small batches).  (Measured and dropped: block 0's F1 as two launches, +1 %; a small batch's later F1 GEMMs on
+  // a quarter of the CUs, +4 % at B = 4.)
   int small_batch = 3;
   int knn_fma = 0;           // neighbour distances with the fma contraction of pytorch3d's CUDA kernel (knn.hip); default: the CPU path's rounding
   int chain_tile = 0;        // chain row-tile height: 0 = per launch (chain.hip chain_tile_p), 1 = 32 rows, 2 = 64 rows (A/B)
