@@ -110,8 +110,9 @@ class POEM_Generalized_Head(nn.Module):
         # and, unlike a cached list of Parameter objects, sees a Parameter that was REPLACED.
         #   ONE ENGINE PER STREAM: an engine's workspace, layout arrays and side streams serve one forward at a time, in stream
         # order.  A caller that alternates small batches over two (or more) torch streams -- the way to fill 256 CUs with batches
-        # of 2, the reference's evaluation batch -- gets one engine per stream, so consecutive forwards overlap on the GPU
-        # (scripts/eval_single.py --streams, bench.py small_batch_scope `two_streams`).  Same kernels, same bits.
+        # of 2, the reference's evaluation batch -- gets one engine per stream, so consecutive forwards never share scratch
+        # memory and may overlap on the GPU (bench.py small_batch_scope `two_streams`: +7 % at batch 4, nothing at batch <= 2
+        # with the default four hardware queues).  Same kernels, same bits.
         self._pcheck = getattr(self, "_pcheck", 0) + 1
         if getattr(self, "_plist", None) is None or self._pcheck % 256 == 0:
             self._plist = [m._parameters for m in self.modules()]      # (the module set itself: refreshed every 256 forwards)
