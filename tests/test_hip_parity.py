@@ -483,6 +483,16 @@ def test_conditioning_sweep_and_cuda_rounding_vs_reference(name):
         # HIP and for the CPU restatement alike (whichever of them flips).  The stage / MPVPE bars are then only meaningful for
         # a run without flips; the neighbour attribution above is what remains checkable (profiles/r03_parity.txt has the numbers).
         if gain > 4 and flips:
+            # ... what IS checkable with flips: everything in front of the first neighbour search (block 0: fixed anchors) on every
+            # row, and block 1 on the rows whose block-1 neighbour sets are the reference's -- their inputs are block 0's outputs,
+            # which no flip has touched; the first decoder layer's mesh (block 0's coordinates) to the gain's MPVPE bar
+            for key, st in rep["stages"].items():
+                if key.startswith("b0.") or key.startswith("b1."):
+                    assert st["clean_rows"] > 0.9, (key, st)
+                    assert st["path_clean"] <= stage_tol * max(st["scale"], 1.0), (fma, key, st)
+            mp0_hip = float(torch.norm(got[0, :, 21:] - ref[0, :, 21:], dim=-1).mean(dim=1).max())
+            mp0_orc = float(torch.norm(orc[0, :, 21:] - ref[0, :, 21:], dim=-1).mean(dim=1).max())
+            assert mp0_hip <= max(1e-6, 3 * mp0_orc), (fma, mp0_hip, mp0_orc)
             continue
         # (the same one step earlier: a run with the OTHER rounding than the fixture's whose near-tie did flip -- small_tie_fma
         #  under the default rounding -- has block-2 rows that gathered the flipped row; stage bars for the matching rounding only)
