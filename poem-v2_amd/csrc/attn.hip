@@ -105,7 +105,11 @@ __device__ long long xattn_ph[8];
 // merges their partials through LDS (attn_combine_kernel's arithmetic, chunk order) and writes the normalised context rows:
 // the partials (4 x 26 MB written per launch at the headline batch and read back by the consumer) never reach HBM.  The waves
 // of a group read different K/V chunks, the W waves with the same chunk the same one (the tile barrier keeps them together).
-template <int DH, int W, bool MERGE = false>
+// HALF (MERGE only, round 4): an item is one 32-channel tile of a query tile's output instead of all DH / 32 of them -- twice the
+// items, each with the full score contraction and softmax but half the P V products (48 instead of 64 MFMAs per key tile).  More
+// MFMAs in all, so it only pays where the launch is one under-filled round anyway: a single sample (100 query-tile items on 256
+// CUs -> 200).  Every output element is the same fma chain as without it.
+template <int DH, int W, bool MERGE = false, bool HALF = false>
 __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restrict__ q, int ldq, int qbr,
                                                            const float4* __restrict__ kimg,
                                                            const float4* __restrict__ vimg,
@@ -113,10 +117,12 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
                                                            int B, int NQ, int NK, int C, int heads, int tpc, float kc2,
                                                            float lazy_raw, int map, int prio_rot, float* __restrict__ ctx) {
   constexpr int KC = DH / 8;               // K fragments (float4) per key tile
-  constexpr int DT = (DH + 31) / 32;       // 32-channel tiles of the output
+  constexpr int DTF = (DH + 31) / 32;      // 32-channel tiles of the output
+  constexpr int DT = HALF ? 1 : DTF;       // ... of an item
+  static_assert(!HALF || MERGE, "channel-tile items exist in the merged form only");
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
   const int nqt = (NQ + 31) / 32, nkt = NK / 32, chunks = nkt / tpc;
-  const int items = MERGE ? B * heads * nqt : B * heads * chunks * nqt;      // MERGE: one item = a query tile, all four chunks
+  const int items = MERGE ? B * heads * nqt * (HALF ? DTF : 1) : B * heads * chunks * nqt;      // MERGE: one item = a query tile, all four chunks
   extern __shared__ __attribute__((aligned(16))) float xa_lds[];            // MERGE: 4W x (DT*4 x 64 float4 | 32 float2)
   // logical block id: blocks of one XCD (blockIdx % 8) take neighbouring item ranges -> one L2 serves a K/V chunk
   const int nb = gridDim.x;
@@ -145,8 +151,9 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
 #ifdef POEM_LAB
     ++dbg_items;
 #endif
-    const int qt = item % nqt;
-    int t = item / nqt;
+    const int d0 = HALF ? item % DTF : 0;      // first output channel tile of this item
+    const int qt = (HALF ? item / DTF : item) % nqt;
+    int t = (HALF ? item / DTF : item) / nqt;
     const int ch = MERGE ? (wv & 3) : t % chunks;
     if (!MERGE) t /= chunks;
     const int head = t % heads, b = t / heads;
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) vf[d][g] = frag_load(vrs, loff, voff + (d * 4 + g) * 1024);
+      for (int g = 0; g < 4; ++g) vf[d][g] = frag_load(vrs, loff, voff + ((d0 + d) * 4 + g) * 1024);
     __builtin_amdgcn_sched_barrier(0);
 
     f32x16 o[DT];
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
           __builtin_amdgcn_sched_barrier(0);
 #ifndef POEM_XA_NOLOADS
 #pragma unroll
-          for (int d = 0; d < DT; ++d) vf[d][i >> 2] = frag_load(vrs, loff, voff + (d * 4 + (i >> 2)) * 1024);
+          for (int d = 0; d < DT; ++d) vf[d][i >> 2] = frag_load(vrs, loff, voff + ((d0 + d) * 4 + (i >> 2)) * 1024);
 #endif
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
             acc.x = fmaf(w4[sx], pp.x, acc.x); acc.y = fmaf(w4[sx], pp.y, acc.y);
             acc.z = fmaf(w4[sx], pp.z, acc.z); acc.w = fmaf(w4[sx], pp.w, acc.w);
           }
-          const int d = k >> 2, g = k & 3;
+          const int d = d0 + (k >> 2), g = k & 3;
           *reinterpret_cast<float4*>(out + 32 * d + 8 * g + 4 * h) = make_float4(acc.x / den, acc.y / den, acc.z / den, acc.w / den);
         }
       }
@@ -741,6 +748,8 @@ static int poem_attn_cus() { return poem_device_cus(); }
 
 // opt-in split precision for the calls enqueued while it is set (api.cpp: around poem_head_forward in SPLIT_F16X3_ALL mode,
 // and by the operator-level entry point); head dims 32 and 64 only, the others keep the exact kernels
+static int g_xattn_half = 1;      // A/B: channel-tile items of the merged kernel for a single sample (poem_set_option "xattn_half")
+extern "C" void poem_cross_attention_half(int on) { g_xattn_half = on; }
 static thread_local int g_xattn_split = 0;      // per host thread, like gemm.hip's split context.  1: split from fp32 images, 2: the images are already split (gemm.hip split output modes)
 extern "C" void poem_cross_attention_split(int on) { g_xattn_split = on; }
 
@@ -861,10 +870,18 @@ extern "C" hipError_t poem_launch_cross_attention_merged(const float* q, int ldq
   const float kc2 = (float)(1.4426950408889634 / sqrt((double)DH));
   const float lazy_raw = POEM_ATTN_LAZY_LOG2 / kc2;
   const size_t lds = (size_t)4 * WV * (DT * 4 * 64 * 4 + 64) * sizeof(float);
+  const long items = (long)B * heads * nqt;
+  if (g_xattn_half && items * DT <= poem_attn_cus()) {      // one under-filled round: channel-tile items (xattn_kernel HALF)
+    auto kh = xattn_kernel<DH, WV, true, true>;
+    static std::atomic<unsigned long long> optin_h{0};
+    if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kh), lds, optin_h); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kh, dim3((unsigned)(items * DT)), dim3(256 * WV), lds, s, q, ldq, qbr, (const float4*)kimg, (const float4*)vimg,
+                       (float4*)nullptr, (float2*)nullptr, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, 1, 0, ctx);
+    return hipGetLastError();
+  }
   auto kern = xattn_kernel<DH, WV, true>;
   static std::atomic<unsigned long long> optin{0};
   if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin); e != hipSuccess) return e;
-  const long items = (long)B * heads * nqt;
   const int grid = (int)std::min<long>(poem_attn_cus(), items);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WV), lds, s, q, ldq, qbr, (const float4*)kimg, (const float4*)vimg,
                      (float4*)nullptr, (float2*)nullptr, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, 1, 0, ctx);

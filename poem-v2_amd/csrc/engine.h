@@ -190,6 +190,7 @@ struct poem_handle_s {
   // one-query blocks of the full vector attention (vecattn.hip): -1 = for small batches (B * Q <= 16 x CUs: the busiest CU gets
   // 7 queries instead of 8 at B = 2; measured B = 1 / 2 / 4 -0.7 / -1.7 / -2.0 %), 0 never, 1 / 2 always (3 / 2 waves per SIMD); same bits
   int va_p1 = -1;
+  bool xattn_half = true;    // merged cross attention of a single sample on channel-tile items (attn.hip HALF); part of the graph key
   bool gemm_kslab = true;    // K >= 512 Linears on the K-slab kernel (gemm.hip); part of the graph key
   bool overlap = true;
   // Per-view index arrays (view_offsets | view_sample | pe_index) live in handle-owned device memory and are re-uploaded

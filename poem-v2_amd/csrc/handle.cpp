@@ -463,6 +463,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "graph_eager") h->graph_eager = value != 0;
   else if (k == "gemm_xcd_map") { poem_gemm_xcd_map(value != 0); h->gemm_xcd_map = value != 0; }
   else if (k == "f1_split") h->f1_split = value != 0;
+  else if (k == "xattn_half") { poem_cross_attention_half(value != 0); h->xattn_half = value != 0; }
   else if (k == "va_p1") { if (value < -1 || value > 2) return POEM_E_ARG; h->va_p1 = value; }
   else if (k == "gemm_kslab") { poem_gemm_kslab(value != 0); h->gemm_kslab = value != 0; }
   else if (k == "small_batch") h->small_batch = value;

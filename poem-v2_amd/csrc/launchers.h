@@ -78,6 +78,7 @@ hipError_t poem_launch_pack_split_tiles(const float* w, int N, int K, void* img,
 void poem_gemm_split_context(const void* packed, size_t bytes, const void* split, const float* scales);
 void poem_gemm_split_explicit(const void* img, const float* scales);
 void poem_cross_attention_split(int on);
+void poem_cross_attention_half(int on);
 int poem_cross_attention_merges(int NK, int C, int heads);
 hipError_t poem_launch_cross_attention_merged_rm(const float* q, const float* k, const float* v, float* ctx, int B, int NQ, int NK,
                                                  int C, int heads, float* scratch, hipStream_t s);

@@ -949,6 +949,10 @@ def test_full_size_batch_properties():
                       ("chain_tile", 1), ("chain_tile", 0), ("graphs", 0), ("graphs", 1)):
         eng.set_option(name, val)
         assert torch.equal(sub([9, 20]), two), (name, val)
+    # ... and on a single sample (the merged attention on channel-tile items)
+    for name, val in (("xattn_half", 0), ("xattn_half", 1), ("xattn_merge", 0), ("xattn_merge", -1)):
+        eng.set_option(name, val)
+        assert torch.equal(sub([17]), one), (name, val)
     # oracle on 2 samples of the big batch
     b2 = dict(mlvl_feat=batch["mlvl_feat"][:16], reference_joints=batch["reference_joints"][:2],
               img_metas=dict(batch["img_metas"], cam_intr=batch["img_metas"]["cam_intr"][:16],
