@@ -162,6 +162,11 @@ int poem_set_chains(poem_handle_t h, int enable);
  * block takes one sampling block instead of two; results unaffected); "graphs" (default 1): replay the launch list of a
  * forward as a hipGraph, keyed by (batch size, workspace, options) -- NOT by the view layout; "graph_eager" (default 0): capture
  * at the first forward of a key instead of the second.
+ * Round 3: "tables_cached" (default 1): read the block-0 anchor tables folded at poem_create (0 = rebuild them on every
+ * forward: same kernel, same inputs, bit-identical); "chain_tile" (default 0 = per launch): row-tile height of the chain
+ * kernels, 1 = 32 rows, 2 = 64 rows (csrc/chain.hip), 3 = 16-row units on v_mfma_f32_16x16x4_f32 (csrc/chain16.hip) -- any
+ * choice gives the same bits; "knn_fma" (default 0): neighbour distances rounded as pytorch3d's CUDA kernel (poem_knn_ex below)
+ * -- the one switch that is NOT round-off neutral by design.
  * Round 4, all bit-identical: "gemm_xcd_map" (default 1; process-wide): panel GEMM blocks of one XCD own a row range and all its
  * column panels (csrc/gemm.hip); "f1_split" (default 1): the basis-point GEMM of blocks >= 1 as a 4C- and a 2C-column launch;
  * "gemm_kslab" (default 1; process-wide): K >= 512 Linears on the K-slab kernel; "bps_defer" (default 0): 1 / 2 / 3 = the

@@ -155,6 +155,21 @@ def test_library_exports_every_declared_symbol():
     assert L.poem_error_string(-2) == b"workspace too small"
 
 
+def test_every_option_name_is_documented_in_the_header():
+    """poem_set_option's names (csrc/handle.cpp) against the comment of its declaration in include/poem_hip.h: a switch a
+    maintainer cannot find in the header does not exist for them."""
+    src = open(os.path.join(ROOT, "poem-v2_amd", "csrc", "handle.cpp")).read()
+    body = src[src.index("int poem_set_option("):]
+    body = body[:body.index("\n}\n")]
+    names = sorted(set(re.findall(r'k == "([a-z0-9_]+)"', body)))
+    assert len(names) >= 20, names
+    hdr = open(os.path.join(ROOT, "include", "poem_hip.h")).read()
+    doc = hdr[:hdr.index("int poem_set_option(")]
+    doc = doc[doc.rindex("/*"):]
+    missing = [n for n in names if f'"{n}"' not in doc]
+    assert not missing, missing
+
+
 def test_library_tensor_table_matches_python():
     import ctypes
     L = hip.lib()
