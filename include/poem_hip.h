@@ -323,6 +323,11 @@ int poem_upsample2_concat_pad(const float* a, int ca, const float* b, int cb, fl
 int poem_conv3x3_down2(const float* in, const void* w_packed, const float* scale, const float* shift, const float* residual,
                        float* out, int views, int cin, int cout, int h, int w, int relu, int64_t out_view_stride,
                        int out_ch_stride, int out_row_stride, int out_offset, void* stream);
+/* Process-wide A/B switches of the decode operators (not per handle: these operators take no handle).  Results do not depend on
+ * them.  "s2_staging_wave" (default 1): poem_conv3x3_down2 as one persistent 9-wave block per CU whose ninth wave does all the
+ * LDS-DMA staging while eight waves multiply; 0 = the round-3 kernel in which every wave stages and multiplies.
+ * POEM_E_ARG for an unknown name. */
+int poem_set_decode_option(const char* name, int value);
 /* feat_decode's tail in one launch (POEM.py:190-193: F.interpolate(x, scale_factor=2, mode="bilinear") followed by feat_in, a
  * 1x1 convolution with bias): in (views,cin,h,w) -> out (views,cout,2h,2w).  The convolution is applied BEFORE the
  * interpolation (they commute: both linear, the interpolation weights sum to one) on the matrix cores with the input and the

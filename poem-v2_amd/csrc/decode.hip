@@ -650,7 +650,164 @@ __global__ __launch_bounds__(512, 4) void conv3x3_s2_kernel(Conv3Args A) {
   }
 }
 
+// The stride-2 ConvBlocks with the staging on a wave of its own (round 4).  What held conv3x3_s2_kernel at 0.43-0.52 of the pipe:
+// vmcnt retires IN ORDER, and every wave had its weight fragments (L2 hits) queued behind its own LDS-DMA requests (HBM:
+// microseconds) -- the MFMAs of tap t + 1 could not start before the staging requests issued two taps earlier were back, so a tap
+// took half an HBM round trip instead of 640 cycles (measured: 24 us per chunk for 5.2 us of MFMAs at the 64^2 level).  Here a
+// block is four MFMA waves -- ROWS = 4 output rows of a view = PXB pixel tiles of 32 x CG groups of five 16-channel tiles,
+// (PXB, CG) = (4, 1), (2, 2), (1, 4) -- plus a fifth wave that does nothing but stage: all LDS-DMA requests of the next chunk
+// at the top of the current one, then s_waitcnt vmcnt(0) and the block barrier.  The MFMA waves have only weight fragments in
+// their queues, requested two taps ahead (ring of three) across chunk and tile boundaries, and never wait for them at a barrier.
+// Three persistent blocks per CU (one MFMA wave of each per SIMD, barriers and epilogues out of phase) walk their tiles; the
+// next tile's first chunk is staged during the last chunk and the epilogue of the current one.
+// Staged layout: per channel the 2 ROWS + 1 input rows as they lie in memory (W floats each, no pad column), fetched 16 bytes
+// per lane (gfx950's buffer_load_dwordx4 ... lds: a wave request = 1 KB of LDS, 18 / 9 / 5 requests per chunk instead of 80 / 40
+// / 24 of dwords at stride 2; every 128-byte line is used whole).  The column left of the image (tap column 0 of output
+// column 0) is a select on the operand; rows above / below the image are offsets beyond the descriptor's range (zero).  The
+// stride-2 operand reads are 2- to 4-way bank conflicts on 4 reads per 20 MFMAs: not on the critical path.
+template <int PXB, int CG, int MAXLD, int ROWS>
+__global__ __launch_bounds__(64 * (PXB * CG + 1)) void conv3x3_s2p_kernel(Conv3Args A, int tiles) {
+  constexpr int CT16 = 5, NW = PXB * CG, NR = 2 * ROWS + 1;
+  extern __shared__ __attribute__((aligned(16))) float tile[];      // 4 + 2 x bstride
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, g = lane >> 4;
+  const int W = A.W, Wo = W / 2, Ho = A.H / 2, KC = A.Cin / 8;
+  const int cplane = NR * W, cfl = 8 * cplane, bstride = (cfl + 255) & ~255;
+  const int rblocks = Ho / ROWS;
+  const int plane4 = A.H * W * 4;
+  const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  if (wv == NW) {
+    // ---- staging wave ----
+    int voff[MAXLD];
+    auto stage = [&](int t, int cc, int buf) {
+      const int n = t / rblocks, yo0 = (t % rblocks) * ROWS;
+      const __amdgpu_buffer_rsrc_t xrs = frag_rsrc(A.skip_b + (size_t)n * A.Cin * (A.H * W), (unsigned)((size_t)A.Cin * plane4));
+      if (cc == 0) {
+#pragma unroll
+        for (int u = 0; u < MAXLD; ++u) {
+          const int i = 256 * u + 4 * lane;                   // first of this lane's four staged floats
+          const int chl = i / cplane, rem = i % cplane;
+          const int y = 2 * yo0 - 1 + rem / W, x = rem % W;
+          const bool valid = i < cfl && y >= 0 && y < A.H;
+          voff[u] = valid ? chl * plane4 + (y * W + x) * 4 : 0x7ffffff0;     // beyond the descriptor's range: zeros
+        }
+      }
+      float* base = tile + 4 + buf * bstride;
+      const int soff = __builtin_amdgcn_readfirstlane(8 * cc * plane4);
+#if defined(__HIP_DEVICE_COMPILE__)     // (the host pass checks the 16-byte form against the host target and drops the kernel's stub)
+#pragma unroll
+      for (int u = 0; u < MAXLD; ++u)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(base + 256 * u), 16, voff[u], soff, 0, 0);
+#else
+      (void)xrs; (void)base; (void)soff;
+#endif
+    };
+    int t = (int)blockIdx.x, cc = 0;
+    stage(t, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    const int total = my_tiles * KC;
+    for (int f = 1; f <= total; ++f) {
+      if (++cc == KC) { cc = 0; t += (int)gridDim.x; }
+      if (f < total) stage(t, cc, f & 1);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    return;
+  }
+  // ---- MFMA waves ----
+  const int ptile = wv % PXB, cgrp = wv / PXB;
+  const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(A.wp16 + (size_t)cgrp * CT16 * 9 * KC * 64, 0xffffffffu);
+  int boff[2], opy[2], opx[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int pix = ptile * 32 + 16 * u + j;          // within the block's ROWS x Wo output pixels
+    opy[u] = pix / Wo;
+    opx[u] = pix % Wo;
+    boff[u] = g * cplane + (2 * opy[u]) * W + 2 * opx[u] - 1;        // tap (0, 0) of channel g: input (2 y - 1, 2 x - 1)
+  }
+  f32x2v w0[CT16], w1[CT16], w2[CT16];
+  float ba[4], bb[4];
+  f32x4 acc[CT16][2];
+#define POEM_S2P_LOADW(AW, TAP, CC)                                                                             \
+  _Pragma("unroll") for (int c = 0; c < CT16; ++c)                                                              \
+    AW[c] = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, ((c * 9 + (TAP)) * KC + (CC)) * 512, 0));
+#define POEM_S2P_LOADB(B, TAP)                                                                                  \
+  {                                                                                                             \
+    const int toff_ = ((TAP) / 3) * W + (TAP) % 3;                                                              \
+    B[0] = tb[boff[0] + toff_]; B[1] = tb[boff[1] + toff_];                                                     \
+    B[2] = tb[boff[0] + 4 * cplane + toff_]; B[3] = tb[boff[1] + 4 * cplane + toff_];                           \
+    if constexpr ((TAP) % 3 == 0) {                                                                             \
+      B[0] = opx[0] ? B[0] : 0.f; B[1] = opx[1] ? B[1] : 0.f; B[2] = opx[0] ? B[2] : 0.f; B[3] = opx[1] ? B[3] : 0.f; \
+    }                                                                                                           \
+  }
+#define POEM_S2P_MMA(AW, B)                                                                                     \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                 \
+    _Pragma("unroll") for (int c = 0; c < CT16; ++c) acc[c][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW[c][0], B[u], acc[c][u], 0, 0, 0); \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                                 \
+    _Pragma("unroll") for (int c = 0; c < CT16; ++c) acc[c][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(AW[c][1], B[2 + u], acc[c][u], 0, 0, 0);
+  // tap TAP on (CUR_W, CUR_B); the weights of tap TAP + 2 (of the next chunk past tap 6) and the operands of tap TAP + 1 requested
+#define POEM_S2P_STEP(CUR_W, CUR_B, NXT_W, NXT_B, TAP)                                                          \
+  POEM_S2P_LOADW(NXT_W, ((TAP) + 2) % 9, ((TAP) + 2 >= 9 ? ccn : cc))                                           \
+  if constexpr ((TAP) < 8) POEM_S2P_LOADB(NXT_B, (TAP) + 1)                                                     \
+  __builtin_amdgcn_sched_barrier(0);                                                                            \
+  POEM_S2P_MMA(CUR_W, CUR_B)                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+  POEM_S2P_LOADW(w0, 0, 0)
+  POEM_S2P_LOADW(w1, 1, 0)
+  asm volatile("s_barrier" ::: "memory");                   // chunk 0 of the first tile has landed
+  int f = 0, t = (int)blockIdx.x;
+  for (int it = 0; it < my_tiles; ++it, t += (int)gridDim.x) {
+#pragma unroll
+    for (int c = 0; c < CT16; ++c)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[c][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < KC; ++cc, ++f) {
+      const float* tb = tile + 4 + (f & 1) * bstride;
+      const int ccn = cc + 1 == KC ? 0 : cc + 1;
+      POEM_S2P_LOADB(ba, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      POEM_S2P_STEP(w0, ba, w2, bb, 0) POEM_S2P_STEP(w1, bb, w0, ba, 1) POEM_S2P_STEP(w2, ba, w1, bb, 2)
+      POEM_S2P_STEP(w0, bb, w2, ba, 3) POEM_S2P_STEP(w1, ba, w0, bb, 4) POEM_S2P_STEP(w2, bb, w1, ba, 5)
+      POEM_S2P_STEP(w0, ba, w2, bb, 6) POEM_S2P_STEP(w1, bb, w0, ba, 7) POEM_S2P_STEP(w2, ba, w1, bb, 8)
+      // this chunk's operands have been read (the MFMAs consumed them); the weights in flight stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // epilogue: lane (g, j) holds channels 80 cgrp + 16c + 4g + e of output pixel (unit u, j); per channel tile the eight
+    // residual values first, then the eight stores
+    const int n = t / rblocks, yo0 = (t % rblocks) * ROWS;
+    int ey[2] = {opy[0], opy[1]}, ex[2] = {opx[0], opx[1]}, eg = g;
+    // (opaque to the optimiser: the 40 store addresses are invariant over the tile loop and would be hoisted into 80 registers)
+    asm volatile("" : "+v"(ey[0]), "+v"(ey[1]), "+v"(ex[0]), "+v"(ex[1]), "+v"(eg));
+    const float* __restrict__ resp = A.res ? A.res + (size_t)n * A.Cout * (Ho * Wo) : nullptr;
+    float* __restrict__ outp = A.out + (size_t)n * A.out_ns + A.out_off;
+#pragma unroll
+    for (int c = 0; c < CT16; ++c) {
+      const int cbase = cgrp * (CT16 * 16) + c * 16 + 4 * eg;
+      if (cbase >= A.Cout) continue;                          // Cout % 4 == 0 (80 / 160 / 320)
+      const float4 sc = *reinterpret_cast<const float4*>(A.scale + cbase);
+      const float4 sh = *reinterpret_cast<const float4*>(A.shift + cbase);
+      float rv[4][2];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) rv[e][u] = resp ? resp[(size_t)(cbase + e) * (Ho * Wo) + (yo0 + ey[u]) * Wo + ex[u]] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float v = fmaf(acc[c][u][e], (&sc.x)[e], (&sh.x)[e]);
+          if (A.relu) v = fmaxf(v, 0.f);
+          outp[(size_t)(cbase + e) * A.out_cs + (yo0 + ey[u]) * A.out_rs + ex[u]] = v + rv[e][u];
+        }
+    }
+  }
+#undef POEM_S2P_LOADW
+#undef POEM_S2P_LOADB
+#undef POEM_S2P_MMA
+#undef POEM_S2P_STEP
+}
+
 // Shapes conv3x3_s2_kernel takes: 80 / 160 / 320 output channels on 8-row output tiles of 32 / 16 / 8 columns.
+static int g_s2_staging_wave = 1;       // A/B switch: 0 = conv3x3_s2_kernel (every wave stages and multiplies)
+extern "C" void poem_decode_s2_staging_wave(int on) { g_s2_staging_wave = on != 0; }
 static int conv3x3_s2_shape(int Cout, int H, int W) {
   if (H != W || H % 16) return 0;
   if (Cout == 80 && W == 64) return 1;
@@ -668,8 +825,30 @@ extern "C" hipError_t poem_launch_conv3x3_down2(const float* in, const void* wp,
               H, W, 2, relu, out_ns, out_cs, out_rs, out_off, views, nullptr, in, 0, Cin};
   const int RS = W / 2 + 1, tplane = 17 * 2 * RS, tstride = ((tplane + 63) & ~63) + 16;
   const size_t lds = (size_t)2 * 8 * tstride * sizeof(float);
+  static std::atomic<unsigned long long> optin[6];
+  if (g_s2_staging_wave) {
+    // three persistent 5-wave blocks per CU (four MFMA waves + the staging wave), tiles of four output rows
+    constexpr int ROWS = 4;
+    const int tiles = views * (H / 2 / ROWS);
+    const int cfl = 8 * (2 * ROWS + 1) * W;
+    const size_t lds_p = (size_t)(4 + 2 * ((cfl + 255) & ~255)) * sizeof(float);
+    const dim3 grid((unsigned)std::min(tiles, 3 * poem_device_cus())), block(320);
+    if (shape == 1) {
+      auto k = conv3x3_s2p_kernel<4, 1, 18, ROWS>;
+      if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(k), lds_p, optin[3]); e != hipSuccess) return e;
+      hipLaunchKernelGGL(k, grid, block, lds_p, s, a, tiles);
+    } else if (shape == 2) {
+      auto k = conv3x3_s2p_kernel<2, 2, 9, ROWS>;
+      if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(k), lds_p, optin[4]); e != hipSuccess) return e;
+      hipLaunchKernelGGL(k, grid, block, lds_p, s, a, tiles);
+    } else {
+      auto k = conv3x3_s2p_kernel<1, 4, 5, ROWS>;
+      if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(k), lds_p, optin[5]); e != hipSuccess) return e;
+      hipLaunchKernelGGL(k, grid, block, lds_p, s, a, tiles);
+    }
+    return hipGetLastError();
+  }
   const dim3 grid((unsigned)(views * (H / 2 / 8))), block(512);
-  static std::atomic<unsigned long long> optin[3];
   if (shape == 1) {
     auto k = conv3x3_s2_kernel<8, 1, 18>;
     if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(k), lds, optin[0]); e != hipSuccess) return e;

@@ -1,5 +1,6 @@
 // Operator-level entry points of libpoem_hip.so (include/poem_hip.h names the reference call each one replaces): argument
 // checks around the launchers of launchers.h.  Stream-ordered, no allocation.
+#include <cstring>
 #include "engine.h"
 
 extern "C" {
@@ -251,6 +252,12 @@ int poem_upcat_conv3x3(const float* a_half, int ca, const float* b_full, int cb,
   if (e == hipErrorNotSupported) return POEM_E_UNSUPPORTED;
   HIPCHK(e);
   return POEM_OK;
+}
+
+int poem_set_decode_option(const char* name, int value) {
+  if (!name) return POEM_E_ARG;
+  if (!strcmp(name, "s2_staging_wave")) { poem_decode_s2_staging_wave(value); return POEM_OK; }
+  return POEM_E_ARG;
 }
 
 int poem_conv1x1_upsample2(const float* in, const void* w_packed, const float* bias, float* out, int views, int cin, int cout,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "poem_conv3x3_packed_bytes": (_sz, [_i, _i]),
     "poem_pack_conv3x3": (_i, [_vp, _i, _i, _vp, _vp]),
     "poem_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp]),
+    "poem_set_decode_option": (_i, [ctypes.c_char_p, _i]),
     "poem_conv3x3_down2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp]),
     "poem_upsample2_concat_pad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "poem_conv1x1_upsample2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -109,6 +109,38 @@ def test_conv3x3_down2_operator(cin, cout, r):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,r,views", [(40, 80, 64, 200), (80, 160, 32, 300), (160, 320, 16, 500), (24, 80, 64, 3)])
+def test_conv3x3_down2_staging_wave_is_bit_identical_to_the_round3_kernel(cin, cout, r, views):
+    """poem_conv3x3_down2's default kernel (persistent blocks of four MFMA waves + a staging wave, four-row tiles) against the
+    round-3 kernel (`s2_staging_wave` 0: every wave stages and multiplies, eight-row tiles) -- same summation order, so
+    bit-identical -- at view counts where a block walks several tiles (more tiles than 3 x 256 block slots) and where the
+    last blocks have one tile fewer, with and without the lateral add."""
+    import poem_v2_amd as pk
+    from poem_v2_amd import hip
+    g = torch.Generator().manual_seed(cin + cout + r + views)
+    x = torch.randn(views, cin, r, r, generator=g).to(DEV)
+    sd = {"c.conv.weight": torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5),
+          "c.conv.bias": 0.1 * torch.randn(cout, generator=g), "c.norm.weight": 1 + 0.2 * torch.randn(cout, generator=g),
+          "c.norm.bias": 0.1 * torch.randn(cout, generator=g), "c.norm.running_mean": 0.1 * torch.randn(cout, generator=g),
+          "c.norm.running_var": 0.5 + torch.rand(cout, generator=g)}
+    ro = r // 2
+    lateral = torch.randn(views, cout, ro, ro, generator=g).to(DEV)
+    conv = pk.decode._Conv3x3(sd, "c", torch.device(DEV))
+    try:
+        for res in (lateral, None):
+            outs = []
+            for on in (1, 0):
+                hip.check(hip.lib().poem_set_decode_option(b"s2_staging_wave", on), "poem_set_decode_option")
+                out = torch.full((views, cout, ro, ro), float("nan"), device=DEV)
+                assert conv.down2(x, r, r, out, pk.decode._plain_strides(cout, ro, ro), residual=res)
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+    finally:
+        hip.lib().poem_set_decode_option(b"s2_staging_wave", 1)
+    assert hip.lib().poem_set_decode_option(b"no_such_switch", 1) != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,r", [(320, 160, 8), (64, 32, 8), (40, 32, 16)])
 def test_conv1x1_upsample2_operator(cin, cout, r):
     """poem_conv1x1_upsample2 (feat_decode's tail in one launch: feat_in applied at the low resolution, result upsampled

@@ -119,8 +119,30 @@ def decode_case(views=256):
     print(f"   PyTorch-ROCm eager (MIOpen): feat_decode {e1*1e3:8.1f} us  uv_decode {e2*1e3:8.1f} us", flush=True)
 
 
+def down2_case(views=256):
+    """feat_decode's three stride-2 ConvBlocks alone, staging wave on / off (`s2_staging_wave`)."""
+    from poem_v2_amd import hip
+    for cin, cout, r in ((40, 80, 64), (80, 160, 32), (160, 320, 16)):
+        g = torch.Generator().manual_seed(0)
+        sd = {"c.conv.weight": torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5), "c.conv.bias": torch.zeros(cout),
+              "c.norm.weight": torch.ones(cout), "c.norm.bias": torch.zeros(cout), "c.norm.running_mean": torch.zeros(cout),
+              "c.norm.running_var": torch.ones(cout)}
+        conv = pk.decode._Conv3x3(sd, "c", dev)
+        x = torch.randn(views, cin, r, r, generator=g).to(dev)
+        ro = r // 2
+        lat = torch.randn(views, cout, ro, ro, generator=g).to(dev)
+        out = torch.empty(views, cout, ro, ro, device=dev)
+        fl = views * 2.0 * 9 * cin * cout * ro * ro
+        line = f"down2 {cin:3d}->{cout:3d} @{r:2d}^2 views={views}:"
+        for on in (0, 1):
+            hip.lib().poem_set_decode_option(b"s2_staging_wave", on)
+            t = timeit(lambda: conv.down2(x, r, r, out, pk.decode._plain_strides(cout, ro, ro), residual=lat), 20)
+            line += f"  staging_wave={on} {t*1e3:7.1f} us ({fl/t/1e9:6.1f} TF)"
+        print(line, flush=True)
+
+
 if __name__ == "__main__":
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     which = sys.argv[1:] or ["gemm"]
     for w in which:
-        {"gemm": gemm_cases, "kslab": kslab_cases, "vecattn": vecattn_case, "attn": attn_case, "knn": knn_case, "decode": decode_case}[w]()
+        {"gemm": gemm_cases, "kslab": kslab_cases, "vecattn": vecattn_case, "attn": attn_case, "knn": knn_case, "decode": decode_case, "down2": down2_case}[w]()
