@@ -776,26 +776,43 @@ __global__ __launch_bounds__(64 * (PXB * CG + 1)) void conv3x3_s2p_kernel(Conv3A
     int ey[2] = {opy[0], opy[1]}, ex[2] = {opx[0], opx[1]}, eg = g;
     // (opaque to the optimiser: the 40 store addresses are invariant over the tile loop and would be hoisted into 80 registers)
     asm volatile("" : "+v"(ey[0]), "+v"(ey[1]), "+v"(ex[0]), "+v"(ex[1]), "+v"(eg));
-    const float* __restrict__ resp = A.res ? A.res + (size_t)n * A.Cout * (Ho * Wo) : nullptr;
-    float* __restrict__ outp = A.out + (size_t)n * A.out_ns + A.out_off;
+    // residual and result through buffer descriptors of the view: a lane offset per unit, the channel in the scalar offset -- all
+    // 40 residual loads in flight at once (one HBM round trip per tile; 64-bit addresses would cost 80 registers)
+    const int po4 = Ho * Wo * 4, cb0 = cgrp * (CT16 * 16) + 4 * eg;     // Cout % 80 == 0: every channel tile of a group exists
+    const __amdgpu_buffer_rsrc_t ors = frag_rsrc(A.out + (size_t)n * A.out_ns + A.out_off, 0xffffffffu);
+    int rvo[2], ovo[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      rvo[u] = cb0 * po4 + ((yo0 + ey[u]) * Wo + ex[u]) * 4;
+      ovo[u] = (cb0 * A.out_cs + (yo0 + ey[u]) * A.out_rs + ex[u]) * 4;
+    }
+    float rv[CT16][4][2];
+    if (A.res) {
+      const __amdgpu_buffer_rsrc_t rrs = frag_rsrc(A.res + (size_t)n * A.Cout * (Ho * Wo), (unsigned)(A.Cout * po4));
+#pragma unroll
+      for (int c = 0; c < CT16; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            rv[c][e][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, rvo[u], (16 * c + e) * po4, 0));
+    } else {
+#pragma unroll
+      for (int c = 0; c < CT16; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv[c][e][0] = rv[c][e][1] = 0.f;
+    }
 #pragma unroll
     for (int c = 0; c < CT16; ++c) {
-      const int cbase = cgrp * (CT16 * 16) + c * 16 + 4 * eg;
-      if (cbase >= A.Cout) continue;                          // Cout % 4 == 0 (80 / 160 / 320)
-      const float4 sc = *reinterpret_cast<const float4*>(A.scale + cbase);
-      const float4 sh = *reinterpret_cast<const float4*>(A.shift + cbase);
-      float rv[4][2];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) rv[e][u] = resp ? resp[(size_t)(cbase + e) * (Ho * Wo) + (yo0 + ey[u]) * Wo + ex[u]] : 0.f;
+      const float4 sc = *reinterpret_cast<const float4*>(A.scale + cb0 + 16 * c);
+      const float4 sh = *reinterpret_cast<const float4*>(A.shift + cb0 + 16 * c);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           float v = fmaf(acc[c][u][e], (&sc.x)[e], (&sh.x)[e]);
           if (A.relu) v = fmaxf(v, 0.f);
-          outp[(size_t)(cbase + e) * A.out_cs + (yo0 + ey[u]) * A.out_rs + ex[u]] = v + rv[e][u];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + rv[c][e][u]), ors, ovo[u], (16 * c + e) * A.out_cs * 4, 0);
         }
     }
   }
