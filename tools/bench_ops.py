@@ -107,6 +107,13 @@ def decode_case(views=256):
     dec = pk.decode.FeatureDecoders(sd, dev)
     if os.environ.get("POEM_FUSE_UPCAT"):
         dec.fuse_upcat = [c == "1" for c in os.environ["POEM_FUSE_UPCAT"]]
+    from poem_v2_amd import hip
+    for name in os.environ.get("POEM_DECODE_AB", "").split(","):
+        if name:
+            hip.lib().poem_set_decode_option(name.encode(), 0)
+            print(f"   {name}=0: feat_decode {timeit(lambda: dec.feat_decode(feats), 10)*1e3:8.1f} us  heatmap_stage "
+                  f"{timeit(lambda: dec.heatmap_stage(feats, 256, 256), 10)*1e3:8.1f} us", flush=True)
+            hip.lib().poem_set_decode_option(name.encode(), 1)
     t1 = timeit(lambda: dec.feat_decode(feats), 10)
     t2 = timeit(lambda: dec.heatmap_stage(feats, 256, 256), 10)
     fl1 = views * 2.0 * (9 * 40 * 80 * 1024 + 9 * 80 * 160 * 256 + 9 * 160 * 320 * 64 + 320 * 160 * 256)
