@@ -324,8 +324,9 @@ int poem_conv3x3_down2(const float* in, const void* w_packed, const float* scale
                        float* out, int views, int cin, int cout, int h, int w, int relu, int64_t out_view_stride,
                        int out_ch_stride, int out_row_stride, int out_offset, void* stream);
 /* Process-wide A/B switches of the decode operators (not per handle: these operators take no handle).  Results do not depend on
- * them.  "s2_staging_wave" (default 1): poem_conv3x3_down2 as one persistent 9-wave block per CU whose ninth wave does all the
- * LDS-DMA staging while eight waves multiply; 0 = the round-3 kernel in which every wave stages and multiplies.
+ * them.  "s2_staging_wave" (default 1): poem_conv3x3_down2 as persistent blocks of four MFMA waves plus a fifth wave that does
+ * all the LDS-DMA staging; 0 = the round-3 kernel in which every wave stages and multiplies; 2..4 = the default kernel with
+ * that many blocks per CU instead of the rule in decode.hip (measurement only; 0 / 1 restore the rule).
  * POEM_E_ARG for an unknown name. */
 int poem_set_decode_option(const char* name, int value);
 /* feat_decode's tail in one launch (POEM.py:190-193: F.interpolate(x, scale_factor=2, mode="bilinear") followed by feat_in, a

@@ -824,7 +824,20 @@ __global__ __launch_bounds__(64 * (PXB * CG + 1)) void conv3x3_s2p_kernel(Conv3A
 
 // Shapes conv3x3_s2_kernel takes: 80 / 160 / 320 output channels on 8-row output tiles of 32 / 16 / 8 columns.
 static int g_s2_staging_wave = 1;       // A/B switch: 0 = conv3x3_s2_kernel (every wave stages and multiplies)
-extern "C" void poem_decode_s2_staging_wave(int on) { g_s2_staging_wave = on != 0; }
+static int g_s2_blocks_per_cu = 0;       // 0: by the tile count (below); 2..4 forced (A/B)
+extern "C" void poem_decode_s2_staging_wave(int on) {
+  if (on >= 2) { g_s2_blocks_per_cu = on; return; }
+  g_s2_staging_wave = on != 0;
+  g_s2_blocks_per_cu = 0;
+}
+// Persistent blocks per CU of conv3x3_s2p_kernel.  Three fit (LDS, registers); but with 4 tiles per CU (the 32^2 level at 256
+// views) three blocks walk {2, 1, 1} tiles and the long one finishes alone -- one MFMA wave per SIMD, 0.75 of the pipe --
+// where two blocks walk {2, 2}: measured 157 vs 140 us; with 8 tiles per CU {3, 3, 2} beats {4, 4} (153 vs 158 us).
+static int s2_blocks_per_cu(int tiles, int cus) {
+  if (g_s2_blocks_per_cu) return g_s2_blocks_per_cu;
+  const int tpc = (tiles + cus - 1) / cus;
+  return tpc >= 2 && tpc % 3 == 1 ? 2 : 3;
+}
 static int conv3x3_s2_shape(int Cout, int H, int W) {
   if (H != W || H % 16) return 0;
   if (Cout == 80 && W == 64) return 1;
@@ -849,7 +862,7 @@ extern "C" hipError_t poem_launch_conv3x3_down2(const float* in, const void* wp,
     const int tiles = views * (H / 2 / ROWS);
     const int cfl = 8 * (2 * ROWS + 1) * W;
     const size_t lds_p = (size_t)(4 + 2 * ((cfl + 255) & ~255)) * sizeof(float);
-    const dim3 grid((unsigned)std::min(tiles, 3 * poem_device_cus())), block(320);
+    const dim3 grid((unsigned)std::min(tiles, s2_blocks_per_cu(tiles, poem_device_cus()) * poem_device_cus())), block(320);
     if (shape == 1) {
       auto k = conv3x3_s2p_kernel<4, 1, 18, ROWS>;
       if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(k), lds_p, optin[3]); e != hipSuccess) return e;

@@ -141,7 +141,7 @@ def down2_case(views=256):
         out = torch.empty(views, cout, ro, ro, device=dev)
         fl = views * 2.0 * 9 * cin * cout * ro * ro
         line = f"down2 {cin:3d}->{cout:3d} @{r:2d}^2 views={views}:"
-        for on in (0, 1):
+        for on in (0, 2, 3, 1):              # 0: round-3 kernel; 2 / 3: blocks per CU forced; 1: the default rule
             hip.lib().poem_set_decode_option(b"s2_staging_wave", on)
             t = timeit(lambda: conv.down2(x, r, r, out, pk.decode._plain_strides(cout, ro, ro), residual=lat), 20)
             line += f"  staging_wave={on} {t*1e3:7.1f} us ({fl/t/1e9:6.1f} TF)"
