@@ -119,6 +119,8 @@ def decode_case(views=256):
     fl1 = views * 2.0 * (9 * 40 * 80 * 1024 + 9 * 80 * 160 * 256 + 9 * 160 * 320 * 64 + 320 * 160 * 256)
     fl2 = views * 2.0 * 9 * (480 * 160 * 256 + 240 * 80 * 1024 + 120 * 40 * 4096)
     print(f"decode views={views}: feat_decode {t1*1e3:8.1f} us ({fl1/t1/1e9:6.1f} TF)  heatmap_stage {t2*1e3:8.1f} us ({fl2/t2/1e9:6.1f} TF)", flush=True)
+    if os.environ.get("POEM_NO_EAGER"):
+        return
     sdd = {k: v.to(dev) for k, v in sd.items()}
     with torch.no_grad():
         e1 = timeit(lambda: do.feat_decode(feats, sdd), 5)
@@ -141,7 +143,7 @@ def down2_case(views=256):
         out = torch.empty(views, cout, ro, ro, device=dev)
         fl = views * 2.0 * 9 * cin * cout * ro * ro
         line = f"down2 {cin:3d}->{cout:3d} @{r:2d}^2 views={views}:"
-        for on in (0, 2, 3, 1):              # 0: round-3 kernel; 2 / 3: blocks per CU forced; 1: the default rule
+        for on in (0, 1, 2, 3, 1):           # 0: round-3 kernel; 1: the default rule; 2 / 3: blocks per CU forced
             hip.lib().poem_set_decode_option(b"s2_staging_wave", on)
             t = timeit(lambda: conv.down2(x, r, r, out, pk.decode._plain_strides(cout, ro, ro), residual=lat), 20)
             line += f"  staging_wave={on} {t*1e3:7.1f} us ({fl/t/1e9:6.1f} TF)"
