@@ -135,6 +135,15 @@ def test_conv3x3_down2_staging_wave_is_bit_identical_to_the_round3_kernel(cin, c
                 assert conv.down2(x, r, r, out, pk.decode._plain_strides(cout, ro, ro), residual=res)
                 outs.append(out)
             assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+            if views <= 8:
+                # the same result written into a zero-bordered buffer (view / channel / row strides and offset of the entry
+                # point): interior == the plain result, border untouched
+                hip.check(hip.lib().poem_set_decode_option(b"s2_staging_wave", 1), "poem_set_decode_option")
+                outp = torch.zeros(views, cout, ro + 2, ro + 2, device=DEV)
+                assert conv.down2(x, r, r, outp, pk.decode._padded_strides(cout, ro, ro), residual=res)
+                assert torch.equal(outp[:, :, 1:-1, 1:-1], outs[0])
+                assert float(outp[:, :, 0].abs().max()) == 0.0 and float(outp[:, :, :, 0].abs().max()) == 0.0
+                assert float(outp[:, :, -1].abs().max()) == 0.0 and float(outp[:, :, :, -1].abs().max()) == 0.0
     finally:
         hip.lib().poem_set_decode_option(b"s2_staging_wave", 1)
     assert hip.lib().poem_set_decode_option(b"no_such_switch", 1) != 0
