@@ -300,6 +300,94 @@ struct Conv3Stager {
   }
 };
 
+// The fused [bilinear x2 of up_a | skip_b] staging at W == 64 with four-row tiles (the last uv_decode convolution, 120 -> 40 at
+// 64^2: 39 % of the stage's time), organised by rows instead of by staged float: wave w of the block stages channel w of the
+// chunk, lane = image column.  A lane's column pair (xx0, xx1) and its weights (hx, lx) never change; the six tile rows
+// y0 - 1 .. y0 + 4 interpolate between the FOUR source rows L_i = clamp(y0 / 2 - 1 + i), row r between (L_{r/2}, L_{r/2 + 1}),
+// with per-row weights (hy, ly) that are wave-uniform scalars by F.interpolate's own formula (0, 0 outside the image).  At the
+// top edge the formula's second source row differs from the pattern's, with weight ly = 0 there: the value is the same.  Eight
+// coalesced row loads per chunk instead of 28 scattered taps, and 20 registers of staging state instead of 98 -- which is what
+// lets TWO blocks share a CU (175 -> <= 128 VGPRs): with one, every block's set-up, first-chunk latency and epilogue were exposed.
+// Every staged value is the same expression as Conv3Stager's: fmaf(q3, r3, fmaf(q2, r2, fmaf(q1, r1, q0 * st))), q = (hy hx, hy lx, ly hx, ly lx).
+struct Conv3RowStager {
+  static constexpr int MAXLD = 8;          // loads per chunk: kind 2 = 4 source rows x 2 columns, kind 1 = 6 plain rows
+  float a[8], st[6];
+  float lx, hx;
+  int xo0, xo1, xo, dst, Wp;
+  float hy[6], ly[6];                      // wave-uniform
+  int Lb[4], yb[6];                        // byte offsets of the source rows (kind 2) / the plain rows (kind 1, clamped), wave-uniform
+  bool yv[6];
+  __amdgpu_buffer_rsrc_t rs_a, rs_b;
+  int Ca, up_plane4, sk_plane4, wv, so;
+
+  __device__ __forceinline__ void init(const Conv3Args& A, int n, int y0, int tid, int /*tplane*/, int tstride) {
+    const int W = A.W, h2 = A.H / 2, w2 = A.W / 2, x = tid & 63;
+    wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Wp = W + 2;
+    Ca = A.Ca;
+    up_plane4 = h2 * w2 * 4; sk_plane4 = A.H * W * 4;
+    rs_a = frag_rsrc(A.up_a + (size_t)n * A.Ca * (h2 * w2), (unsigned)((size_t)A.Ca * up_plane4));
+    rs_b = frag_rsrc(A.skip_b + (size_t)n * A.Cb * (A.H * W), (unsigned)((size_t)A.Cb * sk_plane4));
+    const float sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+    const int xx0 = (int)sx, xx1 = min(xx0 + 1, w2 - 1);
+    lx = sx - (float)xx0; hx = 1.f - lx;
+    xo0 = xx0 * 4; xo1 = xx1 * 4; xo = x * 4;
+    dst = wv * tstride + x + 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Lb[i] = min(max(y0 / 2 - 1 + i, 0), h2 - 1) * w2 * 4;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int y = y0 - 1 + r;
+      yv[r] = y >= 0 && y < A.H;
+      const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
+      const float l = sy - (float)(int)sy;
+      hy[r] = yv[r] ? 1.f - l : 0.f;
+      ly[r] = yv[r] ? l : 0.f;
+      yb[r] = min(max(y, 0), A.H - 1) * W * 4;
+    }
+  }
+  // the two border columns of every staged row are zero for the whole kernel (both buffers): written once
+  __device__ __forceinline__ void zero_borders(float* tile, int tid, int tstride) const {
+    for (int i = tid; i < 2 * 8 * 6 * 2; i += 512) {
+      const int side = i & 1, r = (i >> 1) % 6, chl = (i / 12) % 8, buf = i / 96;
+      tile[buf * 8 * tstride + chl * tstride + r * Wp + side * (Wp - 1)] = 0.f;
+    }
+  }
+  __device__ __forceinline__ static float ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+  }
+  template <int KIND>
+  __device__ __forceinline__ void begin_k(int cc) {
+    so = __builtin_amdgcn_readfirstlane(KIND == 2 ? (8 * cc + wv) * up_plane4 : (8 * cc - Ca + wv) * sk_plane4);
+  }
+  template <int KIND, int u>
+  __device__ __forceinline__ void load_k() {
+    if constexpr (KIND == 2) a[u] = ld(rs_a, (u & 1) ? xo1 : xo0, so + Lb[u >> 1]);
+    else if constexpr (u < 6) a[u] = ld(rs_b, xo, so + yb[u]);
+  }
+  template <int KIND, int U = 0>
+  __device__ __forceinline__ void load_all() {
+    if constexpr (U < MAXLD) { load_k<KIND, U>(); load_all<KIND, U + 1>(); }
+  }
+  template <int KIND>
+  __device__ __forceinline__ void finish_k() {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      if constexpr (KIND == 2) {
+        const int i0 = r >> 1, i1 = i0 + 1;
+        const float q0 = hy[r] * hx, q1 = hy[r] * lx, q2 = ly[r] * hx, q3 = ly[r] * lx;
+        st[r] = fmaf(q3, a[2 * i1 + 1], fmaf(q2, a[2 * i1], fmaf(q1, a[2 * i0 + 1], q0 * a[2 * i0])));
+      } else {
+        st[r] = yv[r] ? a[r] : 0.f;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* buf, int /*tid*/) const {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) buf[dst + r * Wp] = st[r];
+  }
+};
+
 // Stride-1 variant with the input staged in LDS (the three uv_decode convolutions: 9 x Cin x Cout x H x W = 177 M
 // multiply-adds per view each).  The direct kernel above re-reads its input for every tap and every channel-tile group
 // through caches that do not hold it (PMC: 5.2 GB fetched for the 0.5 GB input of the 120 -> 40 layer).  Here a block of 8
@@ -395,8 +483,8 @@ __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
 // to a stride == 16 mod 32 floats so that the two channel planes a 32-lane group reads fall on disjoint banks.
 // Result layout: lane (g, j) holds output channels 16c + 4g .. + 3 of pixel j.
 typedef float f32x2v __attribute__((ext_vector_type(2)));
-template <int CT16, bool UPCAT>
-__global__ __launch_bounds__(512) void conv3x3_lds16_kernel(Conv3Args A) {
+template <int CT16, bool UPCAT, bool ROWSG = false>
+__global__ __launch_bounds__(512, ROWSG ? 4 : 2) void conv3x3_lds16_kernel(Conv3Args A) {
   extern __shared__ __attribute__((aligned(16))) float tile[];      // 2 x 8 x tstride
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
   const int W = A.W, Wp = A.W + 2, KC = A.Cin / 8;
@@ -404,8 +492,11 @@ __global__ __launch_bounds__(512) void conv3x3_lds16_kernel(Conv3Args A) {
   const int rb = (int)(blockIdx.x % rblocks), n = (int)(blockIdx.x / rblocks);
   const int y0 = rb * TR, tplane = (TR + 2) * Wp, tstride = ((tplane + 15) & ~31) + 16;
   const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(A.wp16, 0xffffffffu);
-  Conv3Stager<UPCAT> sg;
+  static_assert(!ROWSG || UPCAT, "the row stager stages the fused input");
+  using SG = std::conditional_t<ROWSG, Conv3RowStager, Conv3Stager<UPCAT>>;
+  SG sg;
   sg.init(A, n, y0, tid, tplane, tstride);
+  if constexpr (ROWSG) sg.zero_borders(tile, tid, tstride);
   f32x4 acc[CT16][2];
 #pragma unroll
   for (int c = 0; c < CT16; ++c)
@@ -457,7 +548,6 @@ __global__ __launch_bounds__(512) void conv3x3_lds16_kernel(Conv3Args A) {
   __builtin_amdgcn_sched_barrier(0);                                                                            \
   POEM_T16_MMA(CUR_A, CUR_B)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
-  using SG = Conv3Stager<UPCAT>;
   // one chunk; NEXT = kind of the chunk staged meanwhile (0: none, 1: plain input / skip tensor, 2: interpolated part)
   auto chunk = [&](auto next_tag, const int cc) {
     constexpr int NEXT = decltype(next_tag)::value;
@@ -823,6 +913,8 @@ __global__ __launch_bounds__(64 * (PXB * CG + 1)) void conv3x3_s2p_kernel(Conv3A
 }
 
 // Shapes conv3x3_s2_kernel takes: 80 / 160 / 320 output channels on 8-row output tiles of 32 / 16 / 8 columns.
+static int g_row_stager = 1;            // A/B switch: 0 = Conv3Stager for every fused-input convolution
+extern "C" void poem_decode_row_stager(int on) { g_row_stager = on != 0; }
 static int g_s2_staging_wave = 1;       // A/B switch: 0 = conv3x3_s2_kernel (every wave stages and multiplies)
 static int g_s2_blocks_per_cu = 0;       // 0: by the tile count (below); 2..4 forced (A/B)
 extern "C" void poem_decode_s2_staging_wave(int on) {
@@ -906,6 +998,17 @@ static hipError_t launch_conv3x3_lds(const Conv3Args& a, hipStream_t s) {
   if (conv3x3_m16(a.Cout)) {
     const int tplane = (TR + 2) * (a.W + 2), tstride = ((tplane + 15) & ~31) + 16;
     const size_t lds16 = (size_t)2 * 8 * tstride * sizeof(float);
+    if constexpr (UPCAT) {
+      // W == 64 (four-row tiles), whole chunks of either kind: staging by rows, two blocks per CU (Conv3RowStager)
+      if (g_row_stager && a.W == 64 && a.Ca % 8 == 0 && a.Cb % 8 == 0) {
+        switch ((a.Cout + 15) / 16) {
+          case 1: hipLaunchKernelGGL((conv3x3_lds16_kernel<1, true, true>), grid, block, lds16, s, a); break;
+          case 3: hipLaunchKernelGGL((conv3x3_lds16_kernel<3, true, true>), grid, block, lds16, s, a); break;
+          default: hipLaunchKernelGGL((conv3x3_lds16_kernel<5, true, true>), grid, block, lds16, s, a); break;
+        }
+        return hipGetLastError();
+      }
+    }
 #define POEM_CONVL16(CTV) hipLaunchKernelGGL((conv3x3_lds16_kernel<CTV, UPCAT>), grid, block, lds16, s, a)
     switch ((a.Cout + 15) / 16) {
       case 1: POEM_CONVL16(1); break;
