@@ -327,8 +327,9 @@ int poem_conv3x3_down2(const float* in, const void* w_packed, const float* scale
  * them.  "s2_staging_wave" (default 1): poem_conv3x3_down2 as persistent blocks of four MFMA waves plus a fifth wave that does
  * all the LDS-DMA staging; 0 = the round-3 kernel in which every wave stages and multiplies; 2..4 = the default kernel with
  * that many blocks per CU instead of the rule in decode.hip (measurement only; 0 / 1 restore the rule).
- * "row_stager" (default 1): poem_upcat_conv3x3 at w = 64 stages its fused input by rows (wave = channel, lane = column, four
- * source rows per chunk) and runs two blocks per CU; 0 = the per-float stager of the other widths.
+ * "row_stager" (default 3; bit 0: at w = 64, bit 1: at w = 32): poem_upcat_conv3x3 stages its fused input by rows (wave =
+ * channel, lane = (row group, column), the source rows of a chunk loaded once) and runs two blocks per CU; 0 = the per-float
+ * stager of the other widths.
  * POEM_E_ARG for an unknown name. */
 int poem_set_decode_option(const char* name, int value);
 /* feat_decode's tail in one launch (POEM.py:190-193: F.interpolate(x, scale_factor=2, mode="bilinear") followed by feat_in, a

@@ -300,28 +300,36 @@ struct Conv3Stager {
   }
 };
 
-// The fused [bilinear x2 of up_a | skip_b] staging at W == 64 with four-row tiles (the last uv_decode convolution, 120 -> 40 at
-// 64^2: 39 % of the stage's time), organised by rows instead of by staged float: wave w of the block stages channel w of the
-// chunk, lane = image column.  A lane's column pair (xx0, xx1) and its weights (hx, lx) never change; the six tile rows
-// y0 - 1 .. y0 + 4 interpolate between the FOUR source rows L_i = clamp(y0 / 2 - 1 + i), row r between (L_{r/2}, L_{r/2 + 1}),
-// with per-row weights (hy, ly) that are wave-uniform scalars by F.interpolate's own formula (0, 0 outside the image).  At the
-// top edge the formula's second source row differs from the pattern's, with weight ly = 0 there: the value is the same.  Eight
-// coalesced row loads per chunk instead of 28 scattered taps, and 20 registers of staging state instead of 98 -- which is what
-// lets TWO blocks share a CU (175 -> <= 128 VGPRs): with one, every block's set-up, first-chunk latency and epilogue were exposed.
+// The fused [bilinear x2 of up_a | skip_b] staging of the 64^2 and 32^2 levels (uv_decode's last two convolutions, 120 -> 40 and
+// 240 -> 80: two thirds of the stage's time), organised by rows instead of by staged float: wave w of the block stages channel w
+// of the chunk, a lane one image column of some of the tile's rows.  A lane's column pair (xx0, xx1) and its weights (hx, lx)
+// never change; tile row r (image row y0 - 1 + r) interpolates between the source rows (L_{r/2}, L_{r/2+1}) of the TR / 2 + 2
+// rows L_i = clamp(y0 / 2 - 1 + i) the tile needs, with the row weight ly of F.interpolate's own formula (wave-uniform at
+// W = 64; hy = 1 - ly; both 0 outside the image).  At the top edge the formula's second source row differs from the pattern's,
+// with weight ly = 0 there: the value is the same.  8 / 12 coalesced row loads per chunk instead of 28 scattered taps, and ~20
+// registers of staging state instead of 98 -- which is what lets TWO blocks share a CU (175 / 202 -> <= 128 VGPRs): with one,
+// every block's set-up, first-chunk latency and epilogue were exposed (982 -> 790 us and 739 -> 672 us at 256 views).
 // Every staged value is the same expression as Conv3Stager's: fmaf(q3, r3, fmaf(q2, r2, fmaf(q1, r1, q0 * st))), q = (hy hx, hy lx, ly hx, ly lx).
+template <int W>
 struct Conv3RowStager {
-  static constexpr int MAXLD = 8;          // loads per chunk: kind 2 = 4 source rows x 2 columns, kind 1 = 6 plain rows
-  float a[8], st[6];
+  // lane = (row group rsub = lane / W, column x = lane % W): R = 64 / W groups; a thread's NRT rows are r_k = rsub + R k.  W = 64:
+  // six rows from four source rows, everything about a row wave-uniform; W = 32 (eight-row tiles): five rows from six source
+  // rows (row r_k between L_k and L_{k+1}), the row weights per lane.
+  static constexpr int R = 64 / W, TR = 256 / W, NRT = (TR + 2) / R, NL = (TR + 2) / 2 + 1;
+  static_assert((TR + 2) % R == 0 && (W == 64 || W == 32), "tile rows deal evenly to the row groups");
+  static constexpr int MAXLD = (2 * NL <= 8) ? 2 * NL : NL;     // load slots per chunk (<= 8: one per tap); two loads a slot when 2 NL > 8
+  static constexpr int LPS = (2 * NL <= 8) ? 1 : 2;
+  static_assert(MAXLD <= 8 && NRT <= MAXLD, "slots");
+  float a[2 * NL], st[NRT];
   float lx, hx;
   int xo0, xo1, xo, dst, Wp;
-  float hy[6], ly[6];                      // wave-uniform
-  int Lb[4], yb[6];                        // byte offsets of the source rows (kind 2) / the plain rows (kind 1, clamped), wave-uniform
-  bool yv[6];
+  float ly[NRT];                           // lower-row weight of tile row r_k, -1 outside the image (wave-uniform at W = 64)
+  int Lb[NL], ybase, H;                    // byte offsets of the source rows (kind 2, wave-uniform); image row of r_0
   __amdgpu_buffer_rsrc_t rs_a, rs_b;
   int Ca, up_plane4, sk_plane4, wv, so;
 
   __device__ __forceinline__ void init(const Conv3Args& A, int n, int y0, int tid, int /*tplane*/, int tstride) {
-    const int W = A.W, h2 = A.H / 2, w2 = A.W / 2, x = tid & 63;
+    const int h2 = A.H / 2, w2 = W / 2, x = (tid & 63) % W, rsub = (tid & 63) / W;
     wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     Wp = W + 2;
     Ca = A.Ca;
@@ -332,24 +340,23 @@ struct Conv3RowStager {
     const int xx0 = (int)sx, xx1 = min(xx0 + 1, w2 - 1);
     lx = sx - (float)xx0; hx = 1.f - lx;
     xo0 = xx0 * 4; xo1 = xx1 * 4; xo = x * 4;
-    dst = wv * tstride + x + 1;
+    dst = wv * tstride + rsub * Wp + x + 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Lb[i] = min(max(y0 / 2 - 1 + i, 0), h2 - 1) * w2 * 4;
+    for (int i = 0; i < NL; ++i) Lb[i] = min(max(y0 / 2 - 1 + i, 0), h2 - 1) * w2 * 4;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const int y = y0 - 1 + r;
-      yv[r] = y >= 0 && y < A.H;
+    for (int k = 0; k < NRT; ++k) {
+      const int y = y0 - 1 + rsub + R * k;
+      const bool valid = y >= 0 && y < A.H;
       const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
-      const float l = sy - (float)(int)sy;
-      hy[r] = yv[r] ? 1.f - l : 0.f;
-      ly[r] = yv[r] ? l : 0.f;
-      yb[r] = min(max(y, 0), A.H - 1) * W * 4;
+      ly[k] = valid ? sy - (float)(int)sy : -1.f;
     }
+    ybase = y0 - 1 + rsub;
+    H = A.H;
   }
   // the two border columns of every staged row are zero for the whole kernel (both buffers): written once
   __device__ __forceinline__ void zero_borders(float* tile, int tid, int tstride) const {
-    for (int i = tid; i < 2 * 8 * 6 * 2; i += 512) {
-      const int side = i & 1, r = (i >> 1) % 6, chl = (i / 12) % 8, buf = i / 96;
+    for (int i = tid; i < 2 * 8 * (TR + 2) * 2; i += 512) {
+      const int side = i & 1, r = (i >> 1) % (TR + 2), chl = (i / (2 * (TR + 2))) % 8, buf = i / (16 * (TR + 2));
       tile[buf * 8 * tstride + chl * tstride + r * Wp + side * (Wp - 1)] = 0.f;
     }
   }
@@ -362,8 +369,12 @@ struct Conv3RowStager {
   }
   template <int KIND, int u>
   __device__ __forceinline__ void load_k() {
-    if constexpr (KIND == 2) a[u] = ld(rs_a, (u & 1) ? xo1 : xo0, so + Lb[u >> 1]);
-    else if constexpr (u < 6) a[u] = ld(rs_b, xo, so + yb[u]);
+    if constexpr (KIND == 2) {
+      if constexpr (LPS == 1) a[u] = ld(rs_a, (u & 1) ? xo1 : xo0, so + Lb[u >> 1]);
+      else { a[2 * u] = ld(rs_a, xo0, so + Lb[u]); a[2 * u + 1] = ld(rs_a, xo1, so + Lb[u]); }
+    } else if constexpr (u < NRT) {
+      a[u] = ld(rs_b, xo + min(max(ybase + R * u, 0), H - 1) * (W * 4), so);
+    }
   }
   template <int KIND, int U = 0>
   __device__ __forceinline__ void load_all() {
@@ -372,19 +383,20 @@ struct Conv3RowStager {
   template <int KIND>
   __device__ __forceinline__ void finish_k() {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
+    for (int k = 0; k < NRT; ++k) {
       if constexpr (KIND == 2) {
-        const int i0 = r >> 1, i1 = i0 + 1;
-        const float q0 = hy[r] * hx, q1 = hy[r] * lx, q2 = ly[r] * hx, q3 = ly[r] * lx;
-        st[r] = fmaf(q3, a[2 * i1 + 1], fmaf(q2, a[2 * i1], fmaf(q1, a[2 * i0 + 1], q0 * a[2 * i0])));
+        const int i0 = R == 1 ? (k >> 1) : k, i1 = i0 + 1;      // r_k >> 1
+        const float l = fmaxf(ly[k], 0.f), hy = ly[k] < 0.f ? 0.f : 1.f - ly[k];
+        const float q0 = hy * hx, q1 = hy * lx, q2 = l * hx, q3 = l * lx;
+        st[k] = fmaf(q3, a[2 * i1 + 1], fmaf(q2, a[2 * i1], fmaf(q1, a[2 * i0 + 1], q0 * a[2 * i0])));
       } else {
-        st[r] = yv[r] ? a[r] : 0.f;
+        st[k] = (unsigned)(ybase + R * k) < (unsigned)H ? a[k] : 0.f;
       }
     }
   }
   __device__ __forceinline__ void store(float* buf, int /*tid*/) const {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) buf[dst + r * Wp] = st[r];
+    for (int k = 0; k < NRT; ++k) buf[dst + R * k * Wp] = st[k];
   }
 };
 
@@ -483,8 +495,9 @@ __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
 // to a stride == 16 mod 32 floats so that the two channel planes a 32-lane group reads fall on disjoint banks.
 // Result layout: lane (g, j) holds output channels 16c + 4g .. + 3 of pixel j.
 typedef float f32x2v __attribute__((ext_vector_type(2)));
-template <int CT16, bool UPCAT, bool ROWSG = false>
-__global__ __launch_bounds__(512, ROWSG ? 4 : 2) void conv3x3_lds16_kernel(Conv3Args A) {
+template <int CT16, bool UPCAT, int RW = 0>
+__global__ __launch_bounds__(512, RW ? 4 : 2) void conv3x3_lds16_kernel(Conv3Args A) {
+  constexpr bool ROWSG = RW != 0;
   extern __shared__ __attribute__((aligned(16))) float tile[];      // 2 x 8 x tstride
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
   const int W = A.W, Wp = A.W + 2, KC = A.Cin / 8;
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(512, ROWSG ? 4 : 2) void conv3x3_lds16_kernel(Conv3
   const int y0 = rb * TR, tplane = (TR + 2) * Wp, tstride = ((tplane + 15) & ~31) + 16;
   const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(A.wp16, 0xffffffffu);
   static_assert(!ROWSG || UPCAT, "the row stager stages the fused input");
-  using SG = std::conditional_t<ROWSG, Conv3RowStager, Conv3Stager<UPCAT>>;
+  using SG = std::conditional_t<ROWSG, Conv3RowStager<ROWSG ? RW : 64>, Conv3Stager<UPCAT>>;
   SG sg;
   sg.init(A, n, y0, tid, tplane, tstride);
   if constexpr (ROWSG) sg.zero_borders(tile, tid, tstride);
@@ -913,8 +926,8 @@ __global__ __launch_bounds__(64 * (PXB * CG + 1)) void conv3x3_s2p_kernel(Conv3A
 }
 
 // Shapes conv3x3_s2_kernel takes: 80 / 160 / 320 output channels on 8-row output tiles of 32 / 16 / 8 columns.
-static int g_row_stager = 1;            // A/B switch: 0 = Conv3Stager for every fused-input convolution
-extern "C" void poem_decode_row_stager(int on) { g_row_stager = on != 0; }
+static int g_row_stager = 3;            // A/B switch: 0 = Conv3Stager for every fused-input convolution
+extern "C" void poem_decode_row_stager(int on) { g_row_stager = on; }      // bit 0: at W = 64, bit 1: at W = 32
 static int g_s2_staging_wave = 1;       // A/B switch: 0 = conv3x3_s2_kernel (every wave stages and multiplies)
 static int g_s2_blocks_per_cu = 0;       // 0: by the tile count (below); 2..4 forced (A/B)
 extern "C" void poem_decode_s2_staging_wave(int on) {
@@ -999,13 +1012,17 @@ static hipError_t launch_conv3x3_lds(const Conv3Args& a, hipStream_t s) {
     const int tplane = (TR + 2) * (a.W + 2), tstride = ((tplane + 15) & ~31) + 16;
     const size_t lds16 = (size_t)2 * 8 * tstride * sizeof(float);
     if constexpr (UPCAT) {
-      // W == 64 (four-row tiles), whole chunks of either kind: staging by rows, two blocks per CU (Conv3RowStager)
-      if (g_row_stager && a.W == 64 && a.Ca % 8 == 0 && a.Cb % 8 == 0) {
+      // W == 64 / 32 (four- / eight-row tiles), whole chunks of either kind: staging by rows, two blocks per CU (Conv3RowStager)
+      if (g_row_stager && a.Ca % 8 == 0 && a.Cb % 8 == 0 && (a.W == 64 || (a.W == 32 && (g_row_stager & 2)))) {
+#define POEM_CONVL16R(CTV)                                                                                    \
+        if (a.W == 64) hipLaunchKernelGGL((conv3x3_lds16_kernel<CTV, true, 64>), grid, block, lds16, s, a);   \
+        else hipLaunchKernelGGL((conv3x3_lds16_kernel<CTV, true, 32>), grid, block, lds16, s, a)
         switch ((a.Cout + 15) / 16) {
-          case 1: hipLaunchKernelGGL((conv3x3_lds16_kernel<1, true, true>), grid, block, lds16, s, a); break;
-          case 3: hipLaunchKernelGGL((conv3x3_lds16_kernel<3, true, true>), grid, block, lds16, s, a); break;
-          default: hipLaunchKernelGGL((conv3x3_lds16_kernel<5, true, true>), grid, block, lds16, s, a); break;
+          case 1: POEM_CONVL16R(1); break;
+          case 3: POEM_CONVL16R(3); break;
+          default: POEM_CONVL16R(5); break;
         }
+#undef POEM_CONVL16R
         return hipGetLastError();
       }
     }

@@ -113,7 +113,7 @@ def decode_case(views=256):
             hip.lib().poem_set_decode_option(name.encode(), 0)
             print(f"   {name}=0: feat_decode {timeit(lambda: dec.feat_decode(feats), 10)*1e3:8.1f} us  heatmap_stage "
                   f"{timeit(lambda: dec.heatmap_stage(feats, 256, 256), 10)*1e3:8.1f} us", flush=True)
-            hip.lib().poem_set_decode_option(name.encode(), 1)
+            hip.lib().poem_set_decode_option(name.encode(), 3 if name == "row_stager" else 1)
     t1 = timeit(lambda: dec.feat_decode(feats), 10)
     t2 = timeit(lambda: dec.heatmap_stage(feats, 256, 256), 10)
     fl1 = views * 2.0 * (9 * 40 * 80 * 1024 + 9 * 80 * 160 * 256 + 9 * 160 * 320 * 64 + 320 * 160 * 256)
