@@ -330,6 +330,8 @@ int poem_conv3x3_down2(const float* in, const void* w_packed, const float* scale
  * "row_stager" (default 3; bit 0: at w = 64, bit 1: at w = 32): poem_upcat_conv3x3 stages its fused input by rows (wave =
  * channel, lane = (row group, column), the source rows of a chunk loaded once) and runs two blocks per CU; 0 = the per-float
  * stager of the other widths.
+ * "pin32" (default 1): the fused-input convolution with five 32-channel tiles (uv_decode's first, 480 -> 160) runs its taps as a
+ * pinned two-stage pipeline (next tap's weights and operands requested before this tap's MFMAs); 0 = compiler-scheduled taps.
  * POEM_E_ARG for an unknown name. */
 int poem_set_decode_option(const char* name, int value);
 /* feat_decode's tail in one launch (POEM.py:190-193: F.interpolate(x, scale_factor=2, mode="bilinear") followed by feat_in, a

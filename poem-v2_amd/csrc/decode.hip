@@ -409,7 +409,11 @@ struct Conv3RowStager {
 // (lane = pixel: conflict-free), and the input leaves HBM (rows + 2) / rows times instead of nine times per channel-tile
 // group.  Chunk-major accumulation (for each chunk the nine taps) -- the direct kernel sums tap-major; both are within the
 // fp32 round-off the tests allow against the reference.
-template <int CT, bool UPCAT>
+// PIN (round 4; the fused-input 480 -> 160 convolution of the 16^2 level): the taps as the pinned two-stage pipeline of
+// conv3x3_lds16_kernel -- tap t + 1's weight fragments and operands requested before tap t's MFMAs, the next chunk's staging
+// loads one float per tap behind them.  Left to the compiler the chunk began with the burst of 28 staging gathers and tap 0's
+// weights queued behind it (vmcnt retires in order): every chunk of every wave waited an L2 round trip at the barrier's far side.
+template <int CT, bool UPCAT, bool PIN = false>
 __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
   extern __shared__ __attribute__((aligned(16))) float tile[];      // 2 x 8 x trows x Wp
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
@@ -438,9 +442,46 @@ __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
   }
   __syncthreads();
   const int boff = (4 * h) * tplane + py * Wp + px;
+  using SG = Conv3Stager<UPCAT>;
+  float4 wa[PIN ? CT : 1], wb[PIN ? CT : 1];
+  float ba[4], bb[4];
+#define POEM_T32_LOADW(AW, TAP, CC)                                                                             \
+  _Pragma("unroll") for (int c = 0; c < CT; ++c) AW[c] = frag_load(wrs, lane * 16, ((c * 9 + (TAP)) * KC + (CC)) * 1024);
+#define POEM_T32_LOADB(B, TAP)                                                                                  \
+  {                                                                                                             \
+    const int toff_ = ((TAP) / 3) * Wp + ((TAP) % 3);                                                           \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) B[t] = tb[t * tplane + toff_];                                \
+  }
+#define POEM_T32_MMA(AW, B)                                                                                     \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                 \
+    _Pragma("unroll") for (int c = 0; c < CT; ++c) acc[c] = mfma32((&AW[c].x)[t], B[t], acc[c]);
+#define POEM_T32_STEP(CUR_A, CUR_B, NXT_A, NXT_B, TAP)                                                          \
+  POEM_T32_LOADW(NXT_A, (TAP) + 1, cc) POEM_T32_LOADB(NXT_B, (TAP) + 1)                                         \
+  if constexpr (NEXT != 0 && (TAP) < SG::MAXLD) sg.template load_k<NEXT, ((TAP) < SG::MAXLD ? (TAP) : 0)>();    \
+  __builtin_amdgcn_sched_barrier(0);                                                                            \
+  POEM_T32_MMA(CUR_A, CUR_B)                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (PIN) { POEM_T32_LOADW(wa, 0, 0) }
   // one chunk; NEXT = kind of the chunk staged meanwhile (0: none, 1: plain input / skip tensor, 2: interpolated part)
   auto chunk = [&](auto next_tag, const int cc) {
     constexpr int NEXT = decltype(next_tag)::value;
+    if constexpr (PIN) {
+      if constexpr (NEXT != 0) sg.template begin_k<NEXT>(cc + 1);
+      const float* tb = tile + (cc & 1) * chunk_floats + boff;
+      POEM_T32_LOADB(ba, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      POEM_T32_STEP(wa, ba, wb, bb, 0) POEM_T32_STEP(wb, bb, wa, ba, 1) POEM_T32_STEP(wa, ba, wb, bb, 2) POEM_T32_STEP(wb, bb, wa, ba, 3)
+      POEM_T32_STEP(wa, ba, wb, bb, 4) POEM_T32_STEP(wb, bb, wa, ba, 5) POEM_T32_STEP(wa, ba, wb, bb, 6) POEM_T32_STEP(wb, bb, wa, ba, 7)
+      { const int ccn = min(cc + 1, KC - 1); POEM_T32_LOADW(wb, 0, ccn) }
+      __builtin_amdgcn_sched_barrier(0);
+      POEM_T32_MMA(wa, ba)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) wa[c] = wb[c];
+      if constexpr (NEXT != 0) { sg.template finish_k<NEXT>(); sg.store(tile + ((cc + 1) & 1) * chunk_floats, tid); }
+      __syncthreads();
+      return;
+    }
     if constexpr (NEXT != 0) { sg.template begin_k<NEXT>(cc + 1); sg.template load_all<NEXT>(); }
     const float* tb = tile + (cc & 1) * chunk_floats + boff;
 #pragma unroll
@@ -466,6 +507,10 @@ __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
     for (; cc + 1 < KC; ++cc) chunk(std::integral_constant<int, 1>{}, cc);
     chunk(std::integral_constant<int, 0>{}, cc);
   }
+#undef POEM_T32_LOADW
+#undef POEM_T32_LOADB
+#undef POEM_T32_MMA
+#undef POEM_T32_STEP
   // epilogue: affine (conv bias + BatchNorm), ReLU, lateral add; lane = pixel, register e = channel 8(e>>2) + 4h + (e&3)
   const int Ho = A.H, Wo = A.W, oy = y0 + py;
 #pragma unroll
@@ -928,6 +973,8 @@ __global__ __launch_bounds__(64 * (PXB * CG + 1)) void conv3x3_s2p_kernel(Conv3A
 // Shapes conv3x3_s2_kernel takes: 80 / 160 / 320 output channels on 8-row output tiles of 32 / 16 / 8 columns.
 static int g_row_stager = 3;            // A/B switch: 0 = Conv3Stager for every fused-input convolution
 extern "C" void poem_decode_row_stager(int on) { g_row_stager = on; }      // bit 0: at W = 64, bit 1: at W = 32
+static int g_pin32 = 1;                 // A/B switch: 0 = compiler-scheduled taps in conv3x3_lds_kernel<5, true>
+extern "C" void poem_decode_pin32(int on) { g_pin32 = on != 0; }
 static int g_s2_staging_wave = 1;       // A/B switch: 0 = conv3x3_s2_kernel (every wave stages and multiplies)
 static int g_s2_blocks_per_cu = 0;       // 0: by the tile count (below); 2..4 forced (A/B)
 extern "C" void poem_decode_s2_staging_wave(int on) {
@@ -1042,7 +1089,10 @@ static hipError_t launch_conv3x3_lds(const Conv3Args& a, hipStream_t s) {
     case 2: POEM_CONVL(2); break;
     case 3: POEM_CONVL(3); break;
     case 4: POEM_CONVL(4); break;
-    default: POEM_CONVL(5); break;
+    default:
+      if (UPCAT && g_pin32) hipLaunchKernelGGL((conv3x3_lds_kernel<5, UPCAT, true>), grid, block, lds, s, a);
+      else POEM_CONVL(5);
+      break;
   }
 #undef POEM_CONVL
   return hipGetLastError();

@@ -120,6 +120,7 @@ hipError_t poem_launch_conv3x3_down2(const float* in, const void* wp, const floa
                                      int out_rs, int out_off, hipStream_t s);
 void poem_decode_s2_staging_wave(int on);
 void poem_decode_row_stager(int on);
+void poem_decode_pin32(int on);
 hipError_t poem_launch_conv1x1_up2(const float* in, const void* wp, const float* bias, float* out, int views, int K, int C, int h,
                                    int w, hipStream_t s);
 hipError_t poem_launch_upcat_pad(const float* a, int Ca, const float* b, int Cb, float* out, int views, int H, int W,

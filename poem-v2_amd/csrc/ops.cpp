@@ -258,6 +258,7 @@ int poem_set_decode_option(const char* name, int value) {
   if (!name) return POEM_E_ARG;
   if (!strcmp(name, "s2_staging_wave")) { poem_decode_s2_staging_wave(value); return POEM_OK; }
   if (!strcmp(name, "row_stager")) { poem_decode_row_stager(value); return POEM_OK; }
+  if (!strcmp(name, "pin32")) { poem_decode_pin32(value); return POEM_OK; }
   return POEM_E_ARG;
 }
 

@@ -216,13 +216,15 @@ def test_upcat_conv3x3_matches_the_two_launch_sequence_and_torch(ca, cb, cout, r
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ca,cb,cout,views,r", [(80, 40, 40, 5, 64), (16, 8, 40, 2, 64), (8, 16, 80, 2, 64), (80, 40, 40, 40, 64),
-                                                (160, 80, 80, 5, 32), (8, 8, 40, 3, 32), (160, 80, 80, 70, 32)])
+                                                (160, 80, 80, 5, 32), (8, 8, 40, 3, 32), (160, 80, 80, 70, 32),
+                                                (320, 160, 160, 9, 16), (16, 8, 160, 3, 16)])
 def test_upcat_conv3x3_row_stager_is_bit_identical_to_the_per_float_stager(ca, cb, cout, views, r):
     """The fused-input convolutions at 64 x 64 and 32 x 32 (uv_decode's last two stages, 120 -> 40 and 240 -> 80) staged by
     rows -- wave = channel, lane = (row group, column), the source rows of a chunk loaded once, two blocks per CU
     (`row_stager` 3, the default) -- against the per-float stager they replace (`row_stager` 0): every staged value is the
     same expression, so the results are bit-identical; top and bottom tiles (clamped source rows, rows outside the image), few
-    and many views, other channel splits."""
+    and many views, other channel splits.  At 16 x 16 (the first stage, 480 -> 160 on 32-channel tiles) the switch under test
+    is `pin32`: the pinned tap pipeline against the compiler-scheduled taps -- same summation order."""
     import poem_v2_amd as pk
     from poem_v2_amd import hip
     g = torch.Generator().manual_seed(ca + 7 * cb + cout + views + r)
@@ -235,13 +237,15 @@ def test_upcat_conv3x3_row_stager_is_bit_identical_to_the_per_float_stager(ca, c
     conv = pk.decode._Conv3x3(sd, "c", torch.device(DEV))
     outs = []
     try:
-        for on in (3, 0):
-            hip.check(hip.lib().poem_set_decode_option(b"row_stager", on), "poem_set_decode_option")
+        for on in (1, 0):
+            hip.check(hip.lib().poem_set_decode_option(b"row_stager", 3 * on), "poem_set_decode_option")
+            hip.check(hip.lib().poem_set_decode_option(b"pin32", on), "poem_set_decode_option")
             out = torch.full((views, cout, r, r), float("nan"), device=DEV)
             assert conv.upcat(a, b, r, r, out, pk.decode._plain_strides(cout, r, r))
             outs.append(out)
     finally:
         hip.lib().poem_set_decode_option(b"row_stager", 3)
+        hip.lib().poem_set_decode_option(b"pin32", 1)
     assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
 
 

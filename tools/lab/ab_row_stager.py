@@ -16,8 +16,9 @@ def timeit(fn, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 outs = {}
-for v in (0, 1, 3, 1, 3):
-    hip.lib().poem_set_decode_option(b"row_stager", v)
+for v in (0, 3, 7, 3, 7):               # bits 0 / 1: row stager at 64^2 / 32^2; bit 2: pinned taps at 16^2
+    hip.lib().poem_set_decode_option(b"row_stager", v & 3)
+    hip.lib().poem_set_decode_option(b"pin32", v >> 2)
     t = timeit(lambda: dec.heatmap_stage(feats, 256, 256))
     outs[v] = dec.heatmap_stage(feats, 256, 256)
     print(f"row_stager={v}: heatmap_stage {t*1e3:.1f} us", flush=True)
