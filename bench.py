@@ -226,7 +226,6 @@ def self_launch(args):
     """``python bench.py --gpus N`` without a launcher: start the N ranks here (torch.distributed.run, one process per GPU,
     rendezvous on 127.0.0.1) instead of silently measuring one.  Refuses loudly when the box has fewer GPUs -- unless
     POEM_SINGLE_DEVICE=1 asks for the functional rehearsal (gloo, every rank on cuda:0; numbers are not scaling numbers)."""
-    import socket
     import subprocess
     ndev = torch.cuda.device_count()
     env = dict(os.environ)
@@ -235,9 +234,7 @@ def self_launch(args):
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible; refusing to report a {args.gpus}-GPU line from "
                              f"fewer devices (POEM_SINGLE_DEVICE=1 rehearses the N-rank code path on one GPU over gloo)")
         env.setdefault("POEM_DIST_BACKEND", "gloo")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = pdist.free_port()
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -386,6 +383,70 @@ def eager_baseline(model_embed, batch, n_samples, dev):
             "sample": f"{n_samples} samples x {views[0]} views per pass, mean of {reps} passes"}
 
 
+def slice_batch(b, lo, hi):
+    """Samples [lo, hi) of a host batch of pk.inputs.synthetic_batch (views are stored sample after sample)."""
+    views = np.asarray(b["img_metas"]["cam_view_num"], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(views)])
+    v0, v1 = int(off[lo]), int(off[hi])
+    metas = dict(b["img_metas"])
+    metas["cam_intr"], metas["cam_extr"] = metas["cam_intr"][v0:v1].contiguous(), metas["cam_extr"][v0:v1].contiguous()
+    metas["cam_view_num"], metas["master_id"] = views[lo:hi].copy(), [0] * (hi - lo)
+    return b["mlvl_feat"][v0:v1].contiguous(), metas, b["reference_joints"][lo:hi].contiguous()
+
+
+def to_dev(item, dev):
+    f, m, r = item
+    m = dict(m)
+    m["cam_intr"], m["cam_extr"] = m["cam_intr"].to(dev), m["cam_extr"].to(dev)
+    return f.to(dev), m, r.to(dev)
+
+
+def c5_global_leg(head, C, dev, rank, world, ksteps, rotate=3):
+    """One GLOBAL ragged batch of 64 samples per step (views ~ U{2..10}, seed 5), the same on every rank, cut into contiguous
+    sample ranges by dist.shard_by_views; each rank runs its shard, the step time is the slowest rank's.  Then the claim the
+    sharding rests on is checked ACROSS processes: the shards' meshes, put together with the path's only collective (an
+    all-reduce(sum) into a zero-padded (3,64,799,3) buffer: x + 0 is exact), are compared bit for bit with rank 0 running the
+    whole batch of 64 in one forward (no kernel's arithmetic depends on the batch a sample runs in)."""
+    views_g = np.random.RandomState(5).randint(2, 11, size=64)
+    lo, hi = pdist.shard_by_views(views_g, rank, world)
+    counts = torch.zeros(2 * world, dtype=torch.float64, device=dev)
+    counts[rank], counts[world + rank] = hi - lo, float(views_g[lo:hi].sum())
+    pdist.all_reduce_sum_(counts)
+    globals_ = [pk.inputs.synthetic_batch(views_g.tolist(), seed=5000 + 7919 * i) for i in range(rotate)]   # rank-independent
+    mine = [to_dev(slice_batch(g, lo, hi), dev) for g in globals_] if hi > lo else []
+    with torch.no_grad():
+        for i in range(3):
+            if mine:
+                head(*mine[i % len(mine)])
+        pdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(ksteps):
+            if mine:
+                head(*mine[i % len(mine)])
+        torch.cuda.synchronize()
+        pdist.barrier()
+        gdt = time.perf_counter() - t0
+        tg = torch.tensor([gdt], dtype=torch.float64, device=dev)
+        pdist.all_reduce_max_(tg)
+        joined = torch.zeros(3, 64, 799, 3, dtype=torch.float32, device=dev)
+        if mine:
+            joined[:, lo:hi] = head(*mine[0])["all_coords_preds"]
+        pdist.all_reduce_sum_(joined)
+        out = {"value": 64 * ksteps / float(tg.item()), "unit": "samples/s", "ms_per_step": float(tg.item()) / ksteps * 1e3,
+               "scaling": "strong", "samples_by_rank": [int(v) for v in counts[:world].tolist()],
+               "views_by_rank": [int(v) for v in counts[world:].tolist()],
+               "note": "one global batch of 64 ragged samples per step, dist.shard_by_views; max over ranks"}
+        if rank == 0:
+            whole = head(*to_dev(slice_batch(globals_[0], 0, 64), dev))["all_coords_preds"]
+            out["sharded_bit_equal_to_single_process"] = bool(torch.equal(whole, joined))
+            out["sharded_max_abs_diff_m"] = float((whole - joined).abs().max())
+            del whole
+        del joined, mine
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -433,6 +494,7 @@ def main():
         local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    grouped = pdist.active()      # a process group exists: N > 1, or a one-rank group forced by POEM_DIST_FORCE_INIT=1
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -514,7 +576,7 @@ def main():
     pdist.all_reduce_max_(tmax)
     dt = float(tmax.item())
     scale_diag = None
-    if world > 1:
+    if grouped:
         # what a reader of the scaling curve needs beside `value`: every rank's own step time (min / max / spread) and the
         # latency of the path's only collective (the 16-byte all-reduce of the metric sums), measured alone
         per = torch.zeros(world, dtype=torch.float64, device=dev)
@@ -548,6 +610,7 @@ def main():
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": step_ms[len(step_ms) // 2] if len(step_ms) % 2 else
         0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]),
+        "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{baseline_config_name(args.model, args.views, args.views_range, args.batch, parametric)}: POEM-{args.model} head "
@@ -557,7 +620,7 @@ def main():
                    "batch_per_gpu": args.batch, "views": args.views if not args.views_range else list(args.views_range), "embed": C,
                    "parallelism": f"dp{world}", "ranks_joined": world,
                    "process_group": (f"{torch.distributed.get_backend()} world_size={torch.distributed.get_world_size()}"
-                                     if world > 1 else "single process")},
+                                     if grouped else "single process")},
     }
     # whole step against the fp32 matrix pipe: FLOPs the launch list executes (not the as-written count) / step time
     ex = executed_flops(C, views, tables=bool(args.anchor_tables) and args.precision == "fp32", parametric=parametric)
@@ -768,6 +831,33 @@ def main():
             except Exception as e:   # informational: never fail the bench line on it
                 extras[name] = {"error": repr(e)[:200]}
         res["extra_configs"] = extras
+        # What the first real `--gpus N` run should show for `c5_global_ragged_batch64` (strong scaling of one global batch of
+        # 64): every rank's shard of that batch (dist.shard_by_views) timed ALONE on this GPU; an N-GPU step takes as long as
+        # its slowest shard (no data-path collective), so predicted value(N) = 64 / max shard time.
+        try:
+            views_g = np.random.RandomState(5).randint(2, 11, size=64)
+            glob_b = pk.inputs.synthetic_batch(views_g.tolist(), seed=5000)
+            pred = {}
+            for n in (1, 2, 4, 8):
+                ms = []
+                for r in range(n):
+                    lo, hi = pdist.shard_by_views(views_g, r, n)
+                    item = to_dev(slice_batch(glob_b, lo, hi), dev)
+                    ms.append(time_leg(head, [item], steps=max(6, 48 // (hi - lo)), warmup=3) * 1e3)
+                    del item
+                pred[f"n{n}"] = {"shard_ms_alone": [round(v, 4) for v in ms], "predicted_ms_per_step": max(ms),
+                                 "predicted_value": 64.0 / max(ms) * 1e3}
+            for n in (2, 4, 8):
+                pred[f"n{n}"]["predicted_speedup_vs_n1"] = pred[f"n{n}"]["predicted_value"] / pred["n1"]["predicted_value"]
+            pred["note"] = ("POEM-medium, one global batch of 64 samples with 2..10 views (seed 5) cut by dist.shard_by_views; each "
+                            "shard timed alone on this one GPU, back-to-back forwards on resident inputs; predicted N-GPU step = the "
+                            "slowest shard (the path has no data-path collective; the 16-byte metric all-reduce is not in this leg); "
+                            "compare with `c5_global_ragged_batch64` of a real --gpus N line")
+            res["predicted_c5_strong_scaling"] = pred
+            del glob_b
+        except Exception as e:   # informational: never fail the bench line on it
+            res["predicted_c5_strong_scaling"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
     if world == 1 and not args.views_range and not parametric and not args.headline_only:
         # one stage earlier (SURVEY 8f rows N1 + N2): backbone pyramid -> feat_decode / heatmap_stage -> DLT -> head.  The
         # HRNet backbone itself is out of scope; its output pyramid is synthetic.  Reported beside the headline, never as it.
@@ -919,43 +1009,17 @@ def main():
             res["speedup_vs_eager"] = value / res["eager_baseline"]["value"]
         except Exception as e:   # the eager leg is informational: never fail the bench line on it
             res["eager_baseline"] = {"error": repr(e)[:200]}
-    if world > 1 and args.precision == "fp32" and not args.headline_only and not args.views_range and not parametric:
+    if grouped and args.precision == "fp32" and not args.headline_only and not args.views_range and not parametric:
         # BASELINE configs[4] as ONE global batch: 64 samples with 2..10 views each (seed 5), split over the ranks by
         # dist.shard_by_views (contiguous sample ranges balanced by their view counts) -- strong scaling of that batch, next
         # to the weak-scaling headline above.  No data-path collective: each rank runs its shard, the time is the slowest rank's.
         try:
-            views_g = np.random.RandomState(5).randint(2, 11, size=64)
-            lo, hi = pdist.shard_by_views(views_g, rank, world)
-            mine = views_g[lo:hi].tolist()
-            counts = torch.zeros(2 * world, dtype=torch.float64, device=dev)
-            counts[rank], counts[world + rank] = hi - lo, float(sum(mine))
-            pdist.all_reduce_sum_(counts)
-            _, b2, _ = make_leg(C, mine, False, dev, rank, rotate=3, seed0=5000)
-            ksteps = max(5, args.steps)
-            with torch.no_grad():
-                for i in range(3):
-                    head(*b2[i % len(b2)][:3])
-                pdist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(ksteps):
-                    head(*b2[i % len(b2)][:3])
-                torch.cuda.synchronize()
-                pdist.barrier()
-                gdt = time.perf_counter() - t0
-            tg = torch.tensor([gdt], dtype=torch.float64, device=dev)
-            pdist.all_reduce_max_(tg)
-            res["c5_global_ragged_batch64"] = {
-                "value": 64 * ksteps / float(tg.item()), "unit": "samples/s", "ms_per_step": float(tg.item()) / ksteps * 1e3,
-                "scaling": "strong", "samples_by_rank": [int(v) for v in counts[:world].tolist()],
-                "views_by_rank": [int(v) for v in counts[world:].tolist()],
-                "note": "one global batch of 64 ragged samples per step, dist.shard_by_views; max over ranks"}
+            res["c5_global_ragged_batch64"] = c5_global_leg(head, C, dev, rank, world, max(5, args.steps))
         except Exception as e:
             res["c5_global_ragged_batch64"] = {"error": repr(e)[:200]}
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    pdist.shutdown()
 
 
 if __name__ == "__main__":

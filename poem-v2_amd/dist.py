@@ -14,20 +14,48 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def force_init():
+    """POEM_DIST_FORCE_INIT=1: build the process group even at WORLD_SIZE 1.  A one-rank RCCL communicator is legal, so a
+    1-GPU box can execute the very branch an 8-GPU run takes (communicator creation with ``device_id=``, device-tensor
+    all-reduces, barrier, destroy) -- tests/test_dist_gpu.py."""
+    return os.environ.get("POEM_DIST_FORCE_INIT") == "1"
+
+
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torch.distributed.run contract)."""
+    """Initialise torch.distributed from RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* (torch.distributed.run contract): one process
+    per GPU, communicator bound to the rank's device -- what the reference's ``setup_ddp`` does with
+    ``init_process_group("nccl")`` + ``set_device(rank)`` + ``barrier()`` (scripts/eval.py:30-43 upstream)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_init()) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                raise RuntimeError("init_from_env: MASTER_PORT is not set (torch.distributed.run exports it); refusing to guess "
+                                   "a rendezvous port for a multi-rank group")
+            os.environ["MASTER_PORT"] = str(free_port())
         if backend == "nccl":
+            if os.environ.get("POEM_SINGLE_DEVICE") == "1":
+                local_rank = 0
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def free_port():
+    """A TCP port free on 127.0.0.1 right now (the launchers and tests never hard-code one)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def active():
+    """True when collectives run: a process group exists (any world size -- a forced one-rank group included)."""
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_range(n_items, rank, world):
@@ -52,17 +80,23 @@ def shard_by_views(cam_view_num, rank, world):
 
 
 def all_reduce_sum_(t):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
 def all_reduce_max_(t):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.barrier()
+
+
+def shutdown():
+    """Tear the group down (``dist.destroy_process_group()``, scripts/eval.py:105 upstream); a no-op without one."""
+    if active():
+        dist.destroy_process_group()

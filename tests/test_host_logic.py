@@ -221,6 +221,11 @@ def test_shard_ranges_cover_everything():
     assert got == list(range(64))
 
 
+def pdist_free_port():
+    from poem_v2_amd.dist import free_port
+    return free_port()
+
+
 _WORKER = r'''
 import os, sys, torch
 sys.path.insert(0, sys.argv[1])
@@ -281,9 +286,10 @@ dist.destroy_process_group()
 def test_dp_metric_allreduce_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", OMP_NUM_THREADS="1")
+    port = str(pdist_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script), ROOT, str(tmp_path)],
+                          "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT, str(tmp_path)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "DP_OK" in out.stdout
@@ -324,9 +330,10 @@ def test_dp_sharding_and_metric_allreduce_gloo_world8(tmp_path):
     contiguous ranges, and the sharded metric equals the single-process one (the world-2 test covers the other metrics)."""
     script = tmp_path / "worker8.py"
     script.write_text(_WORKER8)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", OMP_NUM_THREADS="1")
+    port = str(pdist_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
-                          "--master-addr", "127.0.0.1", "--master-port", "29641", str(script), ROOT],
+                          "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT],
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "DP8_OK" in out.stdout
