@@ -122,7 +122,7 @@ struct HeadRun {
     HIPCHK(poem_launch_conv1x1(mlvl_feat, h->P(T_INPROJ_W), h->R(T_INPROJ_B), h->pe_table, p.pe_index,
                                (fused_fe && !h->taps) ? nullptr : p.x, fused_fe ? p.xt : nullptr, BN, c.in_channels, C, HW, s));
     if (fused_fe && (h->small_batch & 1)) {      // coordinates, inverted extrinsics and the projection table in one launch (merge.hip)
-      HIPCHK(poem_launch_input_tables(h->bps, reference_joints, h->tmpl, p.view_sample, cam_intr, cam_extr, p.ptab, p.centre, p.pt_xyz,
+      HIPCHK(poem_launch_input_tables(h->bps, reference_joints, h->tmpl, p.view_sample, cam_intr, cam_extr, p.ptab, p.ptab + (size_t)plan_views * S * 4, p.centre, p.pt_xyz,
                                       p.xyz[0], BN, B, S, Q, c.feat_h, c.feat_w, img_w, img_h, c.radius, s));
       return POEM_OK;
     }
@@ -130,7 +130,7 @@ struct HeadRun {
     if (fused_fe) {
       float* inv = p.uv + (size_t)BN * S * 2;
       HIPCHK(poem_launch_invert_extr(cam_extr, inv, BN, s));
-      HIPCHK(poem_launch_project_table(h->bps, p.centre, p.view_sample, cam_intr, inv, p.ptab, nullptr, BN, C, c.feat_h, c.feat_w, S,
+      HIPCHK(poem_launch_project_table(h->bps, p.centre, p.view_sample, cam_intr, inv, p.ptab, p.ptab + (size_t)plan_views * S * 4, nullptr, BN, C, c.feat_h, c.feat_w, S,
                                        img_w, img_h, s));
     } else {      // operator front end: the projection (the caller's cameras) here, the sampling inside the body
       HIPCHK(poem_launch_project_uv(h->bps, p.centre, p.view_sample, cam_intr, cam_extr, p.uv + (size_t)BN * S * 2, p.uv, BN, c.feat_h,
@@ -143,19 +143,33 @@ struct HeadRun {
   int sampling(hipStream_t st) {
     if (fused_fe) {
       SampleMergeArgs sm{};
-      sm.xt = p.xt; sm.tab = (const float4*)p.ptab; sm.view_sample = p.view_sample; sm.offs = p.offs;
+      sm.xt = p.xt; sm.tab = (const float4*)p.ptab; sm.tabo = (const uint2*)(p.ptab + (size_t)plan_views * S * 4);
+      sm.view_sample = p.view_sample; sm.offs = p.offs;
       sm.w0 = (const float4*)h->P(T_M00_W); sm.b0 = h->R(T_M00_B); sm.w1 = (const float4*)h->P(T_M02_W); sm.b1 = h->R(T_M02_B);
       sm.h2 = p.h2; sm.q1 = p.q1; sm.S = S; sm.hw = HW; sm.h2_tiled = 1;
       sm.views = plan_views; sm.views_dev = p.offs + B;      // the grid is sized for the plan, the kernel reads the batch's own count
+      // The samples whose view count divides 8 go through sample_group_kernel (the whole stage in one kernel: merge_net[0]'s
+      // hidden rows never reach HBM) when the batch has enough views to fill the chip with its 8-tile units; the two-kernel
+      // form takes the rest.  Which samples go where is decided on the device from the layout (the launch graph is keyed by the
+      // batch size only); the two forms give the same bits.
+      const bool group_ok = h->group_min_views >= 0 && (S / C) % 8 == 0;
+      sm.group_min_views = group_ok ? (h->group_min_views > 0 ? h->group_min_views : 2 * poem_device_cu_count() / ((C / (C == 512 ? 32 : 64)) * (S / C / 8)))
+                                    : 0x7fffffff;
       // (per-forward table build only) The build on the neighbour-search stream holds 68 KB of LDS per block, and next to the
       // MFMA-dense sample_merge waves its blocks linger: a CU that hosts one takes a single sample_merge block (2 x 66.5 KB no
       // longer fit) and the persistent grid runs in two rounds.  sample_merge waits for the build (+0.06 ms on the critical path).
       if (h->tables_first && h->tables_pending) HIPCHK(hipStreamWaitEvent(st, h->ev_tab, 0));
-      HIPCHK(poem_launch_sample_merge(&sm, C, st));
       MergeTailArgs mt{};
       mt.h2 = p.h2; mt.q1 = p.q1; mt.offs = p.offs;
       mt.w0 = (const float4*)h->P(T_M10_W); mt.b0 = h->R(T_M10_B); mt.w1 = (const float4*)h->P(T_M12_W); mt.b1 = h->R(T_M12_B);
       mt.out = p.bps_feat; mt.B = B; mt.S = S; mt.h2_tiled = 1;
+      mt.group_min_views = sm.group_min_views; mt.views_dev = sm.views_dev;
+      if (group_ok) {
+        SampleGroupArgs sg{};
+        sg.sm = sm; sg.w2 = mt.w0; sg.b2 = mt.b0; sg.w3 = mt.w1; sg.b3 = mt.b1; sg.out = p.bps_feat;
+        HIPCHK(poem_launch_sample_group(&sg, C, st));
+      }
+      HIPCHK(poem_launch_sample_merge(&sm, C, st));
       HIPCHK(poem_launch_merge_tail(&mt, C, st));
       return POEM_OK;
     }
@@ -202,7 +216,7 @@ struct HeadRun {
     //  batch's own view total: that total joins the key there)
     const std::vector<int64_t> key = {B, plan_views, fused_fe ? -1 : BN, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
                                       h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
-                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, h->gemm_xcd_map, h->f1_split, h->gemm_kslab, h->va_p1, h->xattn_half};
+                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, h->gemm_xcd_map, h->f1_split, h->gemm_kslab, h->va_p1, h->xattn_half, h->group_min_views};
     poem_handle_s::GraphEntry* hit = nullptr;
     for (auto& g : h->graph_cache)
       if (g.key == key) { hit = &g; break; }

@@ -21,13 +21,14 @@ hipError_t poem_launch_narrow_linear(const float* x, int ldx, const float* w, co
 hipError_t poem_launch_sine_pe(float* out, int F, int H, int W, int max_views, hipStream_t s);
 int poem_sample_merge_supported(int C, int S, int hw);
 hipError_t poem_launch_project_table(const float* bps, const float* centre, const int* view_sample, const float* intr,
-                                     const float* inv_extr, void* tab, float* uv, int views, int C, int fh, int fw, int S,
+                                     const float* inv_extr, void* tabw, void* tabo, float* uv, int views, int C, int fh, int fw, int S,
                                      int img_w, int img_h, hipStream_t s);
 hipError_t poem_launch_view_layout(const ViewLayoutArgs* a, hipStream_t s);
 hipError_t poem_launch_input_tables(const float* bps, const float* ref_joints, const float* tmpl, const int* view_sample,
-                                    const float* intr, const float* extr, void* tab, float* centre, float* pt_xyz, float* query_xyz,
+                                    const float* intr, const float* extr, void* tabw, void* tabo, float* centre, float* pt_xyz, float* query_xyz,
                                     int views, int B, int S, int Q, int fh, int fw, int img_w, int img_h, float radius, hipStream_t s);
 hipError_t poem_launch_sample_merge(const SampleMergeArgs* a, int C, hipStream_t s);
+hipError_t poem_launch_sample_group(const SampleGroupArgs* a, int C, hipStream_t s);
 int poem_device_cu_count(void);
 hipError_t poem_launch_merge_tail(const MergeTailArgs* a, int C, hipStream_t s);
 hipError_t poem_launch_invert_extr(const float* extr, float* inv, int views, hipStream_t s);

@@ -4,7 +4,8 @@
 
 struct SampleMergeArgs {
   const float* xt;            // (views, hw, C): input_proj + positional table, channel-LAST
-  const float4* tab;          // (views, S, 2): per projected point the four bilinear weights | four tap pixels, 16 bits each, in two dwords (+ two unused)
+  const float4* tab;          // (views, S): per projected point the four bilinear weights
+  const uint2* tabo;          // (views, S): ... and its four tap pixels, 16 bits each, in two dwords
   const int* view_sample;     // (views)  view -> sample
   const int* offs;            // (B + 1)  sample -> first view
   const float4* w0; const float* b0;   // merge_net_feature.0.0, packed (C x C)
@@ -17,6 +18,17 @@ struct SampleMergeArgs {
   // memory (= view_offsets[B]) and `views` is only the capacity the grid was sized for -- the captured launch then serves every
   // view layout of a batch size.
   const int* views_dev;
+  // Grouped kernel (sample_group_kernel): samples whose view count N divides 8 run there when the batch has at least
+  // `group_min_views` views (device-side count); this kernel and merge_tail_kernel then skip them.  INT_MAX: never (everything here).
+  int group_min_views;
+};
+
+// sample_group_kernel: the whole sampling stage of the samples with N in {1, 2, 4, 8} in one kernel (merge.hip).
+struct SampleGroupArgs {
+  SampleMergeArgs sm;         // h2 unused; q1: the master rows, written at a group's first tile, read back at its last
+  const float4* w2; const float* b2;   // merge_net_feature.1.0, packed (C/2 x C/2)
+  const float4* w3; const float* b3;   // merge_net_feature.1.2, packed (C x C/2)
+  float* out;                 // (B * S, C) bps_feat
 };
 
 // The per-view index arrays of a ragged batch, built on the device from offsets that travel in the KERNEL-ARGUMENT segment
@@ -40,4 +52,6 @@ struct MergeTailArgs {
   float* out;                 // (B * S, C) bps_feat
   int B, S;
   int h2_tiled;
+  int group_min_views;        // as SampleMergeArgs (with views_dev): the samples the grouped kernel takes are skipped here
+  const int* views_dev;
 };

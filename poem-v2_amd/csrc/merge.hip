@@ -66,6 +66,11 @@ __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[TPW][P], float* _
 
 }  // namespace
 
+// The samples sample_group_kernel takes (N divides its 8-segment units) when the batch is large enough to fill the chip with
+// its units; sample_merge_kernel / merge_tail_kernel skip them.  Both forms produce the same bits (same fma chains, same
+// reduction trees), so the choice may depend on the batch.
+__device__ __forceinline__ bool poem_group_n(int N) { return N == 1 || N == 2 || N == 4 || N == 8; }
+
 template <int C, int P, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMergeArgs A) {
   constexpr int XS = 32 * P, XSP = XS + 1, NTILE = C / 32, TPW = NTILE / NW, KCH = C / 8, HALF = C / 2;
@@ -89,19 +94,26 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
   uint2 to[NIT];                          // tap pixels, 16 bits each: (nw | ne << 16, sw | se << 16)
   auto load_table = [&](int w) {
     const int v = w / TPV, t = w % TPV;
-    const float4* tb = A.tab + ((size_t)v * A.S + (size_t)(t % NSEG) * C) * 2;
+    const size_t p0 = (size_t)v * A.S + (size_t)(t % NSEG) * C;
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int k = i * PPI + wv * PPW + q;
-      tw[i] = tb[2 * k];
-      to[i] = *reinterpret_cast<const uint2*>(tb + 2 * k + 1);
+      tw[i] = A.tab[p0 + k];
+      to[i] = A.tabo[p0 + k];
     }
   };
-  if (slot < nv * TPV) load_table(slot);
+  const bool grouped = A.views_dev && nv >= A.group_min_views;      // sample_group_kernel takes the samples with N | 8
+  int pref = -1;                          // the tile whose table entries the registers hold
+  if (slot < nv * TPV && !grouped) { load_table(slot); pref = slot; }
 
   for (int w = slot; w < nv * TPV; w += L) {
     const int v = w / TPV, t = w % TPV;
     const int c0 = (t / NSEG) * XS, seg = t % NSEG;
+    if (grouped) {
+      const int bb = A.view_sample[v];
+      if (poem_group_n(A.offs[bb + 1] - A.offs[bb])) continue;
+    }
+    if (pref != w) load_table(w);
     __syncthreads();                          // the previous tile's readers of X0
     // ---- fill: X0[k][row] = bilinear sample of plane (v, c0 + row) at point seg*C + k
     {
@@ -165,7 +177,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
       acc_to_lds<TPW, P, XSP>(acc, X0, wv * TPW, 0, j, h);
     }
     __syncthreads();
-    load_table(w + L < nv * TPV ? w + L : w);   // unconditional: a conditional definition would keep the consumed entries live through the GEMMs
+    pref = w + L < nv * TPV ? w + L : w;
+    load_table(pref);                         // unconditional: a conditional definition would keep the consumed entries live through the GEMMs
     // ---- merge_net[0].2: C/64 output tiles x P column tiles = one (tile, p) per wave
     {
       const int t2 = wv / P, p2 = wv % P;
@@ -183,29 +196,83 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// merge_net[1] on a tile of reduced rows, shared by merge_tail_kernel and sample_group_kernel: X0 holds m[k = channel][col]
+// (HALF x 32 P); Linear(HALF, HALF) + ReLU, Linear(HALF, C), / N, + q1 -> out.  Column col is row row_of(col) of q1 / out.
+template <int C, int P, int NW, class RowFn>
+__device__ __forceinline__ void tail_mlp(float* __restrict__ X0, const float4* __restrict__ w0, const float* __restrict__ b0,
+                                         const float4* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ q1,
+                                         float* __restrict__ out, int N, RowFn row_of, int lane, int wv) {
+  constexpr int HALF = C / 2, XS = 32 * P, XSP = XS + 1, NTA = HALF / 32, NTB = C / 32, KCH = HALF / 8;
+  constexpr bool WIDE = NTA >= NW;        // first GEMM: whole column range per wave, or one (tile, p) per wave
+  constexpr int TPWA = WIDE ? NTA / NW : 1, PA = WIDE ? P : 1;
+  constexpr int TPWB = NTB / NW;
+  static_assert(WIDE || NTA * P == NW, "shape");
+  static_assert(NTB % NW == 0, "shape");
+  const int j = lane & 31, h = lane >> 5;
+  // ---- merge_net[1].0 + ReLU (HALF -> HALF)
+  {
+    const int tile0 = WIDE ? wv * TPWA : wv / P, col0 = WIDE ? 0 : 32 * (wv % P);
+    f32x16 acc[TPWA][PA];
+    lds_gemm<KCH, XSP, PA, TPWA, true>(frag_rsrc(w0, (unsigned)(HALF * HALF * 4)), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024,
+                                       X0 + col0, acc, lane);
+    bias_act<TPWA, PA>(acc, b0, tile0, h, true);
+    __syncthreads();
+    acc_to_lds<TPWA, PA, XSP>(acc, X0, tile0, col0, j, h);
+  }
+  __syncthreads();
+  // ---- merge_net[1].2 (HALF -> C), / N, + q1 -> bps_feat
+  {
+    const int tile0 = wv * TPWB;
+    f32x16 acc[TPWB][P];
+    lds_gemm<KCH, XSP, P, TPWB, true>(frag_rsrc(w1, (unsigned)(C * HALF * 4)), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, acc, lane);
+    bias_act<TPWB, P>(acc, b1, tile0, h, false);
+    const float fn = (float)N;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const size_t row = row_of(32 * p + j);
+      const float* qp = q1 + row * C + 4 * h;
+      float* yp = out + row * C + 4 * h;
+#pragma unroll
+      for (int tp = 0; tp < TPWB; ++tp)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 qq = *reinterpret_cast<const float4*>(qp + (tile0 + tp) * 32 + 8 * g);
+          float4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float yv = acc[tp][p][4 * g + e];
+            (&o.x)[e] = (&qq.x)[e] + (N == 1 ? yv : yv / fn);      // merge_finalize_kernel's expression
+          }
+          *reinterpret_cast<float4*>(yp + (tile0 + tp) * 32 + 8 * g) = o;
+        }
+    }
+  }
+}
+
+// Reduction tree of the cross-view dot product <h_n, h_0> over the HALF channels (both kernels): per 4-channel chunk q a
+// 4-term fma chain from 0; chunks of a 32-channel tile t2 = q / 8 -- q % 8 = 2 g + hh -- as ((g0 + g1) + (g2 + g3)) per hh,
+// then hh = 0 + hh = 1; tiles pairwise: (t0 + t1) + (t2 + t3) ...  In the grouped kernel a lane holds the four g chunks of
+// one (t2, hh) in its accumulator registers; here 16 lanes hold chunks q = l16 + 16 i.
 template <int C, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void merge_tail_kernel(MergeTailArgs A) {
-  constexpr int HALF = C / 2, XS = 64, XSP = XS + 1, P = 2;
-  constexpr int NTA = HALF / 32, NTB = C / 32, KCH = HALF / 8;
-  constexpr int TPWA = NTA >= NW ? NTA / NW : 1, PA = NTA >= NW ? 2 : 1;     // first GEMM: whole column range or one (tile, p)
-  constexpr int TPWB = NTB / NW;
+  constexpr int HALF = C / 2, XS = 64, XSP = XS + 1;
   constexpr int F4 = HALF / 64;           // float4 chunks per lane of a 16-lane row group
-  static_assert(NTA >= NW || NTA * 2 == NW, "shape");
-  static_assert(NTB % NW == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* X0 = smem;                       // HALF * XSP
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int rg = lane >> 4, l16 = lane & 15;
   const int items = (A.B * A.S) / XS;
   const int NSEG = A.S / C;
   // tiles of the fused kernel (XS rows there = 32 * P' with P' = 2 for C <= 256, 1 for C = 512)
   constexpr int FXS = C == 512 ? 32 : 64;
   const int TPV = (C / FXS) * NSEG;
+  const bool grouped = A.views_dev && *A.views_dev >= A.group_min_views;
 
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int i0 = item * XS;               // first global basis-point row b * S + s
     const int b = i0 / A.S, s0 = i0 % A.S;
     const int off = A.offs[b], N = A.offs[b + 1] - off;
+    if (grouped && poem_group_n(N)) continue;
     __syncthreads();                        // the previous item's readers of X0
     // ---- reduce over the views: 16 lanes per row, rows jj = 4 * (pass * NW + wv) + rg
     for (int pass = 0; pass < XS / (4 * NW); ++pass) {
@@ -246,16 +313,23 @@ __global__ __launch_bounds__(NW * 64, 2) void merge_tail_kernel(MergeTailArgs A)
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
           if (n0 + u >= N) break;
-          float dot = 0.f;
+          float d[F4];
 #pragma unroll
           for (int i = 0; i < F4; ++i) {
-            dot = fmaf(v[u][i].x, mast[i].x, dot);
-            dot = fmaf(v[u][i].y, mast[i].y, dot);
-            dot = fmaf(v[u][i].z, mast[i].z, dot);
-            dot = fmaf(v[u][i].w, mast[i].w, dot);
+            float t = fmaf(v[u][i].x, mast[i].x, 0.f);
+            t = fmaf(v[u][i].y, mast[i].y, t);
+            t = fmaf(v[u][i].z, mast[i].z, t);
+            t = fmaf(v[u][i].w, mast[i].w, t);
+            t += __shfl_xor(t, 2, 64);          // g bit 0
+            t += __shfl_xor(t, 4, 64);          // g bit 1
+            t += __shfl_xor(t, 1, 64);          // hh
+            t += __shfl_xor(t, 8, 64);          // the tile pair (t2 = 2 i, 2 i + 1)
+            d[i] = t;
           }
-#pragma unroll
-          for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+          float dot;
+          if constexpr (F4 == 1) dot = d[0];
+          else if constexpr (F4 == 2) dot = d[0] + d[1];
+          else dot = (d[0] + d[1]) + (d[2] + d[3]);
 #pragma unroll
           for (int i = 0; i < F4; ++i) {
             acc[i].x = fmaf(dot, v[u][i].x, acc[i].x);
@@ -271,42 +345,193 @@ __global__ __launch_bounds__(NW * 64, 2) void merge_tail_kernel(MergeTailArgs A)
         for (int e = 0; e < 4; ++e) X0[(4 * (l16 + 16 * i) + e) * XSP + jj] = (&acc[i].x)[e];
     }
     __syncthreads();
-    // ---- merge_net[1].0 + ReLU (HALF -> HALF)
-    {
-      const int tile0 = NTA >= NW ? wv * TPWA : wv / 2, col0 = NTA >= NW ? 0 : 32 * (wv % 2);
-      f32x16 acc[TPWA][PA];
-      lds_gemm<KCH, XSP, PA, TPWA, true>(frag_rsrc(A.w0, (unsigned)(HALF * HALF * 4)), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024,
-                                         X0 + col0, acc, lane);
-      bias_act<TPWA, PA>(acc, A.b0, tile0, h, true);
+    tail_mlp<C, 2, NW>(X0, A.w0, A.b0, A.w1, A.b1, A.q1, A.out, N, [&](int col) { return (size_t)i0 + col; }, lane, wv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// sample_group_kernel: the WHOLE sampling stage in one kernel for the samples whose view count N divides 8 -- merge_net[0]'s
+// hidden rows (the (S, N, C/2) block: 537 MB written and read back per 32-sample step at C = 256) never leave the chip.
+//   With N | NSEG the N Q1 rows of a basis point s -- rows s N .. s N + N - 1 -- are N consecutive segments of ONE (view,
+// channel) plane (header: row r of a view = c' * NSEG + seg), so a block that walks the segments of its XS channels in order
+// meets the master row (n = 0) of every point first and then its other views: unit = (view, XS channels, 8 consecutive
+// segments) = 8 tiles of sample_merge_kernel's shape; per tile fill -> Linear + ReLU -> Linear -> h (16 accumulator registers
+// per lane), then in registers: n = 0: h0 = h, m = 0 (N = 1: m = h); n > 0: m += <h, h0> h (merge_features_mv's weights; the
+// dot product's partials meet through 1 KB of LDS); at n = N - 1 the XS finished rows m go through merge_net[1] (tail_mlp)
+// and leave as bps_feat rows.  Only the master rows q1 (the residual) make a round trip: written at n = 0, read at n = N - 1.
+//   Same fma chains and reduction trees as sample_merge_kernel + merge_tail_kernel: bit-identical results.
+template <int C, int P, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void sample_group_kernel(SampleGroupArgs G) {
+  const SampleMergeArgs& A = G.sm;
+  constexpr int XS = 32 * P, XSP = XS + 1, NTILE = C / 32, TPW = NTILE / NW, KCH = C / 8, HALF = C / 2, NT2 = HALF / 32;
+  constexpr int LPP = XS / 4, PPW = 64 / LPP, PPI = NW * PPW, NIT = C / PPI;   // lanes per point, points per wave / block pass
+  constexpr int USEG = 8;                 // segments per unit
+  static_assert(NTILE % NW == 0 && (C / 64) * P == NW && C % PPI == 0 && NIT % 2 == 0 && NT2 * P == NW, "shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* X0 = smem;                       // C * XSP
+  float* red = smem + C * XSP;            // NT2 * XS: per-tile partial dot products
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int NSEG = A.S / C, UPC = NSEG / USEG, UPV = (C / XS) * UPC;
+  const int slot = (int)blockIdx.x, L = (int)gridDim.x;
+  const int nv = A.views_dev ? min(*A.views_dev, A.views) : A.views;
+  if (nv < A.group_min_views) return;
+  const unsigned CC4 = (unsigned)(C * C * 4);
+  const int q = lane / LPP, cg = lane % LPP;
+  const int t2 = wv / P, p2 = wv % P;     // this wave's (32-channel tile, column tile) of h
+
+  // The table entries of a tile's C points (weights 16 B, tap pixels 8 B) are copied into LDS by LDS-DMA (buffer_load ... lds:
+  // memory pipeline -> LDS, no registers) a tile ahead, right before the short second GEMM of the previous tile: the fill
+  // starts with LDS reads instead of two dependent L2 trips, and nothing of the table is held in registers across the GEMMs.
+  float4* TW = reinterpret_cast<float4*>(red + NT2 * XS);     // C weights
+  uint2* TO = reinterpret_cast<uint2*>(TW + C);               // C tap-pixel pairs
+  auto stage_table = [&](int v, int seg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const size_t p0 = (size_t)v * A.S + (size_t)seg * C;
+    const __amdgpu_buffer_rsrc_t wr = frag_rsrc(A.tab + p0, (unsigned)(C * 16));
+    const __amdgpu_buffer_rsrc_t orr = frag_rsrc(A.tabo + p0, (unsigned)(C * 8));
+    for (int r = wv; r < C / 64; r += NW)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (__attribute__((address_space(3))) void*)(TW + 64 * r), 16, lane * 16, r * 1024, 0, 0);
+    for (int r = wv; r < C / 128; r += NW)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(orr, (__attribute__((address_space(3))) void*)(TO + 128 * r), 16, lane * 16, r * 1024, 0, 0);
+#endif
+  };
+  int pref_v = -1, pref_seg = -1;
+
+  for (int u = slot; u < nv * UPV; u += L) {
+    const int v = u / UPV, rest = u % UPV;
+    const int c0 = (rest / UPC) * XS, seg0 = (rest % UPC) * USEG;
+    const int b = A.view_sample[v];
+    const int off = A.offs[b], N = A.offs[b + 1] - off;
+    if (!poem_group_n(N)) continue;
+    const size_t rbase = (size_t)(v - off) * A.S + (size_t)c0 * NSEG;      // Q1 row of (channel c0, segment 0) within the sample
+    const size_t obase = (size_t)b * A.S;
+    f32x16 h0, m;
+    for (int i = 0; i <= USEG; ++i) {
+      const int seg = seg0 + i;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the staged table has landed
+      __syncthreads();                        // the previous tile's readers of X0; the staged table
+      if (i > 0) {
+        // ---- tile i - 1 closed its group: the finished rows m go through merge_net[1]
+        const int np = (i - 1) & (N - 1);
+        if (np == N - 1) {
+          {
+            const f32x16 (&mm)[1][1] = reinterpret_cast<const f32x16 (&)[1][1]>(m);
+            acc_to_lds<1, 1, XSP>(mm, X0, t2, 32 * p2, j, h);
+          }
+          h0 = zero16(); m = zero16();        // dead from here (the next tile is a group's first): not live across merge_net[1]
+          __syncthreads();
+          const int segl = seg - 1;           // the group's last segment
+          tail_mlp<C, P, NW>(X0, G.w2, G.b2, G.w3, G.b3, A.q1, G.out, N,
+                             [&](int col) { return obase + (rbase + (size_t)col * NSEG + segl) / N; }, lane, wv);
+          __syncthreads();                    // its readers of X0, before the next fill
+        }
+        if (i == USEG) break;
+      }
+      const int n = i & (N - 1);
+      if (pref_v != v || pref_seg != seg) {   // (first unit of the block / after skipped units) the table is not staged yet
+        stage_table(v, seg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      // ---- fill: X0[k][row] = bilinear sample of plane (v, c0 + row) at point seg*C + k
+      {
+        const __amdgpu_buffer_rsrc_t xrs = frag_rsrc(A.xt + (size_t)v * A.hw * C, (unsigned)(A.hw * C * 4));
+        const int loff = (c0 + 4 * cg) * 4;
+        constexpr int DEPTH = POEM_SM_DEPTH;
+        constexpr unsigned PIXB = C * 4;        // bytes per pixel of the channel-last planes
+        float4 tap[DEPTH][4], tww[2];
+#define SG_TAPS(I)                                                                               \
+        {                                                                                        \
+          const uint2 o_ = TO[(I) * PPI + wv * PPW + q];                                         \
+          tap[(I) % DEPTH][0] = frag_load(xrs, (int)((o_.x & 0xffffu) * PIXB) + loff, 0);        \
+          tap[(I) % DEPTH][1] = frag_load(xrs, (int)((o_.x >> 16) * PIXB) + loff, 0);            \
+          tap[(I) % DEPTH][2] = frag_load(xrs, (int)((o_.y & 0xffffu) * PIXB) + loff, 0);        \
+          tap[(I) % DEPTH][3] = frag_load(xrs, (int)((o_.y >> 16) * PIXB) + loff, 0);            \
+        }
+#pragma unroll
+        for (int ii = 0; ii < DEPTH - 1; ++ii) SG_TAPS(ii)
+        tww[0] = TW[wv * PPW + q];
+#pragma unroll
+        for (int ii = 0; ii < NIT; ++ii) {
+          if (ii + DEPTH - 1 < NIT) SG_TAPS(ii + DEPTH - 1)
+          if (ii + 1 < NIT) tww[(ii + 1) & 1] = TW[(ii + 1) * PPI + wv * PPW + q];
+          __builtin_amdgcn_sched_barrier(0);
+          const int k = ii * PPI + wv * PPW + q;
+          float* xo = X0 + k * XSP + 4 * cg;
+          const float4 ww = tww[ii & 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // the accumulation order of ATen's grid_sampler_2d (nw, ne, sw, se), as sample.hip's grid_sample_kernel
+            float a = (&tap[ii % DEPTH][0].x)[e] * ww.x;
+            a = fmaf((&tap[ii % DEPTH][1].x)[e], ww.y, a);
+            a = fmaf((&tap[ii % DEPTH][2].x)[e], ww.z, a);
+            a = fmaf((&tap[ii % DEPTH][3].x)[e], ww.w, a);
+            xo[e] = a;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#undef SG_TAPS
+      }
       __syncthreads();
-      acc_to_lds<TPWA, PA, XSP>(acc, X0, tile0, col0, j, h);
-    }
-    __syncthreads();
-    // ---- merge_net[1].2 (HALF -> C), / N, + q1 -> bps_feat
-    {
-      const int tile0 = wv * TPWB;
-      f32x16 acc[TPWB][P];
-      lds_gemm<KCH, XSP, P, TPWB, true>(frag_rsrc(A.w1, (unsigned)(C * HALF * 4)), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, acc, lane);
-      bias_act<TPWB, P>(acc, A.b1, tile0, h, false);
-      const float fn = (float)N;
+      // ---- q1: a group's first tile is its master rows (the residual of the merge)
+      if (n == 0) {
+        for (int jj = wv; jj < XS; jj += NW) {
+          float* dst = A.q1 + (obase + (rbase + (size_t)jj * NSEG + seg) / N) * C;
 #pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const size_t row = (size_t)i0 + 32 * p + j;
-        const float* qp = A.q1 + row * C + 4 * h;
-        float* yp = A.out + row * C + 4 * h;
+          for (int k = lane; k < C; k += 64) dst[k] = X0[k * XSP + jj];
+        }
+      }
+      // ---- merge_net[0].0 + ReLU
+      {
+        f32x16 acc[TPW][P];
+        lds_gemm<KCH, XSP, P, TPW, true>(frag_rsrc(A.w0, CC4), __builtin_amdgcn_readfirstlane(wv * TPW * KCH * 1024), KCH * 1024, X0, acc, lane);
+        bias_act<TPW, P>(acc, A.b0, wv * TPW, h, true);
+        __syncthreads();                        // every wave is done reading the sampled tile
+        acc_to_lds<TPW, P, XSP>(acc, X0, wv * TPW, 0, j, h);
+      }
+      __syncthreads();
+      // the next tile's tap pixels: this unit's next segment, or the first tile of this block's next unit
+      if (i + 1 < USEG) { pref_v = v; pref_seg = seg + 1; }
+      else {
+        const int un = u + L < nv * UPV ? u + L : u;
+        pref_v = un / UPV; pref_seg = ((un % UPV) % UPC) * USEG;
+      }
+      stage_table(pref_v, pref_seg);           // (every wave is past the fill: the staged table has no readers left)
+      // ---- merge_net[0].2: one (32-channel tile, column tile) of h per wave
+      {
+        f32x16 acc[1][1];
+        lds_gemm<KCH, XSP, 1, 1, true>(frag_rsrc(A.w1, CC4 / 2), __builtin_amdgcn_readfirstlane(t2 * KCH * 1024), KCH * 1024, X0 + 32 * p2, acc, lane);
+        bias_act<1, 1>(acc, A.b1, t2, h, false);
+        const f32x16& hn = acc[0][0];
+        if (n == 0) {
+          h0 = hn;
 #pragma unroll
-        for (int tp = 0; tp < TPWB; ++tp)
+          for (int e = 0; e < 16; ++e) m[e] = N == 1 ? hn[e] : 0.f;
+        } else {
+          // <h, h0>: this lane's 16 channels as chunks g (registers 4 g .. 4 g + 3), ((g0 + g1) + (g2 + g3)), the two halves,
+          // then the NT2 channel tiles through LDS -- merge_tail_kernel's tree; m += dot * h
+          float pg[4];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const float4 qq = *reinterpret_cast<const float4*>(qp + (tile0 + tp) * 32 + 8 * g);
-            float4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float yv = acc[tp][p][4 * g + e];
-              (&o.x)[e] = (&qq.x)[e] + (N == 1 ? yv : yv / fn);      // merge_finalize_kernel's expression
-            }
-            *reinterpret_cast<float4*>(yp + (tile0 + tp) * 32 + 8 * g) = o;
+            float d = fmaf(hn[4 * g], h0[4 * g], 0.f);
+            d = fmaf(hn[4 * g + 1], h0[4 * g + 1], d);
+            d = fmaf(hn[4 * g + 2], h0[4 * g + 2], d);
+            d = fmaf(hn[4 * g + 3], h0[4 * g + 3], d);
+            pg[g] = d;
           }
+          const float sd = half_sum((pg[0] + pg[1]) + (pg[2] + pg[3]));
+          float dot = sd;
+          if constexpr (NT2 > 1) {
+            if (h == 0) red[t2 * XS + 32 * p2 + j] = sd;
+            __syncthreads();
+            const float* rp = red + 32 * p2 + j;
+            if constexpr (NT2 == 2) dot = rp[0] + rp[XS];
+            else if constexpr (NT2 == 4) dot = (rp[0] + rp[XS]) + (rp[2 * XS] + rp[3 * XS]);
+            else dot = ((rp[0] + rp[XS]) + (rp[2 * XS] + rp[3 * XS])) + ((rp[4 * XS] + rp[5 * XS]) + (rp[6 * XS] + rp[7 * XS]));
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) m[e] = fmaf(dot, hn[e], m[e]);
+        }
       }
     }
   }
@@ -314,10 +539,10 @@ __global__ __launch_bounds__(NW * 64, 2) void merge_tail_kernel(MergeTailArgs A)
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Projection of the basis points into every view (project_kernel of sample.hip, same fp32 chain) down to the bilinear
-// weights and tap offsets of grid_sample(align_corners=False, zero padding): 32 bytes per (view, point).
+// weights and tap offsets of grid_sample(align_corners=False, zero padding): 24 bytes per (view, point): four weights | four tap pixels of 16 bits, in two arrays.
 __global__ void project_table_kernel(const float* __restrict__ bps, const float* __restrict__ centre,
                                      const int* __restrict__ view_sample, const float* __restrict__ intr,
-                                     const float* __restrict__ inv_extr, float4* __restrict__ tab, float* __restrict__ uv,
+                                     const float* __restrict__ inv_extr, float4* __restrict__ tabw, uint2* __restrict__ tabo, float* __restrict__ uv,
                                      int views, int S, int fw, int fh, float inv_w, float inv_h, int C) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   const int v = blockIdx.y;
@@ -347,10 +572,9 @@ __global__ void project_table_kernel(const float* __restrict__ bps, const float*
   const float w_sw = (vx0 && vy1) ? wx0 * wy1 : 0.f, w_se = (vx1 && vy1) ? wx1 * wy1 : 0.f;
   const int cx0 = min(max(x0, 0), fw - 1), cx1 = min(max(x1, 0), fw - 1);
   const int cy0 = min(max(y0, 0), fh - 1), cy1 = min(max(y1, 0), fh - 1);
-  float4* o = tab + ((size_t)v * S + s) * 2;
-  o[0] = make_float4(w_nw, w_ne, w_sw, w_se);
-  o[1] = make_float4(__uint_as_float((unsigned)(cy0 * fw + cx0) | ((unsigned)(cy0 * fw + cx1) << 16)),
-                     __uint_as_float((unsigned)(cy1 * fw + cx0) | ((unsigned)(cy1 * fw + cx1) << 16)), 0.f, 0.f);
+  tabw[(size_t)v * S + s] = make_float4(w_nw, w_ne, w_sw, w_se);
+  tabo[(size_t)v * S + s] = make_uint2((unsigned)(cy0 * fw + cx0) | ((unsigned)(cy0 * fw + cx1) << 16),
+                                       (unsigned)(cy1 * fw + cx0) | ((unsigned)(cy1 * fw + cx1) << 16));
 }
 
 // The three small input kernels of a forward in ONE launch (round 4: each is a 5-7 us link of a small batch's latency chain):
@@ -358,7 +582,7 @@ __global__ void project_table_kernel(const float* __restrict__ bps, const float*
 // same fp64 elimination) and the sample's centre read from reference_joints; the rows behind them are prep_xyz_kernel's elements.
 __global__ void input_tables_kernel(const float* __restrict__ bps, const float* __restrict__ ref_joints, const float* __restrict__ tmpl,
                                     const int* __restrict__ view_sample, const float* __restrict__ intr,
-                                    const float* __restrict__ extr, float4* __restrict__ tab, float* __restrict__ centre,
+                                    const float* __restrict__ extr, float4* __restrict__ tabw, uint2* __restrict__ tabo, float* __restrict__ centre,
                                     float* __restrict__ pt_xyz, float* __restrict__ query_xyz, int views, int B, int S, int Q, int fw,
                                     int fh, float inv_w, float inv_h, float radius) {
   if ((int)blockIdx.y >= views) {
@@ -400,10 +624,9 @@ __global__ void input_tables_kernel(const float* __restrict__ bps, const float* 
   const float w_sw = (vx0 && vy1) ? wx0 * wy1 : 0.f, w_se = (vx1 && vy1) ? wx1 * wy1 : 0.f;
   const int cx0 = min(max(x0, 0), fw - 1), cx1 = min(max(x1, 0), fw - 1);
   const int cy0 = min(max(y0, 0), fh - 1), cy1 = min(max(y1, 0), fh - 1);
-  float4* o = tab + ((size_t)v * S + s) * 2;
-  o[0] = make_float4(w_nw, w_ne, w_sw, w_se);
-  o[1] = make_float4(__uint_as_float((unsigned)(cy0 * fw + cx0) | ((unsigned)(cy0 * fw + cx1) << 16)),
-                     __uint_as_float((unsigned)(cy1 * fw + cx0) | ((unsigned)(cy1 * fw + cx1) << 16)), 0.f, 0.f);
+  tabw[(size_t)v * S + s] = make_float4(w_nw, w_ne, w_sw, w_se);
+  tabo[(size_t)v * S + s] = make_uint2((unsigned)(cy0 * fw + cx0) | ((unsigned)(cy0 * fw + cx1) << 16),
+                                       (unsigned)(cy1 * fw + cx0) | ((unsigned)(cy1 * fw + cx1) << 16));
 }
 
 
@@ -419,6 +642,19 @@ static hipError_t launch_sample_merge_t(const SampleMergeArgs& a, hipStream_t s)
   const int tpv = (C / XS) * (a.S / C);
   const long items = (long)a.views * tpv;
   const long grid = std::min<long>(items, (long)cu_count() * 2);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, a);
+  return hipGetLastError();
+}
+
+template <int C, int P, int NW>
+static hipError_t launch_sample_group_t(const SampleGroupArgs& a, hipStream_t s) {
+  constexpr int XS = 32 * P, XSP = XS + 1;
+  const size_t lds = ((size_t)C * XSP + (size_t)(C / 64) * XS + (size_t)C * 6) * sizeof(float);   // X tile | dot partials | staged table
+  auto kern = sample_group_kernel<C, P, NW>;
+  static std::atomic<unsigned long long> optin{0};
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin); e != hipSuccess) return e;
+  const long units = (long)a.sm.views * (C / XS) * (a.sm.S / C / 8);
+  const long grid = std::min<long>(units, (long)cu_count() * 2);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, s, a);
   return hipGetLastError();
 }
@@ -440,22 +676,22 @@ extern "C" int poem_sample_merge_supported(int C, int S, int hw) {
 }
 
 extern "C" hipError_t poem_launch_project_table(const float* bps, const float* centre, const int* view_sample, const float* intr,
-                                                const float* inv_extr, void* tab, float* uv, int views, int C, int fh, int fw,
+                                                const float* inv_extr, void* tabw, void* tabo, float* uv, int views, int C, int fh, int fw,
                                                 int S, int img_w, int img_h, hipStream_t s) {
   hipLaunchKernelGGL(project_table_kernel, dim3((S + 255) / 256, views), dim3(256), 0, s, bps, centre, view_sample, intr, inv_extr,
-                     (float4*)tab, uv, views, S, fw, fh, 1.0f / (float)img_w, 1.0f / (float)img_h, C);
+                     (float4*)tabw, (uint2*)tabo, uv, views, S, fw, fh, 1.0f / (float)img_w, 1.0f / (float)img_h, C);
   return hipGetLastError();
 }
 
 extern "C" hipError_t poem_launch_input_tables(const float* bps, const float* ref_joints, const float* tmpl, const int* view_sample,
-                                               const float* intr, const float* extr, void* tab, float* centre, float* pt_xyz,
+                                               const float* intr, const float* extr, void* tabw, void* tabo, float* centre, float* pt_xyz,
                                                float* query_xyz, int views, int B, int S, int Q, int fh, int fw, int img_w, int img_h,
                                                float radius, hipStream_t s) {
   const unsigned gx = (unsigned)((S + 255) / 256);
   const long total = (long)B * S * 3 + (long)B * Q * 3 + 3L * B;
   const unsigned prep_rows = (unsigned)((total + (long)gx * 256 - 1) / ((long)gx * 256));
   hipLaunchKernelGGL(input_tables_kernel, dim3(gx, (unsigned)views + prep_rows), dim3(256), 0, s, bps, ref_joints, tmpl, view_sample, intr,
-                     extr, (float4*)tab, centre, pt_xyz, query_xyz, views, B, S, Q, fw, fh, 1.0f / (float)img_w, 1.0f / (float)img_h, radius);
+                     extr, (float4*)tabw, (uint2*)tabo, centre, pt_xyz, query_xyz, views, B, S, Q, fw, fh, 1.0f / (float)img_w, 1.0f / (float)img_h, radius);
   return hipGetLastError();
 }
 
@@ -464,6 +700,16 @@ extern "C" hipError_t poem_launch_sample_merge(const SampleMergeArgs* a, int C, 
     case 128: return launch_sample_merge_t<128, 2, 4>(*a, s);
     case 256: return launch_sample_merge_t<256, 2, 8>(*a, s);
     case 512: return launch_sample_merge_t<512, 1, 8>(*a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+extern "C" hipError_t poem_launch_sample_group(const SampleGroupArgs* a, int C, hipStream_t s) {
+  if ((a->sm.S / C) % 8) return hipErrorInvalidValue;
+  switch (C) {
+    case 128: return launch_sample_group_t<128, 2, 4>(*a, s);
+    case 256: return launch_sample_group_t<256, 2, 8>(*a, s);
+    case 512: return launch_sample_group_t<512, 1, 8>(*a, s);
     default: return hipErrorInvalidValue;
   }
 }

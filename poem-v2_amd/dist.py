@@ -66,16 +66,22 @@ def shard_range(n_items, rank, world):
 
 
 def shard_by_views(cam_view_num, rank, world):
-    """Contiguous sample range whose summed view count is balanced across ranks (ragged batches: the sampling
-    stage costs ~N_i, the decoder is per-sample constant).  Returns [lo, hi) over samples."""
+    """Contiguous sample range whose cost is balanced across ranks (ragged batches).  Cost of a sample = 1 + 0.0127 N_i:
+    the sampling stage is ~8 us per view next to ~630 us of per-sample decoder work (profiles/r04_step_timeline.txt).  Every
+    boundary is the prefix sum NEAREST to r/world of the total (a first-not-below rule hands out 9 | 7 samples where 8 | 8 is
+    closer: the slowest rank sets the step time).  Returns [lo, hi) over samples."""
     import numpy as np
     v = np.asarray(cam_view_num, dtype=np.int64)
-    cost = v.astype(np.float64) * 0.05 + 1.0          # merge ~5 % of a sample per 8 views (SURVEY 8e)
+    cost = v.astype(np.float64) * 0.0127 + 1.0
     cum = np.concatenate([[0.0], np.cumsum(cost)])
-    bounds = [int(np.searchsorted(cum, cum[-1] * r / world, side="left")) for r in range(world)] + [len(v)]
-    bounds[0] = 0
-    for i in range(1, len(bounds)):
-        bounds[i] = max(bounds[i], bounds[i - 1])
+    bounds = [0]
+    for r in range(1, world):
+        t = cum[-1] * r / world
+        i = int(np.searchsorted(cum, t, side="left"))
+        if i > 0 and abs(cum[i - 1] - t) <= abs(cum[min(i, len(v))] - t):
+            i -= 1
+        bounds.append(max(min(i, len(v)), bounds[-1]))
+    bounds.append(len(v))
     return bounds[rank], bounds[rank + 1]
 
 

@@ -847,6 +847,36 @@ def test_fused_sampling_every_view_count(embed):
     assert _md(bf[1], bf[0]) < 1e-5 * scale
 
 
+@pytest.mark.parametrize("embed", [128, 256, 512])
+def test_grouped_sampling_kernel_is_bit_identical_to_the_two_kernel_form(embed):
+    """sample_group_kernel (merge.hip): the samples whose view count divides 8 run the whole sampling stage in one kernel
+    (merge_net[0]'s hidden rows stay on the chip); the others -- and every sample of a batch too small to fill the chip with
+    the 8-tile units -- go through sample_merge_kernel + merge_tail_kernel.  Which form a sample takes depends on the batch,
+    so the two must give the same bits: one sample of each N = 1 .. 10, forced through the grouped kernel
+    (group_min_views = 1: N = 1, 2, 4, 8 grouped, the rest two-kernel, in one forward) vs never (-1), `bps_feat` and the
+    vertices bit for bit; both against the oracle's sampling stage."""
+    spec = dict(embed=embed, nsample=4096, views=[7, 1, 10, 3, 2, 9, 5, 4, 8, 6, 8, 1, 2, 4], seed=78, parametric=False)
+    cfg, w, consts, batch = case_setup(spec)
+    taps = {}
+    run_oracle(cfg, w, consts, batch, taps=taps)
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    eng = head._engine_for(torch.device(DEV))
+    eng.enable_taps(True)
+    B = len(spec["views"])
+    bf, out = {}, {}
+    for mode in (1, -1, 0):
+        eng.set_option("group_min_views", mode)
+        with torch.no_grad():
+            for _ in range(3):                      # plain launches, capture, replay
+                out[mode] = head(feat, metas, rj)["all_coords_preds"].cpu()
+        bf[mode] = eng.tap("bps_feat", (B, 4096, embed)).cpu()
+    scale = max(1.0, float(taps["bps_feat"].abs().max()))
+    assert _md(bf[1], taps["bps_feat"]) < 2e-5 * scale
+    assert torch.equal(bf[1], bf[-1]) and torch.equal(out[1], out[-1])
+    assert torch.equal(bf[0], bf[-1]) and torch.equal(out[0], out[-1])      # default threshold: whichever form it picks
+
+
 @pytest.mark.parametrize("fused", [1, 0])
 def test_projections_outside_the_image_and_behind_the_camera(fused):
     """grid_sample's zero padding and the |z| < 1e-7 clamp of the projection (ptEmb_head.py:880-883,900): views that see the
