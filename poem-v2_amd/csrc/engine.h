@@ -164,6 +164,7 @@ struct poem_handle_s {
   // chain's rows (small batches).  (Measured and dropped: block 0's F1 as two launches, +1 %; a small batch's later F1 GEMMs on
   // a quarter of the CUs, +4 % at B = 4.)
   int small_batch = 3;
+  int group_xcd = 1;         // sample_group_kernel's XCD-aware unit order (A/B switch)
   int group_min_views = 0;   // sample_group_kernel: 0 = by the chip (units >= 2 per CU), > 0 = this many views, -1 = never (forward.cpp)
   int knn_fma = 0;           // neighbour distances with the fma contraction of pytorch3d's CUDA kernel (knn.hip); default: the CPU path's rounding
   int chain_tile = 0;        // chain row-tile height: 0 = per launch (chain.hip chain_tile_p), 1 = 32 rows, 2 = 64 rows (A/B)

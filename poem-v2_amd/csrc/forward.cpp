@@ -164,6 +164,7 @@ struct HeadRun {
       mt.w0 = (const float4*)h->P(T_M10_W); mt.b0 = h->R(T_M10_B); mt.w1 = (const float4*)h->P(T_M12_W); mt.b1 = h->R(T_M12_B);
       mt.out = p.bps_feat; mt.B = B; mt.S = S; mt.h2_tiled = 1;
       mt.group_min_views = sm.group_min_views; mt.views_dev = sm.views_dev;
+      sm.xcd_order = h->group_xcd;
       if (group_ok) {
         SampleGroupArgs sg{};
         sg.sm = sm; sg.w2 = mt.w0; sg.b2 = mt.b0; sg.w3 = mt.w1; sg.b3 = mt.b1; sg.out = p.bps_feat;
@@ -216,7 +217,7 @@ struct HeadRun {
     //  batch's own view total: that total joins the key there)
     const std::vector<int64_t> key = {B, plan_views, fused_fe ? -1 : BN, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
                                       h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
-                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, h->gemm_xcd_map, h->f1_split, h->gemm_kslab, h->va_p1, h->xattn_half, h->group_min_views};
+                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, h->gemm_xcd_map, h->f1_split, h->gemm_kslab, h->va_p1, h->xattn_half, h->group_min_views, h->group_xcd};
     poem_handle_s::GraphEntry* hit = nullptr;
     for (auto& g : h->graph_cache)
       if (g.key == key) { hit = &g; break; }

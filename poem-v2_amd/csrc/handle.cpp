@@ -467,6 +467,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "va_p1") { if (value < -1 || value > 2) return POEM_E_ARG; h->va_p1 = value; }
   else if (k == "gemm_kslab") { poem_gemm_kslab(value != 0); h->gemm_kslab = value != 0; }
   else if (k == "small_batch") h->small_batch = value;
+  else if (k == "group_xcd") h->group_xcd = value != 0;
   else if (k == "group_min_views") { if (value < -1) return POEM_E_ARG; h->group_min_views = value; }
   else if (k == "bps_defer") { if (value < -1 || value > 3) return POEM_E_ARG; h->bps_defer = value; }
   else if (k == "chain_tile") { if (value < 0 || value > 3) return POEM_E_ARG; h->chain_tile = value; }

@@ -21,6 +21,7 @@ struct SampleMergeArgs {
   // Grouped kernel (sample_group_kernel): samples whose view count N divides 8 run there when the batch has at least
   // `group_min_views` views (device-side count); this kernel and merge_tail_kernel then skip them.  INT_MAX: never (everything here).
   int group_min_views;
+  int xcd_order;              // sample_group_kernel: XCD-aware unit order (merge.hip)
 };
 
 // sample_group_kernel: the whole sampling stage of the samples with N in {1, 2, 4, 8} in one kernel (merge.hip).

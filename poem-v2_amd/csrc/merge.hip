@@ -103,6 +103,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
     }
   };
   const bool grouped = A.views_dev && nv >= A.group_min_views;      // sample_group_kernel takes the samples with N | 8
+  if (grouped) {                          // ... all of them? (a fixed-view batch of 1, 2, 4 or 8 views: nothing to do here)
+    const int B = (int)(A.views_dev - A.offs);
+    int mine = 0;
+    for (int b = tid; b < B; b += NW * 64) mine |= !poem_group_n(A.offs[b + 1] - A.offs[b]);
+    if (!__syncthreads_or(mine)) return;
+  }
   int pref = -1;                          // the tile whose table entries the registers hold
   if (slot < nv * TPV && !grouped) { load_table(slot); pref = slot; }
 
@@ -267,6 +273,11 @@ __global__ __launch_bounds__(NW * 64, 2) void merge_tail_kernel(MergeTailArgs A)
   constexpr int FXS = C == 512 ? 32 : 64;
   const int TPV = (C / FXS) * NSEG;
   const bool grouped = A.views_dev && *A.views_dev >= A.group_min_views;
+  if (grouped) {
+    int mine = 0;
+    for (int b = tid; b < A.B; b += NW * 64) mine |= !poem_group_n(A.offs[b + 1] - A.offs[b]);
+    if (!__syncthreads_or(mine)) return;
+  }
 
   for (int item = blockIdx.x; item < items; item += gridDim.x) {
     const int i0 = item * XS;               // first global basis-point row b * S + s
@@ -397,14 +408,23 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_group_kernel(SampleGro
   };
   int pref_v = -1, pref_seg = -1;
 
-  for (int u = slot; u < nv * UPV; u += L) {
-    const int v = u / UPV, rest = u % UPV;
+  // Unit order.  The UPV units of a view share its feature planes (each 64-channel slice is read by the units of both segment
+  // halves) and its table (every 8-segment part by the units of all channel tiles); workgroups go round-robin over the eight
+  // XCDs, each with its own L2.  XCD-aware order (A.xcd_order, grid a multiple of 8): the blocks of XCD x = blockIdx % 8 walk the
+  // views x, x + 8, ... -- a view's planes and table are fetched from HBM by ONE L2 (381 -> 23x MB read per 32-sample step at
+  // C = 256); plain order: u = blockIdx, blockIdx + grid, ...
+  const bool xo = A.xcd_order && (L & 7) == 0;
+  const int ustep = xo ? (L >> 3) : L, xcd = slot & 7;
+  const int ulimit = xo ? ((nv - xcd + 7) >> 3) * UPV : nv * UPV;     // views xcd, xcd + 8, ... < nv
+  for (int lu = xo ? (slot >> 3) : slot; lu < ulimit; lu += ustep) {
+    const int v = xo ? xcd + 8 * (lu / UPV) : lu / UPV, rest = lu % UPV;
     const int c0 = (rest / UPC) * XS, seg0 = (rest % UPC) * USEG;
     const int b = A.view_sample[v];
     const int off = A.offs[b], N = A.offs[b + 1] - off;
     if (!poem_group_n(N)) continue;
-    const size_t rbase = (size_t)(v - off) * A.S + (size_t)c0 * NSEG;      // Q1 row of (channel c0, segment 0) within the sample
+    const int rbase = (v - off) * A.S + c0 * NSEG;      // Q1 row of (channel c0, segment 0) within the sample (< 8 S)
     const size_t obase = (size_t)b * A.S;
+    const int nsh = __ffs(N) - 1;             // N is 1, 2, 4 or 8: a row's basis point is r >> nsh
     f32x16 h0, m;
     for (int i = 0; i <= USEG; ++i) {
       const int seg = seg0 + i;
@@ -422,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_group_kernel(SampleGro
           __syncthreads();
           const int segl = seg - 1;           // the group's last segment
           tail_mlp<C, P, NW>(X0, G.w2, G.b2, G.w3, G.b3, A.q1, G.out, N,
-                             [&](int col) { return obase + (rbase + (size_t)col * NSEG + segl) / N; }, lane, wv);
+                             [&](int col) { return obase + (size_t)((rbase + col * NSEG + segl) >> nsh); }, lane, wv);
           __syncthreads();                    // its readers of X0, before the next fill
         }
         if (i == USEG) break;
@@ -476,7 +496,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_group_kernel(SampleGro
       // ---- q1: a group's first tile is its master rows (the residual of the merge)
       if (n == 0) {
         for (int jj = wv; jj < XS; jj += NW) {
-          float* dst = A.q1 + (obase + (rbase + (size_t)jj * NSEG + seg) / N) * C;
+          float* dst = A.q1 + (obase + (size_t)((rbase + jj * NSEG + seg) >> nsh)) * C;
 #pragma unroll
           for (int k = lane; k < C; k += 64) dst[k] = X0[k * XSP + jj];
         }
@@ -493,8 +513,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_group_kernel(SampleGro
       // the next tile's tap pixels: this unit's next segment, or the first tile of this block's next unit
       if (i + 1 < USEG) { pref_v = v; pref_seg = seg + 1; }
       else {
-        const int un = u + L < nv * UPV ? u + L : u;
-        pref_v = un / UPV; pref_seg = ((un % UPV) % UPC) * USEG;
+        const int un = lu + ustep < ulimit ? lu + ustep : lu;
+        pref_v = xo ? xcd + 8 * (un / UPV) : un / UPV; pref_seg = ((un % UPV) % UPC) * USEG;
       }
       stage_table(pref_v, pref_seg);           // (every wave is past the fill: the staged table has no readers left)
       // ---- merge_net[0].2: one (32-channel tile, column tile) of h per wave
