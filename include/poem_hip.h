@@ -121,7 +121,12 @@ size_t poem_workspace_bytes(poem_handle_t h, int batch, int total_views);
 /* Diagnostics of the launch-graph cache, n >= 9 slots: [0] graph execs cached by this handle, [1] stream captures,
  * [2] hipGraphInstantiate calls, [3] forwards replayed from a graph, [4] forwards issued as plain launches,
  * [5] view-layout uploads (a forward whose layout equals the previous one uploads nothing), [6] retired execs parked in the
- * process, [7] parked execs taken over by a later capture (hipGraphExecUpdate), [8] updates the runtime refused.
+ * process, [7] parked execs taken over by a later capture (hipGraphExecUpdate), [8] updates the runtime refused, [9] (n >= 10)
+ * parked execs passed over because their last launch was still running.  Retired execs are never destroyed (a runtime
+ * workaround, csrc/handle.cpp): they are parked per device and re-used, so [6] is bounded by the largest number of execs ever
+ * cached at once per (device, shape) -- 12 per handle -- not by the handles created or layouts met; a server that cycles many
+ * model shapes should watch [6].  A parked exec is offered for update only on its own device and only after the launch it
+ * was retired behind has completed.
  * A forward never blocks the host: the layout travels in a kernel's argument segment. */
 int poem_graph_stats(poem_handle_t h, int64_t* out, int n);
 /* view_offsets_host: B+1 prefix sums of views per sample (host memory, the reference's cam_view_num).
@@ -176,7 +181,14 @@ int poem_set_chains(poem_handle_t h, int enable);
  * 32-channel-tile items (twice the blocks, 48 instead of 64 MFMAs per key tile each); "small_batch" (default 3), a bit mask of launch-count / dependency shortcuts: 1 = one input
  * launch (coordinates + inverse extrinsics + projection table) and no query-embedding broadcast where block 0 runs on the anchor
  * tables, 2 = block 0's anchor keys / values read out of the rows its chain projects (batches of <= 5 samples).
- * Unknown names return POEM_E_ARG. */
+ * Round 5, bit-identical: "group_min_views" (default 0): the samples whose view count divides 8 run the whole sampling stage in
+ * ONE kernel (csrc/merge.hip sample_group_kernel: bilinear sampling, merge_net[0], the cross-view dot / weighted sum and
+ * merge_net[1]; the hidden rows of merge_features_mv, ptEmb_head.py:745-762, never reach HBM) when the batch has at least this
+ * many views -- 0 = enough to give every CU two of the kernel's 8-tile units, -1 = never (two-kernel form for every sample);
+ * which samples go where is decided on the device from the view layout; "group_xcd" (default 1): that kernel's units in
+ * XCD-aware order (a view's feature planes and projection table are fetched by one L2).
+ * The switches marked process-wide are launcher statics: setting one on any handle sets it for the process (the launch-graph
+ * key carries the process's values).  Unknown names and out-of-range values return POEM_E_ARG. */
 int poem_set_option(poem_handle_t h, const char* name, int value);
 /* Block-0 anchor tables of poem_head_forward (default on, fp32 mode).  In the first decoder block every query's
  * neighbours are the 32 fixed anchors (anchor_points, lib/models/bricks/point_transformers.py:10-32) and every sample's
@@ -332,7 +344,9 @@ int poem_conv3x3_down2(const float* in, const void* w_packed, const float* scale
  * stager of the other widths.
  * "pin32" (default 1): the fused-input convolution with five 32-channel tiles (uv_decode's first, 480 -> 160) runs its taps as a
  * pinned two-stage pipeline (next tap's weights and operands requested before this tap's MFMAs); 0 = compiler-scheduled taps.
- * POEM_E_ARG for an unknown name. */
+ * "pool_fused" (default 1): poem_upcat_conv3x3_pool_head takes the shapes it supports; 0 = it returns POEM_E_UNSUPPORTED (A/B of
+ * the two-launch form).
+ * POEM_E_ARG for an unknown name or an out-of-range value. */
 int poem_set_decode_option(const char* name, int value);
 /* feat_decode's tail in one launch (POEM.py:190-193: F.interpolate(x, scale_factor=2, mode="bilinear") followed by feat_in, a
  * 1x1 convolution with bias): in (views,cin,h,w) -> out (views,cout,2h,2w).  The convolution is applied BEFORE the
@@ -351,6 +365,15 @@ int poem_upcat_conv3x3(const float* a_half, int ca, const float* b_full, int cb,
                        int out_ch_stride, int out_row_stride, int out_offset, void* stream);
 int poem_pool_conv1x1_sigmoid(const float* x, const float* w, const float* bias, float* heatmaps, int views, int c, int j,
                               int h, int w_, void* stream);
+/* uv_decode's last stage AND the read-out head in one launch (POEM.py:203-207 upstream: F.interpolate x2, torch.cat, ConvBlock,
+ * then max_pool2d(2, 2) + uv_out + sigmoid): poem_upcat_conv3x3 whose epilogue pools its own rows, contracts them with
+ * head_w (j x cout, row-major) + head_b and writes sigmoid(.) to heatmaps (views, j, h/2, w/2) -- the convolution's
+ * (views, cout, h, w) output, which nothing else reads, never reaches HBM.  Same bits as poem_upcat_conv3x3 +
+ * poem_pool_conv1x1_sigmoid.  POEM_E_UNSUPPORTED unless w == 64, 33 <= cout <= 48, j <= 32 and ca, cb are multiples of 8:
+ * call the two operators then. */
+int poem_upcat_conv3x3_pool_head(const float* a_half, int ca, const float* b_full, int cb, const void* w_packed, const float* scale,
+                                 const float* shift, const float* head_w, const float* head_b, float* heatmaps, int views, int cout,
+                                 int j, int h, int w, int relu, void* stream);
 /* Device-side evaluation metrics (replace the host loops of lib/metrics/pa_eval.py:45-83,104-124 and
  * lib/metrics/pck.py:36-96).
  * poem_pa_epe: pred, gt (B,P,3) -> out (B,2) = per-sample (Procrustes-aligned mean distance, plain mean distance);

@@ -748,7 +748,7 @@ static int poem_attn_cus() { return poem_device_cus(); }
 
 // opt-in split precision for the calls enqueued while it is set (api.cpp: around poem_head_forward in SPLIT_F16X3_ALL mode,
 // and by the operator-level entry point); head dims 32 and 64 only, the others keep the exact kernels
-static int g_xattn_half = 1;      // A/B: channel-tile items of the merged kernel for a single sample (poem_set_option "xattn_half")
+static std::atomic<int> g_xattn_half{1};      // A/B: channel-tile items of the merged kernel for a single sample (poem_set_option "xattn_half")
 extern "C" void poem_cross_attention_half(int on) { g_xattn_half = on; }
 static thread_local int g_xattn_split = 0;      // per host thread, like gemm.hip's split context.  1: split from fp32 images, 2: the images are already split (gemm.hip split output modes)
 extern "C" void poem_cross_attention_split(int on) { g_xattn_split = on; }

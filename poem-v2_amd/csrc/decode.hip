@@ -94,6 +94,12 @@ struct Conv3Args {
   const float* up_a;
   const float* skip_b;
   int Ca, Cb;
+  // fused read-out head (conv3x3_lds16_kernel<.., POOL>): instead of `out`, the block's rows go through max_pool2d(2, 2) ->
+  // 1x1 conv (J x Cout, bias) -> sigmoid -> hmap (views, J, H/2, W/2); the convolution's own output never reaches HBM
+  const float* head_w;
+  const float* head_b;
+  float* hmap;
+  int J;
 };
 
 template <int CT, int PT>
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(512) void conv3x3_lds_kernel(Conv3Args A) {
 // to a stride == 16 mod 32 floats so that the two channel planes a 32-lane group reads fall on disjoint banks.
 // Result layout: lane (g, j) holds output channels 16c + 4g .. + 3 of pixel j.
 typedef float f32x2v __attribute__((ext_vector_type(2)));
-template <int CT16, bool UPCAT, int RW = 0>
+template <int CT16, bool UPCAT, int RW = 0, bool POOL = false>
 __global__ __launch_bounds__(512, RW ? 4 : 2) void conv3x3_lds16_kernel(Conv3Args A) {
   constexpr bool ROWSG = RW != 0;
   extern __shared__ __attribute__((aligned(16))) float tile[];      // 2 x 8 x tstride
@@ -639,6 +645,46 @@ __global__ __launch_bounds__(512, RW ? 4 : 2) void conv3x3_lds16_kernel(Conv3Arg
 #undef POEM_T16_STEP
   // epilogue: lane (g, j) holds channels 16c + 4g + e of pixel (unit u, j)
   const int Ho = A.H, Wo = A.W;
+  if constexpr (POOL) {
+    // uv_decode's last convolution (POEM.py:203-207 upstream): its (views, 40, 64, 64) output is only ever read by
+    // max_pool2d + uv_out + sigmoid.  The block's TR = 4 rows hold two rows of 2 x 2 windows: horizontal maxima by a lane
+    // exchange (pixels j, j ^ 1 of a unit), into the idle staging tile as PH[channel][row][column pair]; then (pooled pixel,
+    // joint) pairs over the threads: vertical maximum, the J x Cout contraction as pool_head_kernel's fma chain (channels in
+    // order from 0), bias, sigmoid -- the same bits as the two-launch form.
+    static_assert(RW == 64, "four-row tiles of a 64-pixel-wide map");
+    constexpr int PW = 32, PR = 4;
+    float* PH = tile;                                 // Cout x PR x PW
+    float* HW_ = tile + A.Cout * PR * PW;             // J x Cout weights | J biases  (launcher: fits the staging tile)
+    for (int i = tid; i < A.J * A.Cout; i += 512) HW_[i] = A.head_w[i];
+    for (int i = tid; i < A.J; i += 512) HW_[A.J * A.Cout + i] = A.head_b[i];
+#pragma unroll
+    for (int c = 0; c < CT16; ++c) {
+      const int cbase = c * 16 + 4 * g;
+      const float4 sc = *reinterpret_cast<const float4*>(A.scale + cbase);
+      const float4 sh = *reinterpret_cast<const float4*>(A.shift + cbase);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float v = fmaf(acc[c][u][e], (&sc.x)[e], (&sh.x)[e]);
+          if (A.relu) v = fmaxf(v, 0.f);
+          v = fmaxf(v, __shfl_xor(v, 1, 64));
+          if (!(j & 1) && cbase + e < A.Cout) PH[((cbase + e) * PR + opy[u]) * PW + (opx[u] >> 1)] = v;
+        }
+    }
+    __syncthreads();
+    const int h2 = Ho / 2, w2 = Wo / 2;
+    for (int o = tid; o < A.J * 2 * PW; o += 512) {
+      const int jn = o / (2 * PW), pp = o % (2 * PW), prow = pp / PW, pcol = pp % PW;
+      const float* ph = PH + (2 * prow) * PW + pcol;
+      const float* wj = HW_ + jn * A.Cout;
+      float a = 0.f;
+      for (int c = 0; c < A.Cout; ++c) a = fmaf(fmaxf(ph[c * PR * PW], ph[c * PR * PW + PW]), wj[c], a);
+      const float v = a + HW_[A.J * A.Cout + jn];
+      A.hmap[(((size_t)n * A.J + jn) * h2 + (y0 / 2 + prow)) * w2 + pcol] = 1.0f / (1.0f + expf(-v));
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < CT16; ++c) {
     const int cbase = c * 16 + 4 * g;
@@ -973,6 +1019,8 @@ __global__ __launch_bounds__(64 * (PXB * CG + 1)) void conv3x3_s2p_kernel(Conv3A
 // Shapes conv3x3_s2_kernel takes: 80 / 160 / 320 output channels on 8-row output tiles of 32 / 16 / 8 columns.
 static int g_row_stager = 3;            // A/B switch: 0 = Conv3Stager for every fused-input convolution
 extern "C" void poem_decode_row_stager(int on) { g_row_stager = on; }      // bit 0: at W = 64, bit 1: at W = 32
+static int g_pool_fused = 1;            // A/B switch: 0 = uv_decode's last convolution and the read-out head as two launches
+extern "C" void poem_decode_pool_fused(int on) { g_pool_fused = on != 0; }
 static int g_pin32 = 1;                 // A/B switch: 0 = compiler-scheduled taps in conv3x3_lds_kernel<5, true>
 extern "C" void poem_decode_pin32(int on) { g_pin32 = on != 0; }
 static int g_s2_staging_wave = 1;       // A/B switch: 0 = conv3x3_s2_kernel (every wave stages and multiplies)
@@ -1060,7 +1108,7 @@ static hipError_t launch_conv3x3_lds(const Conv3Args& a, hipStream_t s) {
     const size_t lds16 = (size_t)2 * 8 * tstride * sizeof(float);
     if constexpr (UPCAT) {
       // W == 64 / 32 (four- / eight-row tiles), whole chunks of either kind: staging by rows, two blocks per CU (Conv3RowStager)
-      if (g_row_stager && a.Ca % 8 == 0 && a.Cb % 8 == 0 && (a.W == 64 || (a.W == 32 && (g_row_stager & 2)))) {
+      if (a.Ca % 8 == 0 && a.Cb % 8 == 0 && ((a.W == 64 && (g_row_stager & 1)) || (a.W == 32 && (g_row_stager & 2)))) {
 #define POEM_CONVL16R(CTV)                                                                                    \
         if (a.W == 64) hipLaunchKernelGGL((conv3x3_lds16_kernel<CTV, true, 64>), grid, block, lds16, s, a);   \
         else hipLaunchKernelGGL((conv3x3_lds16_kernel<CTV, true, 32>), grid, block, lds16, s, a)
@@ -1109,6 +1157,24 @@ extern "C" hipError_t poem_launch_upcat_conv3x3(const float* a_half, int Ca, con
   Conv3Args a{nullptr, (const float4*)wp, (const float2*)((const float*)wp + conv3x3_floats32(Cout, Ca + Cb)), scale, shift, nullptr, out,
               Ca + Cb, Cout, H, W, 1, relu, out_ns, out_cs, out_rs, out_off, views, a_half, b_full, Ca, Cb};
   return launch_conv3x3_lds<true>(a, s);
+}
+
+// The same with the read-out head in the epilogue (Conv3Args::hmap): W == 64, Cout <= 48 on 16-row tiles, whole chunks of both
+// input kinds.  hipErrorNotSupported: the caller runs poem_launch_upcat_conv3x3 + poem_launch_pool_head.
+extern "C" hipError_t poem_launch_upcat_conv3x3_pool_head(const float* a_half, int Ca, const float* b_full, int Cb, const void* wp,
+                                                          const float* scale, const float* shift, const float* head_w,
+                                                          const float* head_b, float* hmap, int views, int Cout, int J, int H, int W,
+                                                          int relu, hipStream_t s) {
+  if (Ca % 8 || Cb % 8 || Ca <= 0 || Cb <= 0 || W != 64 || H % 4 || !conv3x3_lds_ok(Cout, H, W) || !conv3x3_m16(Cout) ||
+      (Cout + 15) / 16 != 3 || J < 1 || J > 32 || !(g_row_stager & 1) || !g_pool_fused)
+    return hipErrorNotSupported;
+  const int TR = 256 / W, tplane = (TR + 2) * (W + 2), tstride = ((tplane + 15) & ~31) + 16;
+  const size_t lds16 = (size_t)2 * 8 * tstride * sizeof(float);
+  if ((size_t)(Cout * 4 * 32 + J * Cout + J) * sizeof(float) > lds16) return hipErrorNotSupported;
+  Conv3Args a{nullptr, (const float4*)wp, (const float2*)((const float*)wp + conv3x3_floats32(Cout, Ca + Cb)), scale, shift, nullptr, nullptr,
+              Ca + Cb, Cout, H, W, 1, relu, 0, 0, 0, 0, views, a_half, b_full, Ca, Cb, head_w, head_b, hmap, J};
+  hipLaunchKernelGGL((conv3x3_lds16_kernel<3, true, 64, true>), dim3((unsigned)(views * (H / TR))), dim3(512), lds16, s, a);
+  return hipGetLastError();
 }
 
 // in (views, Cin, H+2, W+2) zero-bordered; out element strides as in Conv3Args.  stride 1 or 2, H, W even,

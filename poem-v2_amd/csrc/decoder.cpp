@@ -140,9 +140,7 @@ struct DecoderRun {
 
   // F1 of block i + 1 behind stage `at` of block i's cross attentions (poem_handle_s::bps_defer)
   int defer_at() const {
-    if (!ov || !chain) return 0;
-    if (h->bps_defer >= 0) return h->bps_defer;
-    return 0;
+    return (ov && chain) ? h->bps_defer : 0;
   }
   int deferred_basis_point_side(int i, int at) {
     if (defer_at() != at || i + 1 >= c.nblocks) return POEM_OK;
@@ -308,10 +306,12 @@ struct DecoderRun {
                                                    p.tab_p[0], p.rs, B, Q, C, 3 * C, 2 * C, 2 * C, s));
       }
     } else {
-      poem_vecattn_one_query_blocks(h->va_p1);
-      HIPCHK(poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
-                                          h->R(vsb + 5), h->P(vsb + 6), h->R(vsb + 7), h->fused[i].w[5], h->R(vsb + 9),
-                                          h->P(vsb + 10), h->R(vsb + 11), p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, 1, s));
+      poem_vecattn_one_query_blocks(h->va_p1);           // (thread-local launcher switch: this handle's value for this launch only)
+      const hipError_t ve = poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
+                                                         h->R(vsb + 5), h->P(vsb + 6), h->R(vsb + 7), h->fused[i].w[5], h->R(vsb + 9),
+                                                         h->P(vsb + 10), h->R(vsb + 11), p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, 1, s);
+      poem_vecattn_one_query_blocks(0);
+      HIPCHK(ve);
     }
     if (const int rc = prof_end(prof, tables && i == 0 ? 1 : 0); rc != POEM_OK) return rc;
     if (chain) {
@@ -344,10 +344,12 @@ struct DecoderRun {
                                                    p.tab_p[1], p.rc, B, Q, C, C, 2 * C, 2 * C, s));
     } else {
       poem_vecattn_one_query_blocks(h->va_p1);
-      HIPCHK(poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
-                                          p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4), h->R(vcb + 5), h->P(vcb + 6),
-                                          h->R(vcb + 7), h->fused[i].w[6], h->R(vcb + 9), h->P(vcb + 10), h->R(vcb + 11), p.rc, B,
-                                          Q, C, C, C, C, 1, s));
+      const hipError_t ve = poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
+                                                         p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4), h->R(vcb + 5), h->P(vcb + 6),
+                                                         h->R(vcb + 7), h->fused[i].w[6], h->R(vcb + 9), h->P(vcb + 10), h->R(vcb + 11), p.rc, B,
+                                                         Q, C, C, C, C, 1, s);
+      poem_vecattn_one_query_blocks(0);
+      HIPCHK(ve);
     }
     return prof_end(prof, tables && i == 0 ? 1 : 0);
   }

@@ -151,7 +151,7 @@ struct poem_handle_s {
   bool graph_broken = false;         // a capture failed once on this handle: stay on plain launches
   hipStream_t cap_stream = nullptr;
   int stream_device = 0;             // device whose stream pool (handle.cpp) the three streams belong to
-  struct GraphEntry { std::vector<int64_t> key; hipGraphExec_t exec; uint64_t stamp; uint64_t shape; };
+  struct GraphEntry { std::vector<int64_t> key; hipGraphExec_t exec; uint64_t stamp; uint64_t shape; hipStream_t last_stream = nullptr; bool launched = false; };
   std::vector<GraphEntry> graph_cache;
   std::vector<std::vector<int64_t>> graph_seen;      // keys met once: a key is captured at its second forward
   bool graph_eager = false;                          // capture at the first forward of a key (tests / benches that want it)
@@ -182,18 +182,14 @@ struct poem_handle_s {
   hipEvent_t ev_bps[8] = {}, ev_xyz[8] = {}, ev_knn[8] = {}, ev_def[8] = {};
   // When the basis-point side (F1) of block i + 1 is issued: 0 = every block's up front, beside block 0 (large batches: the
   // matrix pipe is the limit either way); 1 / 2 / 3 = behind block i's first / second cross attention / its chain -- a small
-  // batch leaves most CUs idle there, and block 0's own cross attention no longer shares the chip with the later blocks' GEMMs;
-  // -1 = by batch size (decoder.cpp)
-  int bps_defer = -1;
-  bool gemm_xcd_map = true;  // panel GEMM: XCD-aware block map (gemm.hip PanelSegs::xcd_map); part of the graph key
+  // batch leaves most CUs idle there, and block 0's own cross attention no longer shares the chip with the later blocks' GEMMs
+  int bps_defer = 0;
   // F1 of blocks >= 1 as two launches -- the four attention images (4C columns) and the vector cross attention's (k | v) rows
   // (2C columns): 8 and 4 panels divide an XCD's 32 CUs evenly (12 do not), so both take the XCD-aware map
   bool f1_split = true;
   // one-query blocks of the full vector attention (vecattn.hip): -1 = for small batches (B * Q <= 16 x CUs: the busiest CU gets
   // 7 queries instead of 8 at B = 2; measured B = 1 / 2 / 4 -0.7 / -1.7 / -2.0 %), 0 never, 1 / 2 always (3 / 2 waves per SIMD); same bits
   int va_p1 = -1;
-  bool xattn_half = true;    // merged cross attention of a single sample on channel-tile items (attn.hip HALF); part of the graph key
-  bool gemm_kslab = true;    // K >= 512 Linears on the K-slab kernel (gemm.hip); part of the graph key
   bool overlap = true;
   // Per-view index arrays (view_offsets | view_sample | pe_index) live in handle-owned device memory and are re-uploaded
   // only when the batch's view layout changes: a pageable H2D copy blocks the host until the stream reaches it, i.e.
@@ -247,8 +243,9 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base);
 void register_taps(poem_handle_t h, const Plan& p, int B, int BN, bool sampling);
 
 // handle.cpp: a retired exec is parked, not destroyed (runtime bug, see there), and offered to the next capture of the same shape
-void poem_park_graph_exec(hipGraphExec_t e, uint64_t shape);
-hipGraphExec_t poem_reuse_graph_exec(hipGraph_t graph, uint64_t shape);      // a parked exec updated to `graph`, or nullptr
+int poem_process_switches();      // handle.cpp: the process-wide launcher switches, for the launch-graph key
+void poem_park_graph_exec(hipGraphExec_t e, uint64_t shape, int device, hipStream_t last_stream, bool launched);
+hipGraphExec_t poem_reuse_graph_exec(hipGraph_t graph, uint64_t shape, int device);      // a parked exec updated to `graph`, or nullptr
 
 // ---- launch sequence (decoder.cpp) -------------------------------------------------------------------------------------------
 int build_anchor_tables(poem_handle_t h, Plan& p, hipStream_t s, bool at_create = false);

@@ -217,7 +217,7 @@ struct HeadRun {
     //  batch's own view total: that total joins the key there)
     const std::vector<int64_t> key = {B, plan_views, fused_fe ? -1 : BN, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
                                       h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
-                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, h->gemm_xcd_map, h->f1_split, h->gemm_kslab, h->va_p1, h->xattn_half, h->group_min_views, h->group_xcd};
+                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, poem_process_switches(), h->f1_split, h->va_p1, h->group_min_views, h->group_xcd};
     poem_handle_s::GraphEntry* hit = nullptr;
     for (auto& g : h->graph_cache)
       if (g.key == key) { hit = &g; break; }
@@ -244,7 +244,7 @@ struct HeadRun {
       }
       ++h->graph_captures;
       if (ok) {
-        exec = poem_reuse_graph_exec(graph, graph_shape_of(c, key));
+        exec = poem_reuse_graph_exec(graph, graph_shape_of(c, key), h->stream_device);
         if (!exec) {
           ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
           ++h->graph_instantiations;
@@ -262,15 +262,17 @@ struct HeadRun {
         size_t lru = 0;
         for (size_t i = 1; i < h->graph_cache.size(); ++i)
           if (h->graph_cache[i].stamp < h->graph_cache[lru].stamp) lru = i;
-        poem_park_graph_exec(h->graph_cache[lru].exec, h->graph_cache[lru].shape);      // (not destroyed: handle.cpp)
+        poem_park_graph_exec(h->graph_cache[lru].exec, h->graph_cache[lru].shape, h->stream_device, h->graph_cache[lru].last_stream,
+                             h->graph_cache[lru].launched);      // (not destroyed: handle.cpp)
         h->graph_cache.erase(h->graph_cache.begin() + lru);
       }
-      h->graph_cache.push_back({key, exec, 0, graph_shape_of(c, key)});
+      h->graph_cache.push_back({key, exec, 0, graph_shape_of(c, key), nullptr, false});
       hit = &h->graph_cache.back();
     }
     hit->stamp = ++h->graph_clock;
     POEM_TRACE("graph launch exec=%p", (void*)hit->exec);
     HIPCHK(hipGraphLaunch(hit->exec, s));
+    hit->last_stream = s; hit->launched = true;
     ++h->graph_replays;
     POEM_TRACE("graph launched");
     if (c.parametric) {      // the captured tail wrote pose / shape into the workspace

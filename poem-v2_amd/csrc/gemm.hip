@@ -823,9 +823,9 @@ __global__ __launch_bounds__((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512, 2) voi
 }
 
 static int poem_num_cus() { return poem_device_cus(); }
-static int g_kslab = 1;                            // A/B switch (poem_set_option "gemm_kslab"; process-wide, scheduling only)
+static std::atomic<int> g_kslab{1};                            // A/B switch (poem_set_option "gemm_kslab"; process-wide, scheduling only)
 extern "C" void poem_gemm_kslab(int on) { g_kslab = on; }
-static int g_panel_xcd_map = 1;                    // A/B switch (poem_set_option "gemm_xcd_map"; process-wide, scheduling only)
+static std::atomic<int> g_panel_xcd_map{1};                    // A/B switch (poem_set_option "gemm_xcd_map"; process-wide, scheduling only)
 extern "C" void poem_gemm_xcd_map(int on) { g_panel_xcd_map = on; }
 
 template <int NT, int MT, bool GELU, bool SPLIT = false>

@@ -2,7 +2,14 @@
 // tables folded there (positional table, block-0 anchor tables), option switches, debug taps and the HIP-event profile.
 #include "engine.h"
 
+#include <atomic>
 thread_local int g_last_hip_error = 0;
+
+// The launcher switches that are PROCESS-wide (gemm_xcd_map | gemm_kslab << 1 | xattn_half << 2: statics of gemm.hip / attn.hip,
+// scheduling only, bit-identical results): whichever handle sets one sets it for every handle, so the launch-graph key carries the
+// process's current values, not a per-handle copy that the launches would not follow.
+static std::atomic<int> g_proc_switches{7};
+int poem_process_switches() { return g_proc_switches.load(); }
 
 // Everything of a handle that takes part in a stream capture -- the capture stream, the two side streams, the fork / join
 // events -- comes from a process-wide pool per device ("capture kit") and goes back to it at poem_destroy instead of being
@@ -24,9 +31,28 @@ struct CaptureKit {
 };
 std::mutex g_pool_mutex;
 std::map<int, std::vector<CaptureKit>> g_kit_pool;         // device id -> idle kits
-struct ParkedExec { hipGraphExec_t exec; uint64_t shape; };
+// A parked exec belongs to the DEVICE it was instantiated on (its kernel nodes, and the internal branch streams the runtime
+// gave it, live there) and may still be EXECUTING when it is parked -- an LRU-evicted exec's last hipGraphLaunch is only
+// enqueued, the forward never syncs.  `done` is recorded behind that last launch; the exec is offered for an in-place update
+// (hipGraphExecUpdate rewrites node parameters) only on its own device and only once the event has completed.
+struct ParkedExec { hipGraphExec_t exec; uint64_t shape; int device; hipEvent_t done; };
 std::vector<ParkedExec> g_parked_execs;                    // never destroyed (see above); re-used by poem_reuse_graph_exec
-int64_t g_exec_reuses = 0, g_exec_update_failures = 0;
+std::vector<hipEvent_t> g_idle_done_events;                // events of re-used execs, kept for the next parking (never destroyed either)
+int64_t g_exec_reuses = 0, g_exec_update_failures = 0, g_exec_busy_skips = 0;
+
+// (g_pool_mutex held) an event recorded on `last_stream` behind the exec's last launch; nullptr when it never ran
+hipEvent_t done_event_locked(hipStream_t last_stream, bool launched) {
+  if (!launched) return nullptr;
+  hipEvent_t ev = nullptr;
+  if (!g_idle_done_events.empty()) { ev = g_idle_done_events.back(); g_idle_done_events.pop_back(); }
+  else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipEventRecord(ev, last_stream) != hipSuccess) {       // (a destroyed caller stream: the work on it has drained)
+    (void)hipGetLastError();
+    g_idle_done_events.push_back(ev);
+    return nullptr;
+  }
+  return ev;
+}
 
 hipEvent_t** kit_event_slots(poem_handle_t h, hipEvent_t** out) {
   int n = 0;
@@ -82,29 +108,36 @@ void return_kit(poem_handle_t h) {
 
 void park_execs(poem_handle_t h) {
   std::lock_guard<std::mutex> lock(g_pool_mutex);
-  for (auto& g : h->graph_cache) g_parked_execs.push_back({g.exec, g.shape});
+  for (auto& g : h->graph_cache)
+    g_parked_execs.push_back({g.exec, g.shape, h->stream_device, done_event_locked(g.last_stream, g.launched)});
   h->graph_cache.clear();
 }
 }  // namespace
 
-void poem_park_graph_exec(hipGraphExec_t e, uint64_t shape) {
+void poem_park_graph_exec(hipGraphExec_t e, uint64_t shape, int device, hipStream_t last_stream, bool launched) {
   std::lock_guard<std::mutex> lock(g_pool_mutex);
-  g_parked_execs.push_back({e, shape});
+  g_parked_execs.push_back({e, shape, device, done_event_locked(last_stream, launched)});
 }
 
 // A parked exec of the same shape, updated in place to the freshly captured graph (kernel arguments, grids and functions of
 // every node are rewritten; earlier launches of the exec that are still in flight keep what they were launched with).  An
 // update the runtime refuses leaves the exec parked.
-hipGraphExec_t poem_reuse_graph_exec(hipGraph_t graph, uint64_t shape) {
-  ParkedExec cand{nullptr, 0};
+hipGraphExec_t poem_reuse_graph_exec(hipGraph_t graph, uint64_t shape, int device) {
+  ParkedExec cand{nullptr, 0, 0, nullptr};
   {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
-    for (size_t i = g_parked_execs.size(); i-- > 0;)
-      if (g_parked_execs[i].shape == shape) {
-        cand = g_parked_execs[i];
-        g_parked_execs.erase(g_parked_execs.begin() + i);
-        break;
+    for (size_t i = g_parked_execs.size(); i-- > 0;) {
+      ParkedExec& pe = g_parked_execs[i];
+      if (pe.shape != shape || pe.device != device) continue;
+      if (pe.done) {
+        if (hipEventQuery(pe.done) != hipSuccess) { (void)hipGetLastError(); ++g_exec_busy_skips; continue; }   // still running its last launch
+        g_idle_done_events.push_back(pe.done);
+        pe.done = nullptr;
       }
+      cand = pe;
+      g_parked_execs.erase(g_parked_execs.begin() + i);
+      break;
+    }
   }
   if (!cand.exec) return nullptr;
   hipGraphNode_t err_node = nullptr;
@@ -119,7 +152,7 @@ hipGraphExec_t poem_reuse_graph_exec(hipGraph_t graph, uint64_t shape) {
   POEM_TRACE("exec update refused e=%d res=%d", (int)e, (int)res);
   ++g_exec_update_failures;
   // shape 0 never matches a capture: an exec the runtime would not update is kept out of further attempts
-  g_parked_execs.insert(g_parked_execs.begin(), {cand.exec, 0});
+  g_parked_execs.insert(g_parked_execs.begin(), {cand.exec, 0, cand.device, nullptr});
   return nullptr;
 }
 
@@ -461,15 +494,15 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "knn_fma") h->knn_fma = value != 0;
   else if (k == "graphs") h->graphs = value != 0;
   else if (k == "graph_eager") h->graph_eager = value != 0;
-  else if (k == "gemm_xcd_map") { poem_gemm_xcd_map(value != 0); h->gemm_xcd_map = value != 0; }
+  else if (k == "gemm_xcd_map") { poem_gemm_xcd_map(value != 0); g_proc_switches.fetch_and(~1); g_proc_switches.fetch_or(value ? 1 : 0); }
   else if (k == "f1_split") h->f1_split = value != 0;
-  else if (k == "xattn_half") { poem_cross_attention_half(value != 0); h->xattn_half = value != 0; }
+  else if (k == "xattn_half") { poem_cross_attention_half(value != 0); g_proc_switches.fetch_and(~4); g_proc_switches.fetch_or(value ? 4 : 0); }
   else if (k == "va_p1") { if (value < -1 || value > 2) return POEM_E_ARG; h->va_p1 = value; }
-  else if (k == "gemm_kslab") { poem_gemm_kslab(value != 0); h->gemm_kslab = value != 0; }
+  else if (k == "gemm_kslab") { poem_gemm_kslab(value != 0); g_proc_switches.fetch_and(~2); g_proc_switches.fetch_or(value ? 2 : 0); }
   else if (k == "small_batch") h->small_batch = value;
   else if (k == "group_xcd") h->group_xcd = value != 0;
   else if (k == "group_min_views") { if (value < -1) return POEM_E_ARG; h->group_min_views = value; }
-  else if (k == "bps_defer") { if (value < -1 || value > 3) return POEM_E_ARG; h->bps_defer = value; }
+  else if (k == "bps_defer") { if (value < 0 || value > 3) return POEM_E_ARG; h->bps_defer = value; }
   else if (k == "chain_tile") { if (value < 0 || value > 3) return POEM_E_ARG; h->chain_tile = value; }
   else return POEM_E_ARG;
   return POEM_OK;
@@ -477,6 +510,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
 
 // [0] execs cached by this handle  [1] captures  [2] instantiations  [3] graph replays  [4] forwards on plain launches
 // [5] view-layout uploads  [6] execs parked in the process  [7] parked execs re-used by update  [8] updates the runtime refused
+// [9] (n >= 10) parked execs passed over because their last launch had not finished
 int poem_graph_stats(poem_handle_t h, int64_t* out, int n) {
   if (!h || !out || n < 9) return POEM_E_ARG;
   out[0] = (int64_t)h->graph_cache.size();
@@ -484,6 +518,7 @@ int poem_graph_stats(poem_handle_t h, int64_t* out, int n) {
   out[5] = h->layout_uploads;
   std::lock_guard<std::mutex> lock(g_pool_mutex);
   out[6] = (int64_t)g_parked_execs.size(); out[7] = g_exec_reuses; out[8] = g_exec_update_failures;
+  if (n >= 10) out[9] = g_exec_busy_skips;
   return POEM_OK;
 }
 

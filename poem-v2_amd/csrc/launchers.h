@@ -122,6 +122,10 @@ hipError_t poem_launch_conv3x3_down2(const float* in, const void* wp, const floa
 void poem_decode_s2_staging_wave(int on);
 void poem_decode_row_stager(int on);
 void poem_decode_pin32(int on);
+void poem_decode_pool_fused(int on);
+hipError_t poem_launch_upcat_conv3x3_pool_head(const float* a_half, int Ca, const float* b_full, int Cb, const void* wp,
+                                               const float* scale, const float* shift, const float* head_w, const float* head_b,
+                                               float* hmap, int views, int Cout, int J, int H, int W, int relu, hipStream_t s);
 hipError_t poem_launch_conv1x1_up2(const float* in, const void* wp, const float* bias, float* out, int views, int K, int C, int h,
                                    int w, hipStream_t s);
 hipError_t poem_launch_upcat_pad(const float* a, int Ca, const float* b, int Cb, float* out, int views, int H, int W,

@@ -254,11 +254,25 @@ int poem_upcat_conv3x3(const float* a_half, int ca, const float* b_full, int cb,
   return POEM_OK;
 }
 
+int poem_upcat_conv3x3_pool_head(const float* a_half, int ca, const float* b_full, int cb, const void* w_packed, const float* scale,
+                                 const float* shift, const float* head_w, const float* head_b, float* heatmaps, int views, int cout,
+                                 int j, int h, int w, int relu, void* stream) {
+  if (!a_half || !b_full || !w_packed || !scale || !shift || !head_w || !head_b || !heatmaps || views <= 0 || cout <= 0 || j <= 0 ||
+      h <= 0 || w <= 0 || ca <= 0 || cb <= 0)
+    return POEM_E_ARG;
+  const hipError_t e = poem_launch_upcat_conv3x3_pool_head(a_half, ca, b_full, cb, w_packed, scale, shift, head_w, head_b, heatmaps, views,
+                                                           cout, j, h, w, relu, (hipStream_t)stream);
+  if (e == hipErrorNotSupported) return POEM_E_UNSUPPORTED;
+  HIPCHK(e);
+  return POEM_OK;
+}
+
 int poem_set_decode_option(const char* name, int value) {
   if (!name) return POEM_E_ARG;
   if (!strcmp(name, "s2_staging_wave")) { poem_decode_s2_staging_wave(value); return POEM_OK; }
-  if (!strcmp(name, "row_stager")) { poem_decode_row_stager(value); return POEM_OK; }
+  if (!strcmp(name, "row_stager")) { if (value < 0 || value > 3) return POEM_E_ARG; poem_decode_row_stager(value); return POEM_OK; }
   if (!strcmp(name, "pin32")) { poem_decode_pin32(value); return POEM_OK; }
+  if (!strcmp(name, "pool_fused")) { poem_decode_pool_fused(value); return POEM_OK; }
   return POEM_E_ARG;
 }
 

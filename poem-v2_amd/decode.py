@@ -109,6 +109,7 @@ class FeatureDecoders:
         self.device = torch.device(device)
         self.fuse_upcat = [True, True, True]     # per uv_decode stage: poem_upcat_conv3x3 (one launch) vs upsample/concat + conv
         self.fuse_feat_in = True                 # feat_in + bilinear x2 in one launch (poem_conv1x1_upsample2)
+        self.fuse_pool_head = True               # uv_decode's last stage + max-pool + uv_out + sigmoid in one launch
         sd = state_dict
         with torch.cuda.device(self.device):
             self.feat_delayer = [_Conv3x3(sd, f"feat_delayer.{i}", self.device) for i in range(3)]
@@ -198,6 +199,16 @@ class FeatureDecoders:
             x, r = rev[0], rev[0].shape[-1]
             for i, conv in enumerate(self.uv_delayer):
                 r *= 2
+                if i == 2 and self.fuse_pool_head and self.fuse_upcat[i]:
+                    # the last stage and the read-out head in one launch: its (BN,40,64,64) output is read by nothing else
+                    hm = torch.empty(views, NUM_JOINTS, r // 2, r // 2, dtype=torch.float32, device=self.device)
+                    rc = hip.lib().poem_upcat_conv3x3_pool_head(
+                        hip.ptr(x), int(x.shape[1]), hip.ptr(rev[i + 1]), int(rev[i + 1].shape[1]), conv.packed.data_ptr(),
+                        hip.ptr(conv.scale), hip.ptr(conv.shift), hip.ptr(self.uv_out_w), hip.ptr(self.uv_out_b), hip.ptr(hm), views,
+                        conv.cout, NUM_JOINTS, r, r, 1, hip.stream())
+                    if rc != hip.POEM_E_UNSUPPORTED:
+                        hip.check(rc, "poem_upcat_conv3x3_pool_head")
+                        return hm
                 y = torch.empty(views, conv.cout, r, r, dtype=torch.float32, device=self.device)
                 if not (self.fuse_upcat[i] and conv.upcat(x, rev[i + 1], r, r, y, _plain_strides(conv.cout, r, r))):   # one launch where it pays
                     conv(upsample2_concat_pad(x, rev[i + 1], r, r, 1), r, r, 1, y, _plain_strides(conv.cout, r, r))

@@ -15,6 +15,19 @@ from .builder import HEAD, build_transformer
 from .inputs import synthetic_template
 from .weights import live_key_shapes
 
+# Epoch of the process's module TREES: bumped whenever any nn.Module registers a submodule (`head.transformer = ...`,
+# `blocks[1] = ...`, parametrize.register_parametrization, add_module).  The head caches the `_parameters` dicts of its
+# submodules (see _engine_for) and re-walks its tree only when this moved -- a replaced SUBMODULE is seen at the next forward.
+_TREE_EPOCH = [0]
+
+
+def _on_module_registration(module, name, submodule):
+    _TREE_EPOCH[0] += 1
+    return None
+
+
+torch.nn.modules.module.register_module_module_registration_hook(_on_module_registration)
+
 
 @HEAD.register_module()
 class POEM_Generalized_Head(nn.Module):
@@ -93,10 +106,18 @@ class POEM_Generalized_Head(nn.Module):
         self._engine = None
 
     def _live_weights(self):
-        sd = self.state_dict()
+        """The tensors the forward reads, by the reference's key names, as the MODULES present them (attribute access, so a
+        parametrized weight -- torch.nn.utils.parametrize -- arrives as its current value, not as `parametrizations.*.original`)."""
         shapes = live_key_shapes(self.embed_dims, self.in_channels, 799, self.transformer.layer_num,
                                  self.parametric_output)
-        return {k: sd[k].reshape(s) for k, s in shapes.items()}
+        out = {}
+        with torch.no_grad():
+            for k, s in shapes.items():
+                obj = self
+                for part in k.split("."):
+                    obj = obj[int(part)] if part.isdigit() and not hasattr(obj, part) else getattr(obj, part)
+                out[k] = obj.detach().reshape(s)
+        return out
 
     def _apply(self, fn, *a, **k):
         self._plist = None                     # .to() / .cuda() / .float(): the parameters move
@@ -107,15 +128,16 @@ class POEM_Generalized_Head(nn.Module):
         # (load_state_dict incl. assign=True, `module.weight = nn.Parameter(...)`, .to(), in-place edits).  The submodules'
         # `_parameters` dicts are cached and read directly: walking the module tree for its 199 parameters costs ~0.3 ms of
         # host time per forward -- more than enqueueing the whole step (a hipGraph replay); reading the dicts costs ~0.06 ms
-        # and, unlike a cached list of Parameter objects, sees a Parameter that was REPLACED.
+        # and, unlike a cached list of Parameter objects, sees a Parameter that was REPLACED; a replaced SUBMODULE moves
+        # _TREE_EPOCH (module-registration hook above) and the list is rebuilt.
         #   ONE ENGINE PER STREAM: an engine's workspace, layout arrays and side streams serve one forward at a time, in stream
         # order.  A caller that alternates small batches over two (or more) torch streams -- the way to fill 256 CUs with batches
         # of 2, the reference's evaluation batch -- gets one engine per stream, so consecutive forwards never share scratch
         # memory and may overlap on the GPU (bench.py small_batch_scope `two_streams`: +7 % at batch 4, nothing at batch <= 2
         # with the default four hardware queues).  Same kernels, same bits.
-        self._pcheck = getattr(self, "_pcheck", 0) + 1
-        if getattr(self, "_plist", None) is None or self._pcheck % 256 == 0:
-            self._plist = [m._parameters for m in self.modules()]      # (the module set itself: refreshed every 256 forwards)
+        if getattr(self, "_plist", None) is None or self._plist_epoch != _TREE_EPOCH[0]:
+            self._plist = [m._parameters for m in self.modules()]      # (the module set itself: re-walked when a module tree changed)
+            self._plist_epoch = _TREE_EPOCH[0]
         sig = (str(device),) + tuple((id(p), p.data_ptr(), p._version) for d in self._plist for p in d.values() if p is not None)
         if self._engine_sig != sig:
             self._engines.clear()

@@ -86,6 +86,7 @@ SIGNATURES = {
     "poem_conv1x1_upsample2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "poem_upcat_conv3x3": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i, _i, _i, _vp]),
     "poem_pool_conv1x1_sigmoid": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "poem_upcat_conv3x3_pool_head": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "poem_pa_epe": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "poem_mano_to_openpose": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "poem_rot6d_to_axis_angle": (_i, [_vp, _vp, _vp, _i, _vp]),
@@ -237,12 +238,12 @@ class Engine:
         return self.workspace, self.workspace.numel()
 
     GRAPH_STAT_NAMES = ("cached_execs", "captures", "instantiations", "replays", "plain_forwards", "layout_uploads",
-                        "parked_execs", "exec_reuses", "exec_update_refusals")
+                        "parked_execs", "exec_reuses", "exec_update_refusals", "exec_busy_skips")
 
     def graph_stats(self):
         """Counters of the launch-graph cache (include/poem_hip.h poem_graph_stats)."""
-        out = (ctypes.c_int64 * 9)()
-        check(lib().poem_graph_stats(self.handle, out, 9), "poem_graph_stats")
+        out = (ctypes.c_int64 * 10)()
+        check(lib().poem_graph_stats(self.handle, out, 10), "poem_graph_stats")
         return dict(zip(self.GRAPH_STAT_NAMES, [int(v) for v in out]))
 
     def enable_taps(self, flag=True):

@@ -250,6 +250,54 @@ def test_upcat_conv3x3_row_stager_is_bit_identical_to_the_per_float_stager(ca, c
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ca,cb,views", [(80, 40, 5), (16, 8, 2), (80, 40, 37)])
+def test_uv_decode_last_stage_with_the_read_out_head_fused_is_bit_identical(ca, cb, views):
+    """poem_upcat_conv3x3_pool_head: uv_decode's last convolution (120 -> 40 at 64 x 64) with max_pool2d(2, 2) + uv_out +
+    sigmoid in its epilogue (POEM.py:203-207) against the two launches it replaces -- the same affine / ReLU, the same maxima,
+    the 40-term contraction as the same fma chain: bit-identical heat maps; the whole decoder with the switch on and off."""
+    import poem_v2_amd as pk
+    from poem_v2_amd import hip
+    g = torch.Generator().manual_seed(3 * ca + cb + views)
+    r, cout, J = 64, 40, 21
+    a, b = torch.randn(views, ca, r // 2, r // 2, generator=g).to(DEV), torch.randn(views, cb, r, r, generator=g).to(DEV)
+    cin = ca + cb
+    sd = {"c.conv.weight": torch.randn(cout, cin, 3, 3, generator=g) / (3.0 * cin ** 0.5),
+          "c.conv.bias": 0.1 * torch.randn(cout, generator=g), "c.norm.weight": 1 + 0.2 * torch.randn(cout, generator=g),
+          "c.norm.bias": 0.1 * torch.randn(cout, generator=g), "c.norm.running_mean": 0.1 * torch.randn(cout, generator=g),
+          "c.norm.running_var": 0.5 + torch.rand(cout, generator=g)}
+    conv = pk.decode._Conv3x3(sd, "c", torch.device(DEV))
+    hw, hb = (0.3 * torch.randn(J, cout, generator=g)).to(DEV), (0.1 * torch.randn(J, generator=g)).to(DEV)
+    y = torch.empty(views, cout, r, r, device=DEV)
+    assert conv.upcat(a, b, r, r, y, pk.decode._plain_strides(cout, r, r))
+    two = torch.empty(views, J, r // 2, r // 2, device=DEV)
+    hip.check(hip.lib().poem_pool_conv1x1_sigmoid(hip.ptr(y), hip.ptr(hw), hip.ptr(hb), hip.ptr(two), views, cout, J, r, r, hip.stream()))
+    one = torch.full((views, J, r // 2, r // 2), float("nan"), device=DEV)
+    hip.check(hip.lib().poem_upcat_conv3x3_pool_head(hip.ptr(a), ca, hip.ptr(b), cb, conv.packed.data_ptr(), hip.ptr(conv.scale),
+                                                     hip.ptr(conv.shift), hip.ptr(hw), hip.ptr(hb), hip.ptr(one), views, cout, J, r, r, 1,
+                                                     hip.stream()), "poem_upcat_conv3x3_pool_head")
+    assert torch.equal(one, two) and bool(torch.isfinite(one).all())
+    ref = torch.sigmoid(torch.nn.functional.conv2d(torch.nn.functional.max_pool2d(y, 2, 2), hw[:, :, None, None], hb))
+    assert _md(one, ref) < 1e-6
+    # shapes it does not take are refused, not mangled
+    assert hip.lib().poem_upcat_conv3x3_pool_head(hip.ptr(a), ca, hip.ptr(b), cb, conv.packed.data_ptr(), hip.ptr(conv.scale),
+                                                  hip.ptr(conv.shift), hip.ptr(hw), hip.ptr(hb), hip.ptr(one), views, cout, J, 32, 32, 1,
+                                                  hip.stream()) == hip.POEM_E_UNSUPPORTED
+    if (ca, cb) == (80, 40):
+        sdd = do.seeded_decoder_state(3)
+        feats = [f.to(DEV) for f in do.synthetic_mlvl_feats(views, 3)]
+        dec = pk.decode.FeatureDecoders(sdd, DEV)
+        hm1 = dec.uv_decode(feats)
+        dec.fuse_pool_head = False
+        assert torch.equal(hm1, dec.uv_decode(feats))
+        try:
+            hip.check(hip.lib().poem_set_decode_option(b"pool_fused", 0), "poem_set_decode_option")
+            dec.fuse_pool_head = True
+            assert torch.equal(hm1, dec.uv_decode(feats))          # refused -> the two-launch form
+        finally:
+            hip.lib().poem_set_decode_option(b"pool_fused", 1)
+
+
+@pytest.mark.gpu
 def test_upsample_concat_matches_torch():
     import torch.nn.functional as F
     import poem_v2_amd as pk

@@ -135,6 +135,24 @@ def test_engine_is_rebuilt_when_a_parameter_object_is_replaced(monkeypatch):
     assert len(built) == 4 and built[-1] == 5.0
     head._engine_for("cpu")
     assert len(built) == 4
+    # a replaced SUBMODULE (round 5: seen at the very next forward, not within 256): a fresh Conv2d, a parametrization
+    import copy
+    conv = copy.deepcopy(head.input_proj)
+    with torch.no_grad():
+        conv.weight.fill_(7.0)
+    head.input_proj = conv
+    head._engine_for("cpu")
+    assert len(built) == 5 and built[-1] == 7.0
+
+    class Twice(torch.nn.Module):
+        def forward(self, w):
+            return 2.0 * w
+
+    torch.nn.utils.parametrize.register_parametrization(head.input_proj, "weight", Twice())
+    head._engine_for("cpu")
+    assert len(built) == 6 and built[-1] == 14.0
+    head._engine_for("cpu")
+    assert len(built) == 6
 
 
 # ---- C ABI ------------------------------------------------------------------------------------------------------
