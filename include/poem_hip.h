@@ -86,6 +86,16 @@ typedef struct poem_config {
   int32_t max_views;   /* largest views-per-sample the positional table is folded for */
   float radius;        /* RADIUS_SAMPLE (0.1) */
   float ln_eps;        /* BertConfig.layer_norm_eps (1e-12) */
+  /* ABI 2: the positional-encoding switches of the reference's constructor.  No release config changes them. */
+  int32_t pe_normalize;   /* POSITIONAL_ENCODING.NORMALIZE (1; lib/models/layers/petr_transformer.py:451-457) */
+  int32_t petr_embedding; /* PETR_EMBEDDING (0; lib/models/heads/ptEmb_head.py:692,865-867): position_encoder of the cameras'
+                           * frustum points is added to the positional embedding; four more weight tensors, listed last */
+  int32_t depth_num;      /* DEPTH_NUM (32); with petr_embedding: 3 * depth_num must be a multiple of 8 */
+  int32_t lid;            /* LID (0): linear-increasing depth bins (ptEmb_head.py:122-126) */
+  int32_t reserved0;
+  double depth_start, depth_end; /* DEPTH_START, DEPTH_END (0.0, 1.2) -- doubles, as the reference's Python scalars are:      */
+  double position_range[6];      /* POSITION_RANGE (xmin ymin zmin xmax ymax zmax); each is rounded to fp32 where the reference's
+                                  * tensor-scalar arithmetic rounds it */
 } poem_config_t;
 
 typedef struct poem_handle_s* poem_handle_t;
@@ -274,6 +284,15 @@ int poem_layernorm(const float* x, const float* gamma, const float* beta, float*
 /* table: (sum_{N=1..max_views} N, C, H*W) */
 int poem_pe_table(const void* adapt_w_packed, const float* adapt_b, int embed, int h, int w, int max_views,
                   float* scratch_sine, float* table, void* stream);
+/* the same with SinePositionalEncoding3D's `normalize` argument (petr_transformer.py:451-457): 0 = plain cumulative counts */
+int poem_pe_table_ex(const void* adapt_w_packed, const float* adapt_b, int embed, int h, int w, int max_views, int normalize,
+                     float* scratch_sine, float* table, void* stream);
+/* The input of position_encoder (BasePointEmbedHead.position_embeding, lib/models/heads/ptEmb_head.py:113-181;
+ * inverse_sigmoid lib/utils/transform.py:1145-1161): out (views, 3 * depth_num, feat_h, feat_w), channel 3 d + axis = the
+ * inverse sigmoid of the position_range-normalised master-frame coordinate of pixel (x, y)'s frustum point at depth d.
+ * img0, img1 = img_metas["inp_img_shape"][0], [1].  Reads cfg's feat_h, feat_w, depth_num, lid, depth_*, position_range. */
+int poem_frustum_features(const poem_config_t* cfg, const float* cam_intr, const float* cam_extr, int views, int img0, int img1,
+                          float* out, void* stream);
 /* x[v,c,p] = W[c,:] . feat[v,:,p] + b[c] + table[pe_index[v], c, p] */
 int poem_input_proj(const float* feat, const void* w_packed, const float* bias, const float* table,
                     const int32_t* pe_index, float* x, int views, int in_channels, int embed, int hw, void* stream);

@@ -38,6 +38,13 @@ class PathConfig:
     center_idx: int = 9       # TRANSFORMER_CENTER_IDX
     ln_eps: float = 1e-12     # BertConfig.layer_norm_eps default
     knn_fma: bool = False     # neighbour distances with the fma contraction of pytorch3d's CUDA kernel (see knn_distances)
+    pe_normalize: bool = True     # POSITIONAL_ENCODING.NORMALIZE (every release config: true)
+    petr: bool = False            # PETR_EMBEDDING (no release config sets it; ptEmb_head.py:692,869-871)
+    depth_num: int = 32           # DEPTH_NUM, POSITION_RANGE, LID, DEPTH_START, DEPTH_END: the camera-frustum grid of the
+    position_range: tuple = (-0.6, -0.6, 0.0, 0.6, 0.6, 1.2)      # PETR embedding (ptEmb_head.py:65-70)
+    lid: bool = False
+    depth_start: float = 0.0
+    depth_end: float = 1.2
 
 
 def linear(x, w, b=None):
@@ -47,7 +54,7 @@ def linear(x, w, b=None):
 # ----------------------------------------------------------------------------------------------------
 # positional encoding  (lib/models/layers/petr_transformer.py:434-469, ptEmb_head.py:853-860)
 # ----------------------------------------------------------------------------------------------------
-def sine_pe_3d(n_views, H, W, num_feats, temperature=10000.0, scale=2 * math.pi, eps=1e-6):
+def sine_pe_3d(n_views, H, W, num_feats, temperature=10000.0, scale=2 * math.pi, eps=1e-6, normalize=True):
     """SinePositionalEncoding3D on an all-valid mask of shape (1,N,H,W) -> (N, 3*num_feats, H, W).
 
     Per axis the num_feats channels are [sin(even dims) || cos(odd dims)] *concatenated* (the
@@ -56,9 +63,10 @@ def sine_pe_3d(n_views, H, W, num_feats, temperature=10000.0, scale=2 * math.pi,
     n_e = ones.cumsum(1)
     y_e = ones.cumsum(2)
     x_e = ones.cumsum(3)
-    n_e = n_e / (n_e[:, -1:] + eps) * scale
-    y_e = y_e / (y_e[:, :, -1:] + eps) * scale
-    x_e = x_e / (x_e[:, :, :, -1:] + eps) * scale
+    if normalize:                                        # petr_transformer.py:451-457 (offset 0)
+        n_e = n_e / (n_e[:, -1:] + eps) * scale
+        y_e = y_e / (y_e[:, :, -1:] + eps) * scale
+        x_e = x_e / (x_e[:, :, :, -1:] + eps) * scale
     dim_t = torch.arange(num_feats, dtype=torch.float32)
     dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_feats)
 
@@ -70,10 +78,52 @@ def sine_pe_3d(n_views, H, W, num_feats, temperature=10000.0, scale=2 * math.pi,
     return pos[0]
 
 
-def positional_table(w, n_views, H, W, embed):
+def positional_table(w, n_views, H, W, embed, normalize=True):
     """adapt_pos3d(sine PE) for a sample with n_views views -> (N, C, H, W) (ptEmb_head.py:857-858)."""
-    pe = sine_pe_3d(n_views, H, W, embed // 2).to(w["adapt_pos3d.weight"].device)
+    pe = sine_pe_3d(n_views, H, W, embed // 2, normalize=normalize).to(w["adapt_pos3d.weight"].device)
     return F.conv2d(pe, w["adapt_pos3d.weight"], w["adapt_pos3d.bias"])
+
+
+def frustum_features(cfg, cam_intr, cam_extr, H, W, inp_img_shape):
+    """The input of ``position_encoder`` (BasePointEmbedHead.position_embeding, ptEmb_head.py:113-181): the points of every
+    view's camera frustum -- feature-map pixel centres (u, v) x ``depth_num`` depths -- lifted to camera space with the
+    intrinsics, moved to the shared (master) frame with the extrinsics, normalised by ``position_range`` and passed through
+    ``inverse_sigmoid`` (lib/utils/transform.py:1145-1161) -> (BN, 3 * depth_num, H, W), channel = 3 * d + axis."""
+    inp_h, inp_w = inp_img_shape                              # :115 (the names are swapped against forward()'s, :831)
+    BN, D = cam_intr.shape[0], cfg.depth_num
+    coords_h = torch.arange(H).float() * inp_h / H            # :118
+    coords_w = torch.arange(W).float() * inp_w / W            # :119
+    index = torch.arange(0, D, 1).float()
+    if cfg.lid:                                               # :122-126
+        bin_size = (cfg.depth_end - cfg.depth_start) / (D * (1 + D))
+        coords_d = cfg.depth_start + bin_size * index * (index + 1)
+    else:                                                     # :127-130
+        bin_size = (cfg.depth_end - cfg.depth_start) / D
+        coords_d = cfg.depth_start + bin_size * index
+    u = coords_w.view(1, W, 1, 1)                             # coords[..., 0] of the (W, H, D, 3) mesh grid, :135
+    v = coords_h.view(1, 1, H, 1)
+    d = coords_d.view(1, 1, 1, D)
+    fx, fy = cam_intr[:, 0, 0].view(BN, 1, 1, 1), cam_intr[:, 1, 1].view(BN, 1, 1, 1)
+    cx, cy = cam_intr[:, 0, 2].view(BN, 1, 1, 1), cam_intr[:, 1, 2].view(BN, 1, 1, 1)
+    x = (u - cx) / fx * d                                     # :153-154
+    y = (v - cy) / fy * d
+    z = d.expand(BN, W, H, D)
+    cam = torch.stack([x.expand(BN, W, H, D), y.expand(BN, W, H, D), z, torch.ones(BN, W, H, D)], dim=-1)    # :161
+    world = torch.matmul(cam_extr.view(BN, 1, 1, 1, 4, 4), cam.unsqueeze(-1)).squeeze(-1)[..., :3]           # :162-164
+    pr = cfg.position_range
+    world = torch.stack([(world[..., c] - pr[c]) / (pr[c + 3] - pr[c]) for c in range(3)], dim=-1)           # :170-175
+    feat = world.permute(0, 3, 4, 2, 1).contiguous().view(BN, 3 * D, H, W)                                   # :179
+    eps = 1e-5                                                # inverse_sigmoid
+    feat = feat.clamp(min=0, max=1)
+    return torch.log(feat.clamp(min=eps) / (1 - feat).clamp(min=eps))
+
+
+def petr_position_embedding(w, cfg, cam_intr, cam_extr, H, W, inp_img_shape):
+    """coords_position_embeding of position_embeding (ptEmb_head.py:182): position_encoder = Conv1x1 -> ReLU -> Conv1x1
+    (:101-105) on the frustum features -> (BN, C, H, W)."""
+    f = frustum_features(cfg, cam_intr, cam_extr, H, W, inp_img_shape)
+    h = F.relu(F.conv2d(f, w["position_encoder.0.weight"], w["position_encoder.0.bias"]))
+    return F.conv2d(h, w["position_encoder.2.weight"], w["position_encoder.2.bias"])
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -377,7 +427,9 @@ def head_forward(w, cfg, consts, mlvl_feat, cam_intr, cam_extr, cam_view_num, re
     H, W = mlvl_feat.shape[-2:]
     inp_w, inp_h = inp_img_shape   # the reference's (swapped) naming, ptEmb_head.py:831
     x = F.conv2d(mlvl_feat, w["input_proj.weight"], w["input_proj.bias"])                      # :835
-    pe = torch.cat([positional_table(w, n, H, W, C) for n in views], dim=0)                      # :853-860
+    pe = torch.cat([positional_table(w, n, H, W, C, cfg.pe_normalize) for n in views], dim=0)    # :853-860
+    if cfg.petr:                                                                                 # :865-867
+        pe = pe + petr_position_embedding(w, cfg, cam_intr, cam_extr, H, W, inp_img_shape)
     x = x + pe                                                                                   # :870
     centre = reference_joints[:, 9, :]                                                           # :873 (always joint 9)
     bps_world = consts["bps"][None] + centre[:, None, :]                                         # :874,790-809

@@ -64,6 +64,8 @@ enum {  // per-block slots
   B_FLAT_W = 62, B_FLAT_B, B_MANO_W, B_MANO_B, B_COUNT_PARAM = 66
 };
 
+// first of the four PETR tensors (position_encoder.0.weight, .0.bias, .2.weight, .2.bias), behind every block's slots
+static inline int petr_slot(const poem_config_t& c) { return T_HEAD_COUNT + c.nblocks * (c.parametric ? B_COUNT_PARAM : B_COUNT); }
 static inline size_t pe_views(int max_views) { return (size_t)max_views * (max_views + 1) / 2; }   // view slots of the folded positional table
 std::vector<TensorSpec> tensor_table(const poem_config_t& c);      // handle.cpp
 int check_config(const poem_config_t* c);
@@ -223,6 +225,7 @@ struct Plan {
   // sampling stage
   float *x, *uv, *g, *h1, *h2, *mm, *mh, *y, *bps_feat, *centre, *pt_xyz, *xyz[9];
   float *xt, *ptab, *q1;   // fused sampling: channel-last planes, projection table, residual rows
+  float *petr_f, *petr_h, *petr_tab;   // PETR_EMBEDDING: frustum features (BN, 3D, HW), hidden (BN, 2C, HW), per-view table (BN, C, HW)
   // decoder (per call scratch)
   float *feats0, *qp, *ctx, *att, *h_attn, *y3, *rs, *qc, *rc, *y4, *ffo;
   // basis-point side, one set per block (produced ahead of time on the side stream):

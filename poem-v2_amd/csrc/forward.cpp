@@ -119,7 +119,20 @@ struct HeadRun {
     prof_slot = h->prof_used;
     if (prof_fe) { HIPCHK(hipEventRecord(h->prof_ev[2 * prof_slot], s)); h->prof_kind[h->prof_used++] = POEM_PROF_SAMPLING; }
     fused_fe = h->fused_sampling && h->precision == POEM_PRECISION_FP32 && poem_sample_merge_supported(C, S, HW) != 0;
-    HIPCHK(poem_launch_conv1x1(mlvl_feat, h->P(T_INPROJ_W), h->R(T_INPROJ_B), h->pe_table, p.pe_index,
+    const float* table = h->pe_table;
+    const int32_t* table_index = p.pe_index;
+    if (c.petr_embedding) {
+      // PETR_EMBEDDING (ptEmb_head.py:865-867): posi_embed = adapt_pos3d(sine) + position_encoder(frustum features of the
+      // batch's cameras) -- a per-VIEW table built here from the caller's cameras; input_proj then adds it as it adds the folded one
+      const int ps = petr_slot(c), K0 = 3 * c.depth_num;
+      HIPCHK(poem_launch_frustum_features(cam_intr, cam_extr, p.petr_f, BN, c.feat_h, c.feat_w, c.depth_num, c.lid != 0, c.depth_start,
+                                          c.depth_end, c.position_range, img_w, img_h, s));      // (img_w, img_h) = inp_img_shape[0], [1]
+      HIPCHK(poem_launch_conv1x1_ex(p.petr_f, h->P(ps), h->R(ps + 1), nullptr, nullptr, p.petr_h, nullptr, BN, K0, 2 * C, HW, 1, s));
+      HIPCHK(poem_launch_conv1x1_ex(p.petr_h, h->P(ps + 2), h->R(ps + 3), h->pe_table, p.pe_index, p.petr_tab, nullptr, BN, 2 * C, C, HW, 0, s));
+      table = p.petr_tab;
+      table_index = nullptr;      // row v of the table is view v's
+    }
+    HIPCHK(poem_launch_conv1x1(mlvl_feat, h->P(T_INPROJ_W), h->R(T_INPROJ_B), table, table_index,
                                (fused_fe && !h->taps) ? nullptr : p.x, fused_fe ? p.xt : nullptr, BN, c.in_channels, C, HW, s));
     if (fused_fe && (h->small_batch & 1)) {      // coordinates, inverted extrinsics and the projection table in one launch (merge.hip)
       HIPCHK(poem_launch_input_tables(h->bps, reference_joints, h->tmpl, p.view_sample, cam_intr, cam_extr, p.ptab, p.ptab + (size_t)plan_views * S * 4, p.centre, p.pt_xyz,

@@ -192,6 +192,10 @@ std::vector<TensorSpec> tensor_table(const poem_config_t& c) {
       lin(106, C, false);
     }
   }
+  if (c.petr_embedding) {      // position_encoder.0 / .2 (ptEmb_head.py:101-105), listed last: petr_slot()
+    lin(2 * C, 3 * c.depth_num, true);
+    lin(C, 2 * C, true);
+  }
   return t;
 }
 
@@ -207,13 +211,19 @@ int check_config(const poem_config_t* c) {
   if (c->nsample > 4096 || c->nquery > 4096 || c->nquery < 33) return POEM_E_UNSUPPORTED;
   if ((c->feat_h * c->feat_w) % 32) return POEM_E_UNSUPPORTED;
   if (c->max_views < 1 || c->max_views > 64 || c->nblocks < 1) return POEM_E_ARG;
+  if (c->petr_embedding) {
+    if (c->depth_num < 8 || c->depth_num > 1024 || (3 * c->depth_num) % 8) return POEM_E_UNSUPPORTED;      // 8-deep weight fragments
+    if (!(c->depth_end > c->depth_start)) return POEM_E_ARG;
+    for (int k = 0; k < 3; ++k)
+      if (!(c->position_range[k + 3] > c->position_range[k])) return POEM_E_ARG;
+  }
   return POEM_OK;
 }
 
 // ---- workspace plan -------------------------------------------------------------------------------------------------
 extern "C" {
 
-int poem_abi_version(void) { return 1; }
+int poem_abi_version(void) { return 2; }
 int poem_last_hip_error(void) { return g_last_hip_error; }
 const char* poem_error_string(int code) {
   switch (code) {
@@ -422,8 +432,8 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
   h->pe_table = (float*)cur;
   cur += align_up(pe_views(cfg->max_views) * C * hw * 4, 256);
   float* sine = (float*)cur;
-  rc = poem_pe_table(h->P(T_ADAPT_W), h->R(T_ADAPT_B), C, cfg->feat_h, cfg->feat_w, cfg->max_views, sine, h->pe_table,
-                     stream);
+  rc = poem_pe_table_ex(h->P(T_ADAPT_W), h->R(T_ADAPT_B), C, cfg->feat_h, cfg->feat_w, cfg->max_views, cfg->pe_normalize != 0, sine,
+                        h->pe_table, stream);
   if (rc != POEM_OK) { poem_destroy(h); return rc; }
   {
     if (!take_kit(h)) { poem_destroy(h); return POEM_E_LAUNCH; }

@@ -18,7 +18,12 @@ hipError_t poem_launch_layernorm(const float* x, const float* g, const float* b,
                                  float eps, hipStream_t s);
 hipError_t poem_launch_narrow_linear(const float* x, int ldx, const float* w, const float* b, const float* base,
                                      float* out, int rows, int K, int N, hipStream_t s);
-hipError_t poem_launch_sine_pe(float* out, int F, int H, int W, int max_views, hipStream_t s);
+hipError_t poem_launch_sine_pe(float* out, int F, int H, int W, int max_views, int normalize, hipStream_t s);
+hipError_t poem_launch_frustum_features(const float* intr, const float* extr, float* out, int views, int H, int W, int D, int lid,
+                                        double depth_start, double depth_end, const double* position_range, int img0, int img1,
+                                        hipStream_t s);
+hipError_t poem_launch_conv1x1_ex(const float* feat, const void* Wp, const float* bias, const float* table, const int* pe_index,
+                                  float* x, float* xt, int views, int K, int C, int hw, int relu, hipStream_t s);
 int poem_sample_merge_supported(int C, int S, int hw);
 hipError_t poem_launch_project_table(const float* bps, const float* centre, const int* view_sample, const float* intr,
                                      const float* inv_extr, void* tabw, void* tabo, float* uv, int views, int C, int fh, int fw, int S,

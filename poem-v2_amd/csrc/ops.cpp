@@ -43,13 +43,26 @@ int poem_layernorm(const float* x, const float* gamma, const float* beta, float*
   return POEM_OK;
 }
 
-int poem_pe_table(const void* adapt_w_packed, const float* adapt_b, int embed, int fh, int fw, int max_views,
-                  float* scratch_sine, float* table, void* stream) {
+int poem_pe_table_ex(const void* adapt_w_packed, const float* adapt_b, int embed, int fh, int fw, int max_views, int normalize,
+                     float* scratch_sine, float* table, void* stream) {
   if (!adapt_w_packed || !adapt_b || !scratch_sine || !table || embed % 2 || (fh * fw) % 32) return POEM_E_ARG;
   hipStream_t s = (hipStream_t)stream;
-  HIPCHK(poem_launch_sine_pe(scratch_sine, embed / 2, fh, fw, max_views, s));
+  HIPCHK(poem_launch_sine_pe(scratch_sine, embed / 2, fh, fw, max_views, normalize != 0, s));
   HIPCHK(poem_launch_conv1x1(scratch_sine, adapt_w_packed, adapt_b, nullptr, nullptr, table, nullptr, (int)pe_views(max_views),
                              3 * embed / 2, embed, fh * fw, s));
+  return POEM_OK;
+}
+
+int poem_pe_table(const void* adapt_w_packed, const float* adapt_b, int embed, int fh, int fw, int max_views,
+                  float* scratch_sine, float* table, void* stream) {
+  return poem_pe_table_ex(adapt_w_packed, adapt_b, embed, fh, fw, max_views, 1, scratch_sine, table, stream);
+}
+
+int poem_frustum_features(const poem_config_t* cfg, const float* cam_intr, const float* cam_extr, int views, int img0, int img1,
+                          float* out, void* stream) {
+  if (!cfg || !cam_intr || !cam_extr || !out || views <= 0 || cfg->depth_num <= 0 || cfg->feat_h <= 0 || cfg->feat_w <= 0) return POEM_E_ARG;
+  HIPCHK(poem_launch_frustum_features(cam_intr, cam_extr, out, views, cfg->feat_h, cfg->feat_w, cfg->depth_num, cfg->lid != 0,
+                                      cfg->depth_start, cfg->depth_end, cfg->position_range, img0, img1, (hipStream_t)stream));
   return POEM_OK;
 }
 

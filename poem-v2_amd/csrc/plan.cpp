@@ -71,6 +71,11 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
     p.tab_g[k] = a.take<float>(poem_vector_attention_table_floats((int)Q, (int)C));
     p.tab_p[k] = a.take<float>(poem_vector_attention_table_floats((int)Q, (int)C));
   }
+  if (c.petr_embedding) {
+    p.petr_f = a.take<float>((size_t)BN * 3 * c.depth_num * HW);
+    p.petr_h = a.take<float>((size_t)BN * 2 * C * HW);
+    p.petr_tab = a.take<float>((size_t)BN * C * HW);
+  }
   p.bytes = align_up(a.off, 256);
   return p;
 }

@@ -6,7 +6,8 @@
 // Sine positional encoding (petr_transformer.py:434-469 upstream) for every view count N = 1..max_views:
 // sine[(pv, ch, y, x)], pv enumerates (N, n) pairs in order N=1:(0) N=2:(0,1) ..., ch = [p(e_n) | p(e_y) | p(e_x)],
 // p(e) = [sin(e/d_0), sin(e/d_2), ... | cos(e/d_1), cos(e/d_3), ...] (two concatenated halves of F/2).
-__global__ void sine_pe_kernel(float* __restrict__ out, int F, int H, int W, int max_views) {
+// normalize = 0 (POSITIONAL_ENCODING.NORMALIZE false, :451 upstream): the embeddings are the plain cumulative counts n + 1, y + 1, x + 1.
+__global__ void sine_pe_kernel(float* __restrict__ out, int F, int H, int W, int max_views, int normalize) {
   const int hw = H * W;
   const long total = (long)(max_views * (max_views + 1) / 2) * 3 * F * hw;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -22,7 +23,8 @@ __global__ void sine_pe_kernel(float* __restrict__ out, int F, int H, int W, int
   const float scale = 6.283185307179586f;  // 2*pi as fp32
   const float eps = 1e-6f;
   float e;
-  if (axis == 0) e = (float)(n + 1) / ((float)N + eps) * scale;
+  if (!normalize) e = (float)((axis == 0 ? n : axis == 1 ? y : x) + 1);
+  else if (axis == 0) e = (float)(n + 1) / ((float)N + eps) * scale;
   else if (axis == 1) e = (float)(y + 1) / ((float)H + eps) * scale;
   else e = (float)(x + 1) / ((float)W + eps) * scale;
   const bool is_cos = f >= F / 2;
@@ -33,22 +35,22 @@ __global__ void sine_pe_kernel(float* __restrict__ out, int F, int H, int W, int
   out[i] = is_cos ? cosf(v) : sinf(v);
 }
 
-extern "C" hipError_t poem_launch_sine_pe(float* out, int F, int H, int W, int max_views, hipStream_t s) {
+extern "C" hipError_t poem_launch_sine_pe(float* out, int F, int H, int W, int max_views, int normalize, hipStream_t s) {
   const long total = (long)(max_views * (max_views + 1) / 2) * 3 * F * H * W;
-  hipLaunchKernelGGL(sine_pe_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, F, H, W, max_views);
+  hipLaunchKernelGGL(sine_pe_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, F, H, W, max_views, normalize);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // 1x1 convolution as an MFMA GEMM with the weights as the A operand (packed fragment order) and the feature planes
 // as the B operand read straight from global (lanes along the pixel axis -> coalesced):
-//   x[v, c, p] = sum_k W[c, k] * feat[v, k, p] + bias[c] (+ table[pe_index[v], c, p])
+//   x[v, c, p] = act(sum_k W[c, k] * feat[v, k, p] + bias[c] (+ table[pe_index ? pe_index[v] : v, c, p])),  act = ReLU or none
 // One wave: 32 channels x (32*PT) pixels of one view.
 template <int PT>
 __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ feat, const float4* __restrict__ Wp,
                                                       const float* __restrict__ bias, const float* __restrict__ table,
                                                       const int* __restrict__ pe_index, float* __restrict__ x,
-                                                      float* __restrict__ xt, int views, int K, int C, int hw) {
+                                                      float* __restrict__ xt, int views, int K, int C, int hw, int relu) {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int pgroups = hw / (32 * PT);
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
       for (int pt = 0; pt < PT; ++pt) acc[pt] = mfma32((&a.x)[t], row[pt * 32], acc[pt]);
     }
   }
-  const float* tab = table ? table + (size_t)pe_index[v] * C * hw : nullptr;
+  const float* tab = table ? table + (size_t)(pe_index ? pe_index[v] : v) * C * hw : nullptr;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = ct * 32 + mfma_row(i, h);
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
       const int p = pg * 32 * PT + pt * 32 + r;
       float val = acc[pt][i] + bv;
       if (tab) val += tab[(size_t)c * hw + p];
+      if (relu) val = fmaxf(val, 0.f);
       acc[pt][i] = val;
       if (x) x[((size_t)v * C + c) * hw + p] = val;
     }
@@ -109,7 +112,7 @@ template <int NW, int PT>
 __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __restrict__ feat, const float4* __restrict__ Wp,
                                                              const float* __restrict__ bias, const float* __restrict__ table,
                                                              const int* __restrict__ pe_index, float* __restrict__ x,
-                                                             float* __restrict__ xt, int views, int K, int C, int hw) {
+                                                             float* __restrict__ xt, int views, int K, int C, int hw, int relu) {
   extern __shared__ __attribute__((aligned(16))) float ftile[];    // K * 32 * PT
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
   constexpr int PX = 32 * PT, F4 = PX / 4;      // pixels per block, float4 per staged feature row
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __res
     }
   }
   __syncthreads();
-  const float* tab = table ? table + (size_t)pe_index[v] * C * hw : nullptr;
+  const float* tab = table ? table + (size_t)(pe_index ? pe_index[v] : v) * C * hw : nullptr;
   const float* fb = ftile + (4 * h) * PX + r;
   for (int ct = wv; ct < ctiles; ct += NW) {
     const float4* wp = Wp + (size_t)ct * KC * 64 + lane;
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __res
         const int p = pg * PX + pt * 32 + r;
         float val = acc[pt][i] + bv;
         if (tab) val += tab[(size_t)c * hw + p];
+        if (relu) val = fmaxf(val, 0.f);
         acc[pt][i] = val;
         if (x) x[((size_t)v * C + c) * hw + p] = val;
       }
@@ -189,16 +193,16 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __res
   }
 }
 
-extern "C" hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, const float* bias, const float* table,
-                                          const int* pe_index, float* x, float* xt, int views, int K, int C, int hw,
-                                          hipStream_t s) {
+extern "C" hipError_t poem_launch_conv1x1_ex(const float* feat, const void* Wp, const float* bias, const float* table,
+                                             const int* pe_index, float* x, float* xt, int views, int K, int C, int hw,
+                                             int relu, hipStream_t s) {
   const int ctiles = (C + 31) / 32;
   if (hw % 128 == 0 && C % 32 == 0 && K % 8 == 0 && (size_t)K * 512 <= 96 * 1024 && ((uintptr_t)feat & 15) == 0) {
     const int nw = ctiles >= 8 ? 8 : 4;
     if (views * (hw / 128) * 2 <= poem_device_cus()) {      // few views: 32-pixel blocks (same fma chain per output element)
       auto kern = nw == 8 ? conv1x1_lds_kernel<8, 1> : conv1x1_lds_kernel<4, 1>;
       hipLaunchKernelGGL(kern, dim3((unsigned)(views * (hw / 32))), dim3(nw * 64), (size_t)K * 128, s, feat, (const float4*)Wp, bias, table,
-                         pe_index, x, xt, views, K, C, hw);
+                         pe_index, x, xt, views, K, C, hw, relu);
       return hipGetLastError();
     }
     const size_t lds = (size_t)K * 512;
@@ -206,18 +210,77 @@ extern "C" hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, con
     static std::atomic<unsigned long long> optin[2];
     if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), 96 * 1024, optin[nw == 8]); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)(views * (hw / 128))), dim3(nw * 64), lds, s, feat, (const float4*)Wp, bias, table,
-                       pe_index, x, xt, views, K, C, hw);
+                       pe_index, x, xt, views, K, C, hw, relu);
     return hipGetLastError();
   }
   if (hw % 128 == 0) {
     const long waves = (long)views * ctiles * (hw / 128);
     hipLaunchKernelGGL((conv1x1_kernel<4>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, feat, (const float4*)Wp,
-                       bias, table, pe_index, x, xt, views, K, C, hw);
+                       bias, table, pe_index, x, xt, views, K, C, hw, relu);
   } else {
     const long waves = (long)views * ctiles * (hw / 32);
     hipLaunchKernelGGL((conv1x1_kernel<1>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, feat, (const float4*)Wp,
-                       bias, table, pe_index, x, xt, views, K, C, hw);
+                       bias, table, pe_index, x, xt, views, K, C, hw, relu);
   }
+  return hipGetLastError();
+}
+
+extern "C" hipError_t poem_launch_conv1x1(const float* feat, const void* Wp, const float* bias, const float* table,
+                                          const int* pe_index, float* x, float* xt, int views, int K, int C, int hw,
+                                          hipStream_t s) {
+  return poem_launch_conv1x1_ex(feat, Wp, bias, table, pe_index, x, xt, views, K, C, hw, 0, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PETR position embedding, its input (BasePointEmbedHead.position_embeding, ptEmb_head.py:113-181 upstream; live when
+// PETR_EMBEDDING is set): the frustum of every view -- feature-map pixel (x, y) at image coordinates (x * img1 / W,
+// y * img0 / H), D depths -- lifted with the view's intrinsics, moved to the master frame with its extrinsics (camera ->
+// master, NOT inverted), normalised by position_range and passed through inverse_sigmoid (transform.py:1145-1161):
+//   out[v, 3 d + axis, y, x].  One thread per (view, pixel); the D depths are a loop (3 D stores, coalesced along x).
+struct FrustumArgs {
+  const float* intr;      // (views, 3, 3)
+  const float* extr;      // (views, 4, 4)
+  float* out;             // (views, 3 D, H, W)
+  int views, H, W, D, lid;
+  float img0, img1;       // inp_img_shape[0], [1] -- position_embeding unpacks them as (h, w), forward() as (w, h): followed as written
+  float depth_start, bin_size;      // coords_d = depth_start + bin_size * i  (LID: bin_size * i * (i + 1)); fp32 roundings of the doubles
+  float lo[3], span[3];   // (float)position_range[c], (float)(position_range[c + 3] - position_range[c])
+};
+
+__global__ void frustum_features_kernel(FrustumArgs A) {
+  const int hw = A.H * A.W;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)A.views * hw) return;
+  const int v = (int)(i / hw), p = (int)(i % hw), y = p / A.W, x = p % A.W;
+  const float* K = A.intr + (size_t)v * 9;
+  const float* E = A.extr + (size_t)v * 16;
+  const float u = (float)x * A.img1 / (float)A.W, w = (float)y * A.img0 / (float)A.H;      // :118-119
+  const float cu = (u - K[2]) / K[0], cv = (w - K[5]) / K[4];                             // :153
+  float* o = A.out + (size_t)v * 3 * A.D * hw + p;
+  for (int d = 0; d < A.D; ++d) {
+    const float fi = (float)d;
+    const float dep = A.lid ? A.depth_start + A.bin_size * fi * (fi + 1.0f) : A.depth_start + A.bin_size * fi;   // :122-130
+    const float X = cu * dep, Y = cv * dep;                                                // :154
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* r = E + 4 * c;
+      const float wc = fmaf(r[2], dep, fmaf(r[1], Y, r[0] * X)) + r[3];                   // :164 (row c of extr . [X Y Z 1])
+      float t = (wc - A.lo[c]) / A.span[c];                                                // :170-175
+      t = fminf(fmaxf(t, 0.f), 1.f);                                                       // inverse_sigmoid, eps 1e-5
+      o[(size_t)(3 * d + c) * hw] = logf(fmaxf(t, 1e-5f) / fmaxf(1.0f - t, 1e-5f));
+    }
+  }
+}
+
+extern "C" hipError_t poem_launch_frustum_features(const float* intr, const float* extr, float* out, int views, int H, int W, int D,
+                                                   int lid, double depth_start, double depth_end, const double* position_range,
+                                                   int img0, int img1, hipStream_t s) {
+  FrustumArgs a{intr, extr, out, views, H, W, D, lid, (float)img0, (float)img1, (float)depth_start, 0.f, {}, {}};
+  // the Python scalars of the reference are doubles; a tensor-scalar operation rounds the scalar to fp32 first
+  a.bin_size = (float)(lid ? (depth_end - depth_start) / ((double)D * (1 + D)) : (depth_end - depth_start) / (double)D);
+  for (int c = 0; c < 3; ++c) { a.lo[c] = (float)position_range[c]; a.span[c] = (float)(position_range[c + 3] - position_range[c]); }
+  const long total = (long)views * H * W;
+  hipLaunchKernelGGL(frustum_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

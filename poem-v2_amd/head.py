@@ -50,17 +50,25 @@ class POEM_Generalized_Head(nn.Module):
         self.num_preds = cfg.NUM_PREDS
         self.center_shift = cfg.get("CENTER_SHIFT", False)
         assert self.query_type == "KPT"                                  # ptEmb_head.py:721
-        if self.PETR_embedding:
-            raise NotImplementedError("PETR_EMBEDDING=True is not used by any release config and is not built")
-        if not self.cfg_position_encoding.get("NORMALIZE", True):
-            raise NotImplementedError("POSITIONAL_ENCODING.NORMALIZE=False is not used by any release config and is not built "
-                                      "(the positional table is folded with normalize=True, scale 2*pi, temperature 1e4)")
+        # ptEmb_head.py:65-70: the camera-frustum grid of the PETR embedding (read unconditionally upstream; used when PETR_EMBEDDING)
+        self.depth_num = int(cfg.get("DEPTH_NUM", 32))
+        self.position_range = [float(v) for v in cfg.get("POSITION_RANGE", [-0.6, -0.6, 0.0, 0.6, 0.6, 1.2])]
+        self.LID = bool(cfg.get("LID", False))
+        self.depth_start = float(cfg.get("DEPTH_START", 0.0))
+        self.depth_end = float(cfg.get("DEPTH_END", 1.2))
+        self.pe_normalize = bool(self.cfg_position_encoding.get("NORMALIZE", True))
+        if self.PETR_embedding and (3 * self.depth_num) % 8:
+            raise ValueError("PETR_EMBEDDING: DEPTH_NUM must be a multiple of 8 (the 3 * DEPTH_NUM input channels of "
+                             "position_encoder feed 8-deep matrix-core fragments)")
         if self.cfg_position_encoding.NUM_FEATS * 2 != self.embed_dims:
             raise ValueError("POSITIONAL_ENCODING.NUM_FEATS must be EMBED_DIMS / 2")
         C = self.embed_dims
         # parameter containers with the reference's names (ptEmb_head.py:94,101,701-707,729)
         self.input_proj = nn.Conv2d(self.in_channels, C, kernel_size=1)
         self.adapt_pos3d = nn.Conv2d(C * 3 // 2, C, kernel_size=1)
+        if self.PETR_embedding:                # :101-105 upstream (always built there; live only with PETR_EMBEDDING)
+            self.position_encoder = nn.Sequential(nn.Conv2d(3 * self.depth_num, C * 2, kernel_size=1), nn.ReLU(),
+                                                  nn.Conv2d(C * 2, C, kernel_size=1))
         self.merge_net_feature = nn.ModuleList([
             nn.Sequential(nn.Linear(C, C), nn.ReLU(), nn.Linear(C, C // 2)),
             nn.Sequential(nn.Linear(C // 2, C // 2), nn.ReLU(), nn.Linear(C // 2, C))])
@@ -94,7 +102,8 @@ class POEM_Generalized_Head(nn.Module):
         """Load a reference checkpoint (full model or head-only); dead tensors are ignored."""
         from .weights import split_state_dict
         live, ignored = split_state_dict(sd, self.embed_dims, in_channels=self.in_channels,
-                                         nblocks=self.transformer.layer_num, parametric=self.parametric_output)
+                                         nblocks=self.transformer.layer_num, parametric=self.parametric_output,
+                                         petr=self.PETR_embedding, depth_num=self.depth_num)
         missing, unexpected = self.load_state_dict(live, strict=False)
         assert not unexpected, unexpected
         self._drop_engines()
@@ -109,7 +118,7 @@ class POEM_Generalized_Head(nn.Module):
         """The tensors the forward reads, by the reference's key names, as the MODULES present them (attribute access, so a
         parametrized weight -- torch.nn.utils.parametrize -- arrives as its current value, not as `parametrizations.*.original`)."""
         shapes = live_key_shapes(self.embed_dims, self.in_channels, 799, self.transformer.layer_num,
-                                 self.parametric_output)
+                                 self.parametric_output, petr=self.PETR_embedding, depth_num=self.depth_num)
         out = {}
         with torch.no_grad():
             for k, s in shapes.items():
@@ -152,7 +161,9 @@ class POEM_Generalized_Head(nn.Module):
             cfg = hip.make_config(self.embed_dims, in_channels=self.in_channels, nsample=self.nsample, nquery=799,
                                   heads=t.num_attention_heads, nblocks=t.layer_num, parametric=self.parametric_output,
                                   max_views=self.max_views, radius=self.radius, ln_eps=t.layer_norm_eps,
-                                  feat_h=self._feat_hw[0], feat_w=self._feat_hw[1])
+                                  feat_h=self._feat_hw[0], feat_w=self._feat_hw[1], pe_normalize=self.pe_normalize,
+                                  petr_embedding=self.PETR_embedding, depth_num=self.depth_num, lid=self.LID,
+                                  depth_start=self.depth_start, depth_end=self.depth_end, position_range=self.position_range)
             bps, anchor, aidx = hip.load_assets(self.nsample)
             eng = hip.Engine(cfg, self._live_weights(), bps, anchor, aidx, self.template, device)
             self._engines[skey] = eng

@@ -22,7 +22,11 @@ class PoemConfig(ctypes.Structure):
                 ("nquery", ctypes.c_int32), ("heads", ctypes.c_int32), ("nblocks", ctypes.c_int32),
                 ("knn", ctypes.c_int32), ("parametric", ctypes.c_int32), ("feat_h", ctypes.c_int32),
                 ("feat_w", ctypes.c_int32), ("max_views", ctypes.c_int32), ("radius", ctypes.c_float),
-                ("ln_eps", ctypes.c_float)]
+                ("ln_eps", ctypes.c_float),
+                # ABI 6: the positional-encoding switches of the reference's constructor (include/poem_hip.h)
+                ("pe_normalize", ctypes.c_int32), ("petr_embedding", ctypes.c_int32), ("depth_num", ctypes.c_int32),
+                ("lid", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("depth_start", ctypes.c_double),
+                ("depth_end", ctypes.c_double), ("position_range", ctypes.c_double * 6)]
 
 
 _vp, _i, _f, _sz, _i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
@@ -67,6 +71,8 @@ SIGNATURES = {
     "poem_unpack_rows": (_i, [_vp, _i, _i, _vp, _vp]),
     "poem_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "poem_pe_table": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "poem_pe_table_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "poem_frustum_features": (_i, [_cfgp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "poem_input_proj": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "poem_project_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "poem_merge_reduce": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -156,9 +162,11 @@ def stream():
 
 
 def make_config(embed, in_channels=160, nsample=4096, nquery=799, heads=4, nblocks=3, knn=32, parametric=False,
-                feat_h=16, feat_w=16, max_views=10, radius=0.1, ln_eps=1e-12):
+                feat_h=16, feat_w=16, max_views=10, radius=0.1, ln_eps=1e-12, pe_normalize=True, petr_embedding=False,
+                depth_num=32, lid=False, depth_start=0.0, depth_end=1.2, position_range=(-0.6, -0.6, 0.0, 0.6, 0.6, 1.2)):
     return PoemConfig(embed, in_channels, nsample, nquery, heads, nblocks, knn, int(bool(parametric)), feat_h, feat_w,
-                      max_views, radius, ln_eps)
+                      max_views, radius, ln_eps, int(bool(pe_normalize)), int(bool(petr_embedding)), int(depth_num),
+                      int(bool(lid)), 0, float(depth_start), float(depth_end), (ctypes.c_double * 6)(*[float(v) for v in position_range]))
 
 
 def load_assets(nsample, root=None):
@@ -184,7 +192,8 @@ class Engine:
         L = lib()
         self.cfg = cfg
         self.device = torch.device(device)
-        shapes = live_key_shapes(cfg.embed, cfg.in_channels, cfg.nquery, cfg.nblocks, bool(cfg.parametric))
+        shapes = live_key_shapes(cfg.embed, cfg.in_channels, cfg.nquery, cfg.nblocks, bool(cfg.parametric),
+                                 petr=bool(cfg.petr_embedding), depth_num=cfg.depth_num)
         n = L.poem_num_weight_tensors(ctypes.byref(cfg))
         check(n, "poem_num_weight_tensors")
         if n != len(shapes):

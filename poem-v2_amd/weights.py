@@ -16,7 +16,7 @@ import torch
 MODEL_EMBED = {"small": 128, "medium": 256, "large": 512, "huge": 1024, "medium_MANO": 256}
 
 
-def live_key_shapes(embed, in_channels=160, nquery=799, nblocks=3, parametric=False):
+def live_key_shapes(embed, in_channels=160, nquery=799, nblocks=3, parametric=False, petr=False, depth_num=32):
     C = embed
     k = OrderedDict()
 
@@ -63,6 +63,13 @@ def live_key_shapes(embed, in_channels=160, nquery=799, nblocks=3, parametric=Fa
         if parametric:
             lin(p + "flat_verts", 1, nquery)
             lin(p + "mano_linear", 106, C)
+    if petr:
+        # PETR_EMBEDDING=True (ptEmb_head.py:101-105,865-867): position_encoder is live.  Listed LAST (after the blocks, not at
+        # its state_dict position behind adapt_pos3d) so that the canonical indices of every other tensor do not depend on it.
+        k["position_encoder.0.weight"] = (2 * C, 3 * depth_num, 1, 1)
+        k["position_encoder.0.bias"] = (2 * C,)
+        k["position_encoder.2.weight"] = (C, 2 * C, 1, 1)
+        k["position_encoder.2.bias"] = (C,)
     return k
 
 

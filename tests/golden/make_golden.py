@@ -70,7 +70,22 @@ CASES = {
     # so the same operating point (max |xyz| ~ 1 m, O(1) coordinate updates per block) sits at a lower gain
     "large_hot": dict(model="large", embed=512, nsample=4096, views=[5, 3], seed=23, parametric=False, full=False, gain=1.8,
                       ln_spread=0.3),
+    # round 5.  The two constructor switches no release config sets: PETR_EMBEDDING (position_encoder of the cameras' frustum
+    # points added to the positional embedding, ptEmb_head.py:113-182,865-867) and POSITIONAL_ENCODING.NORMALIZE = false
+    # (petr_transformer.py:451-457) -- the release yaml's frustum grid, a second grid (LID bins, 16 depths, shifted range)
+    # together with NORMALIZE false, and PETR at the medium release shape
+    "tinypetr": dict(model="medium", embed=32, nsample=1024, views=[1, 2, 3], seed=31, parametric=False, full=True, petr=True),
+    "tinynonorm": dict(model="medium", embed=32, nsample=1024, views=[3, 1, 2], seed=32, parametric=False, full=True, pe_normalize=False),
+    "tinypetrlid": dict(model="medium", embed=32, nsample=1024, views=[2, 4], seed=33, parametric=False, full=True, petr=True,
+                        pe_normalize=False, lid=True, depth_num=16, depth_start=0.05, depth_end=1.5,
+                        position_range=[-0.5, -0.7, 0.1, 0.7, 0.5, 1.4]),
+    "mediumpetr": dict(model="medium", embed=256, nsample=4096, views=[3, 5], seed=34, parametric=False, full=False, petr=True),
 }
+
+
+def petr_kwargs(spec):
+    """The keyword arguments of live_key_shapes / seeded_state_dict that the PETR switch adds."""
+    return dict(petr=True, depth_num=spec.get("depth_num", 32)) if spec.get("petr") else {}
 
 
 def check_tie_pair():
@@ -115,6 +130,13 @@ def run_reference(spec):
     cfg["TRANSFORMER"]["BPS_FEAT_DIM"] = spec["nsample"]
     cfg["TRANSFORMER"]["PARAMETRIC_OUTPUT"] = spec["parametric"]
     cfg["POSITIONAL_ENCODING"]["NUM_FEATS"] = C // 2
+    cfg["POSITIONAL_ENCODING"]["NORMALIZE"] = bool(spec.get("pe_normalize", True))
+    if spec.get("petr"):
+        cfg["PETR_EMBEDDING"] = True
+        for key, name in (("DEPTH_NUM", "depth_num"), ("LID", "lid"), ("DEPTH_START", "depth_start"), ("DEPTH_END", "depth_end"),
+                          ("POSITION_RANGE", "position_range")):
+            if name in spec:
+                cfg[key] = spec[name]
     cwd = make_cwd(spec["nsample"])
     os.chdir(cwd)
     rh.KNN_FMA = bool(spec.get("knn_fma", False))
@@ -122,7 +144,7 @@ def run_reference(spec):
         head = build_head(cfg, data_preset=CN(y["DATA_PRESET"]))
         head.eval()
         sd = pk.weights.seeded_state_dict(C, seed=spec["seed"], parametric=spec["parametric"], gain=spec.get("gain", 1.0),
-                                          ln_spread=spec.get("ln_spread", 0.02))
+                                          ln_spread=spec.get("ln_spread", 0.02), **petr_kwargs(spec))
         ref_sd = head.state_dict()
         for k, v in sd.items():
             assert k in ref_sd and tuple(ref_sd[k].shape) == tuple(v.shape), f"key/shape mismatch: {k}"

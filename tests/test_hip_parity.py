@@ -346,7 +346,38 @@ def test_project_and_sample_matches_oracle():
     assert _md(got, ref) < 2e-5
 
 
-@pytest.mark.parametrize("name", ["tiny", "tinymano"])
+@pytest.mark.parametrize("lid,depth_num,fh,fw,img", [(False, 32, 16, 16, (256, 256)), (True, 16, 16, 16, (256, 256)), (False, 8, 8, 24, (384, 128))])
+def test_frustum_features_match_the_oracle(lid, depth_num, fh, fw, img):
+    """poem_frustum_features (the input of position_encoder, ptEmb_head.py:113-181 + inverse_sigmoid) against the oracle's
+    restatement, which tests/test_oracle_golden.py pins to the reference through the tinypetr / tinypetrlid / mediumpetr
+    fixtures.  The 4 x 4 product and logf round differently from the CPU's (1 ulp of a coordinate of magnitude ~1, i.e. ~1e-7 of
+    the normalised coordinate t) and d/dt log(t / (1 - t)) = 1 / (t (1 - t)) grows towards the clamps: compared as t
+    (3e-7) everywhere and as values (2e-5) where |value| < 5; the clamped entries (|v| = log(1e5)) sit at the same places."""
+    views = [3, 1, 4]
+    b = pk.inputs.synthetic_batch(views, seed=5)
+    m = b["img_metas"]
+    ocfg = po.PathConfig(petr=True, lid=lid, depth_num=depth_num, depth_start=0.05 if lid else 0.0, depth_end=1.3,
+                         position_range=(-0.5, -0.7, 0.1, 0.7, 0.5, 1.4) if lid else (-0.6, -0.6, 0.0, 0.6, 0.6, 1.2))
+    want = po.frustum_features(ocfg, m["cam_intr"], m["cam_extr"], fh, fw, img)
+    cfg = hip.make_config(256, feat_h=fh, feat_w=fw, petr_embedding=True, depth_num=depth_num, lid=lid, depth_start=ocfg.depth_start,
+                          depth_end=ocfg.depth_end, position_range=ocfg.position_range)
+    out = torch.full((sum(views), 3 * depth_num, fh, fw), float("nan"), device=DEV)
+    import ctypes
+    K, E = m["cam_intr"].to(DEV), m["cam_extr"].to(DEV)
+    hip.check(hip.lib().poem_frustum_features(ctypes.byref(cfg), hip.ptr(K), hip.ptr(E), sum(views), img[0], img[1], hip.ptr(out),
+                                              hip.stream()), "poem_frustum_features")
+    got = out.cpu()
+    assert bool(torch.isfinite(got).all())
+    clamp = math.log(1e5)
+    edge = (want.abs() > clamp - 1e-3)
+    assert 0.02 < float(edge.float().mean()) < 0.8           # the case has both saturated and interior points
+    assert _md(torch.sigmoid(got.double()), torch.sigmoid(want.double())) < 3e-7
+    mid = want.abs() < 5.0
+    assert float(mid.float().mean()) > 0.2 and _md(got[mid], want[mid]) < 2e-5
+    assert float(((got.abs() > clamp - 1e-3) != edge).float().mean()) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinypetr", "tinynonorm", "tinypetrlid"])
 def test_head_tiny_stage_taps_vs_golden(name):
     z, meta = load_golden(name)
     spec = meta["spec"]
@@ -376,7 +407,7 @@ def test_head_tiny_stage_taps_vs_golden(name):
         assert _md(out["pred_shape"], torch.from_numpy(z["pred_shape"])) < 2e-5
 
 
-@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano"])
+@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano", "mediumpetr"])
 def test_head_release_shapes_vs_golden_and_oracle(name):
     """BASELINE.json bar: MPVPE of the HIP path vs the reference <= 1e-3 mm (1e-6 m), last decoder layer."""
     z, meta = load_golden(name)
@@ -950,6 +981,43 @@ def test_other_feature_map_and_image_sizes_through_the_whole_path(embed, fh, fw,
     with torch.no_grad():
         one = head(feat[2:5].contiguous(), m1, rj[1:2].contiguous())["all_coords_preds"].cpu()
     assert torch.equal(one[:, 0], outs[1][:, 1])
+
+
+def test_petr_embedding_ragged_batch_both_front_ends_and_graph_replays():
+    """PETR_EMBEDDING through everything the default path has: a ragged batch, the fused and the operator sampling front ends
+    (bit-identical `x` either way: the same input_proj launch), graph replays (the per-view table is rebuilt from the caller's
+    cameras in front of every replay: new cameras, same graph), a sample alone == the sample in its batch."""
+    spec = dict(embed=256, nsample=4096, views=[8, 3, 1, 8], seed=77, parametric=False, petr=True)
+    cfg, w, consts, batch = case_setup(spec)
+    orc = run_oracle(cfg, w, consts, batch)["all_coords_preds"]
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    outs = {}
+    with torch.no_grad():
+        for fused in (1, 0):
+            head.set_option("fused_sampling", fused)
+            for _ in range(3):
+                outs[fused] = head(feat, metas, rj)["all_coords_preds"].cpu()
+            assert float(torch.norm(outs[fused][-1, :, 21:] - orc[-1, :, 21:], dim=-1).mean()) < 1e-6, fused
+        head.set_option("fused_sampling", 1)
+        assert head._engine.graph_stats()["replays"] >= 1
+        # other cameras through the same engine and graph
+        b2 = pk.inputs.synthetic_batch(spec["views"], seed=78)
+        feat2, metas2, rj2 = batch_to(b2, DEV)
+        got2 = head(feat2, metas2, rj2)["all_coords_preds"].cpu()
+        orc2 = run_oracle(cfg, w, consts, b2)["all_coords_preds"]
+        assert float(torch.norm(got2[-1, :, 21:] - orc2[-1, :, 21:], dim=-1).mean()) < 1e-6
+        m1 = dict(metas)
+        m1["cam_intr"], m1["cam_extr"] = metas["cam_intr"][8:11].contiguous(), metas["cam_extr"][8:11].contiguous()
+        m1["cam_view_num"], m1["master_id"] = np.asarray([3]), [0]
+        one = head(feat[8:11].contiguous(), m1, rj[1:2].contiguous())["all_coords_preds"].cpu()
+    assert torch.equal(one[:, 0], outs[1][:, 1])
+    # without the switch the same weights give another answer (the embedding is live)
+    spec0 = dict(spec, petr=False)
+    head0 = build_hip_head(spec0, DEV)
+    with torch.no_grad():
+        base = head0(feat, metas, rj)["all_coords_preds"].cpu()
+    assert float((base - outs[1]).abs().max()) > 1e-4
 
 
 def test_errors_are_loud():

@@ -11,7 +11,7 @@ def _maxdiff(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
 
 
-@pytest.mark.parametrize("name", ["tiny", "tinymano"])
+@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinypetr", "tinynonorm", "tinypetrlid"])
 def test_tiny_stage_taps(name):
     z, meta = load_golden(name)
     cfg, w, consts, batch = case_setup(meta["spec"])
@@ -33,7 +33,7 @@ def test_tiny_stage_taps(name):
         assert _maxdiff(out["pred_shape"], z["pred_shape"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano"])
+@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano", "mediumpetr"])
 def test_release_shapes(name):
     z, meta = load_golden(name)
     cfg, w, consts, batch = case_setup(meta["spec"])
@@ -49,6 +49,26 @@ def test_release_shapes(name):
     if meta["spec"]["parametric"]:     # medium_MANO tail (Q3 + rot6d -> axis-angle), toy MANO stand-in on both sides
         assert _maxdiff(out["pred_pose"], z["pred_pose"]) < 1e-4
         assert _maxdiff(out["pred_shape"], z["pred_shape"]) < 1e-5
+
+
+def test_the_petr_and_normalize_switches_change_the_positional_embedding():
+    """The round-5 fixtures really exercise the two switches: on the SAME inputs and weights the oracle's `x` moves by O(1) when
+    PETR_EMBEDDING is dropped / NORMALIZE flipped, and the frustum features are not saturated (most of the synthetic cameras'
+    frustum lies inside position_range)."""
+    import dataclasses
+    for name, field in (("tinypetr", "petr"), ("tinynonorm", "pe_normalize"), ("tinypetrlid", "petr")):
+        z, meta = load_golden(name)
+        cfg, w, consts, batch = case_setup(meta["spec"])
+        taps, flipped = {}, {}
+        run_oracle(cfg, w, consts, batch, taps=taps)
+        run_oracle(dataclasses.replace(cfg, **{field: not getattr(cfg, field)}), w, consts, batch, taps=flipped)
+        assert _maxdiff(taps["x"], z["tap.x"]) < 2e-5 and _maxdiff(flipped["x"], z["tap.x"]) > 0.05, name
+        if cfg.petr:
+            m = batch["img_metas"]
+            f = po.frustum_features(cfg, m["cam_intr"], m["cam_extr"], 16, 16, m["inp_img_shape"])
+            assert f.shape == (sum(meta["spec"]["views"]), 3 * cfg.depth_num, 16, 16)
+            inside = float((f.abs() < 11.0).float().mean())          # |inverse_sigmoid| = 11.51 at the clamps
+            assert 0.3 < inside < 1.0, inside
 
 
 @pytest.mark.parametrize("name", ["small_hot", "medium_hot", "large_hot"])

@@ -28,13 +28,18 @@ def oracle_consts(nsample=4096):
 
 
 def seeded_weights(spec):
+    extra = dict(petr=True, depth_num=spec.get("depth_num", 32)) if spec.get("petr") else {}
     return pk.weights.seeded_state_dict(spec["embed"], seed=spec["seed"], parametric=spec["parametric"],
-                                        gain=spec.get("gain", 1.0), ln_spread=spec.get("ln_spread", 0.02))
+                                        gain=spec.get("gain", 1.0), ln_spread=spec.get("ln_spread", 0.02), **extra)
+
+
+PE_SPEC_KEYS = ("pe_normalize", "petr", "depth_num", "lid", "depth_start", "depth_end", "position_range")      # round 5
 
 
 def case_setup(spec):
     """spec: dict(embed, nsample, views, seed, parametric) -> (cfg, weights, consts, batch)."""
-    cfg = po.PathConfig(embed=spec["embed"], nsample=spec["nsample"], parametric=spec["parametric"])
+    cfg = po.PathConfig(embed=spec["embed"], nsample=spec["nsample"], parametric=spec["parametric"],
+                        **{k: (tuple(spec[k]) if k == "position_range" else spec[k]) for k in PE_SPEC_KEYS if k in spec})
     w = seeded_weights(spec)
     consts = oracle_consts(spec["nsample"])
     batch = synthetic_batch(spec["views"], seed=spec["seed"])
@@ -55,7 +60,14 @@ from poem_v2_amd.configs import head_cfg  # noqa: E402,F401
 
 def build_hip_head(spec, device="cuda:0"):
     """HIP head filled with the same seeded weights / template the oracle and the golden vectors use."""
-    head = pk.build_head(head_cfg(spec["embed"], spec["nsample"], spec["parametric"]), data_preset=pk.CN({}))
+    hc = head_cfg(spec["embed"], spec["nsample"], spec["parametric"])
+    hc["POSITIONAL_ENCODING"]["NORMALIZE"] = bool(spec.get("pe_normalize", True))
+    hc["PETR_EMBEDDING"] = bool(spec.get("petr", False))
+    for key, name in (("DEPTH_NUM", "depth_num"), ("LID", "lid"), ("DEPTH_START", "depth_start"), ("DEPTH_END", "depth_end"),
+                      ("POSITION_RANGE", "position_range")):
+        if name in spec:
+            hc[key] = spec[name]
+    head = pk.build_head(hc, data_preset=pk.CN({}))
     sd = seeded_weights(spec)
     missing, unexpected = head.load_state_dict(sd, strict=False)
     assert not missing and not unexpected
