@@ -196,7 +196,13 @@ int poem_set_chains(poem_handle_t h, int enable);
  * merge_net[1]; the hidden rows of merge_features_mv, ptEmb_head.py:745-762, never reach HBM) when the batch has at least this
  * many views -- 0 = enough to give every CU two of the kernel's 8-tile units, -1 = never (two-kernel form for every sample);
  * which samples go where is decided on the device from the view layout; "group_xcd" (default 1): that kernel's units in
- * XCD-aware order (a view's feature planes and projection table are fetched by one L2).
+ * XCD-aware order (a view's feature planes and projection table are fetched by one L2); "d2_first" (default 1): the
+ * feed-forward chain of a block is issued in front of the next block's neighbour searches, so the launch graph keeps it on the
+ * hardware queue of the chain before it (a launch that waits for another queue costs 5-13 us in a replayed graph) and the
+ * searches take the side queue; "wait_merge" (default -1 = 3; bit mask): 1 = the first cross attention is issued in front of
+ * the side stream's remaining launches (same reason), 2 = the main stream waits for the later blocks' basis-point GEMMs once,
+ * where block 0's vector cross attention waits for its anchor rows anyway, 4 (lab) = it waits for a block's neighbour searches
+ * at the block's first cross attention.  Scheduling only.
  * The switches marked process-wide are launcher statics: setting one on any handle sets it for the process (the launch-graph
  * key carries the process's values).  Unknown names and out-of-range values return POEM_E_ARG. */
 int poem_set_option(poem_handle_t h, const char* name, int value);

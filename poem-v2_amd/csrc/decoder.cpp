@@ -61,6 +61,18 @@ struct DecoderRun {
   const float* anchor = nullptr;
   int shared = 0;
   bool knn_issued[9] = {};
+  // wait_merge (chain mode with side streams; scheduling only).  A launch that waits for another stream costs 5-13 us in a
+  // replayed launch graph even when the other side finished long ago (LABNOTES R5.3), and a small batch is a chain of ~40
+  // dependent launches: (a) the first cross attention is issued in FRONT of the side stream's remaining launches (block 0's
+  // anchor rows, the later blocks' F1), so the runtime keeps F1(0) -> attention on one hardware queue; (b) the main stream waits
+  // for the later blocks' F1 once, where block 0's vector cross attention waits for its anchor rows anyway; (c, lab bit, off) it waits for
+  // block i's neighbour searches where block i's first cross attention starts instead of in front of the vector self attention
+  // (nothing at B <= 3, +0.5-1 % from four samples on: the searches no longer overlap the first cross attention).
+  // Measured (a) + (b): B = 1 / 2 / 4 -2.0 / -1.4 / -1.2 %, B >= 8 +-0.
+  bool wmerge = false;
+  int wmask = 0;              // 1 = (a), 2 = (b), 4 = (c)
+  bool side_rest_pending = false;
+  bool bps_waited[9] = {}, knn_waited[9] = {};
   bool anchor_from_y3 = false;      // block 0 on the tables: (kg | v) of the anchor rows are rows of p.y3 (small batches)
 
   DecoderRun(poem_handle_t h_, Plan& p_, const float* feats_in, const float* pt_xyz_, const float* pt_feats_, int B_, float* pose,
@@ -125,7 +137,11 @@ struct DecoderRun {
       HIPCHK(poem_launch_gemm_segs(pt_feats, C, f.w[0], f.b[0], BS, C, POEM_ACT_NONE, C, anchored ? 4 : 6, outs, modes, sb));
     }
     if (ov) HIPCHK(hipEventRecord(h->ev_bps[i], sb));      // the cross attentions wait for the K / V images only
-    if (anchored) {
+    if (anchored && !side_rest_pending) return basis_point_anchor_rows(f);
+    return POEM_OK;
+  }
+  int basis_point_anchor_rows(const poem_handle_s::Fused& f) {
+    {
       // the vector cross attention of block 0 reads only the 32 anchor rows of (kc | vc): project just those (the same
       // fma chain per element as the full GEMM's rows); its own event: the first cross attention does not wait for them
       HIPCHK(poem_launch_gather_anchor_rows(pt_feats, C, h->anchor_idx, S, p.anch_x[1], B, C, p.ident, sb));
@@ -151,10 +167,12 @@ struct DecoderRun {
 
   // ---- neighbours of block i >= 1 from xyz_i (block 0: the fixed anchors for both attentions -- Q2).  The large search
   // first: it gets its CUs before the persistent attention kernel of the block takes them all.
-  int neighbour_searches(int i) {
+  // `recorded`: ev_xyz[i] has already been recorded on s where xyz_i became final (tail(): the searches are then ISSUED behind
+  // the chain launch that follows -- see there)
+  int neighbour_searches(int i, bool recorded = false) {
     if (knn_issued[i]) return POEM_OK;
     if (ov) {
-      HIPCHK(hipEventRecord(h->ev_xyz[i], s));            // xyz_i is final here
+      if (!recorded) HIPCHK(hipEventRecord(h->ev_xyz[i], s));            // xyz_i is final here
       HIPCHK(hipStreamWaitEvent(sk, h->ev_xyz[i], 0));
     }
     HIPCHK(poem_launch_knn(p.xyz[i], pt_xyz, p.idx_cross[i], B, Q, S, h->knn_fma, sk));
@@ -203,7 +221,11 @@ struct DecoderRun {
     const int bb = h->block_base(i);
     if (chain) {
       const int a1 = bb + B_A1, a2 = bb + B_A2;
-      if (ov) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
+      if (ov && !bps_waited[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_bps[i], 0));
+      if (ov && (wmask & 4) && h->knn_early && i > 0 && knn_issued[i] && !knn_waited[i]) {      // (c)
+        HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
+        knn_waited[i] = true;
+      }
       // the chain combines the attention's split-key partials while it fills its tile (no attn_combine launch, no ctx round trip)
       const void *part_o = nullptr, *part_ml = nullptr;
       int pchunks = 0;
@@ -222,6 +244,13 @@ struct DecoderRun {
         a.pc_heads = c.heads; a.pc_chunks = pchunks; a.pc_nq = Q; a.pc_kc2 = pkc2;
       };
       HIPCHK(attention(q0, 2 * C, q_batch, p.y1[i], p.y1[i] + (size_t)BS * C));
+      if (side_rest_pending) {                                               // (a)
+        side_rest_pending = false;
+        if (tables && i == 0)
+          if (const int rc = basis_point_anchor_rows(h->fused[0]); rc != POEM_OK) return rc;
+        for (int k = 1; k < c.nblocks; ++k)
+          if (const int rc = basis_point_side(k); rc != POEM_OK) return rc;
+      }
       if (const int rc = deferred_basis_point_side(i, 1); rc != POEM_OK) return rc;
       ChainArgs ca = chain_args(0);
       ca.x = p.ctx; ca.ldx = C;
@@ -288,7 +317,7 @@ struct DecoderRun {
   int vector_self(int i) {
     const int vsb = h->block_base(i) + B_VS;
     const float* xyz = p.xyz[i];
-    if (ov && i > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
+    if (ov && i > 0 && !knn_waited[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
     const bool prof = prof_begin();
     if (h->precision != POEM_PRECISION_FP32) {
       const auto& sw = h->split[2 * i];
@@ -332,6 +361,11 @@ struct DecoderRun {
   int vector_cross(int i) {
     const int vcb = h->block_base(i) + B_VC;
     const float* xyz = p.xyz[i];
+    if (ov && (wmask & 2) && i == 0 && defer_at() == 0)                        // (b)
+      for (int k = 1; k < c.nblocks; ++k) {
+        HIPCHK(hipStreamWaitEvent(s, h->ev_bps[k], 0));
+        bps_waited[k] = true;
+      }
     const bool prof = prof_begin();
     if (h->precision != POEM_PRECISION_FP32) {
       const auto& sw = h->split[2 * i + 1];
@@ -382,7 +416,14 @@ struct DecoderRun {
       cd.wreg2 = h->R(bb + B_REG2_W); cd.breg2 = h->R(bb + B_REG2_B); cd.xyz_in = xyz; cd.xyz_out = p.xyz[i + 1];
       HIPCHK(poem_launch_chain(&cd, C, s));       // D1: xyz_{i+1} is final behind it (the next block's searches wait for it)
       if (feats_dead) return POEM_OK;
-      if (ov && h->knn_early && !last)            // the next block's searches overlap D2 and the next cross attention
+      // The next block's searches overlap D2 and the next cross attention.  Which of the two is ISSUED first decides which one
+      // the launch graph keeps on D1's hardware queue (the runtime continues a node's queue with its first-created successor and
+      // moves the others to another queue: a cross-queue edge costs ~10 us, LABNOTES R5.3): D2 first keeps D1 -> D2 -> next cross
+      // attention -- the critical path -- on one queue and sends the searches, which have ~80 us of slack, to the side queue.
+      const bool early = ov && h->knn_early && !last;
+      const bool d2_first = early && h->d2_first != 0;
+      if (early && d2_first) HIPCHK(hipEventRecord(h->ev_xyz[i + 1], s));
+      if (early && !d2_first)
         if (const int rc = neighbour_searches(i + 1); rc != POEM_OK) return rc;
       ChainArgs ce = chain_args(3);
       ce.x = p.f_cross[i]; ce.ldx = C;
@@ -393,6 +434,8 @@ struct DecoderRun {
         ce.w2 = (const float4*)h->fused[i + 1].w[1]; ce.b2 = h->fused[i + 1].b[1]; ce.n2 = 2; ce.y2 = p.qeqp; ce.ldy2 = 2 * C;
       }
       HIPCHK(poem_launch_chain(&ce, C, s));
+      if (early && d2_first)
+        if (const int rc = neighbour_searches(i + 1, true); rc != POEM_OK) return rc;
       feats = p.feats[i];
       return c.parametric && last ? parametric_tail(i) : POEM_OK;
     }
@@ -417,8 +460,11 @@ struct DecoderRun {
   int run() {
     int rc = fork();
     if (rc != POEM_OK) return rc;
-    if (ov)          // the basis-point side of every block up front on its stream (or block 0's only: defer_at())
-      for (int i = 0; i < (defer_at() ? 1 : c.nblocks); ++i)
+    wmask = (ov && chain) ? (h->wait_merge >= 0 ? h->wait_merge : 3) : 0;
+    wmerge = wmask != 0;
+    side_rest_pending = (wmask & 1) && defer_at() == 0;
+    if (ov)          // the basis-point side of every block up front on its stream (or block 0's only: defer_at(), wait_merge (a))
+      for (int i = 0; i < ((defer_at() || side_rest_pending) ? 1 : c.nblocks); ++i)
         if ((rc = basis_point_side(i)) != POEM_OK) return rc;
     for (int i = 0; i < c.nblocks; ++i) {
       idx_s = idx_c = h->anchor_idx;       // block 0: the fixed anchors for both attentions (Q2)

@@ -192,6 +192,13 @@ struct poem_handle_s {
   // one-query blocks of the full vector attention (vecattn.hip): -1 = for small batches (B * Q <= 16 x CUs: the busiest CU gets
   // 7 queries instead of 8 at B = 2; measured B = 1 / 2 / 4 -0.7 / -1.7 / -2.0 %), 0 never, 1 / 2 always (3 / 2 waves per SIMD); same bits
   int va_p1 = -1;
+  // D2 issued in front of the next block's neighbour searches (decoder.cpp tail(): which successor of D1 the launch graph keeps on
+  // D1's hardware queue): 0 = the searches first (rounds 1-4), 1 = D2 first (measured -1.3 / -0.5 / -0.4 % at B = 1 / 2 / 32);
+  // scheduling only
+  int d2_first = 1;
+  // fewer cross-stream waits on the query-side chain (decoder.cpp DecoderRun::wmerge): bit mask 1 = (a), 2 = (b), 4 = (c) there;
+  // -1 = (a) + (b); scheduling only
+  int wait_merge = -1;
   bool overlap = true;
   // Per-view index arrays (view_offsets | view_sample | pe_index) live in handle-owned device memory and are re-uploaded
   // only when the batch's view layout changes: a pageable H2D copy blocks the host until the stream reaches it, i.e.

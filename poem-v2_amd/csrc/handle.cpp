@@ -507,6 +507,8 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "gemm_xcd_map") { poem_gemm_xcd_map(value != 0); g_proc_switches.fetch_and(~1); g_proc_switches.fetch_or(value ? 1 : 0); }
   else if (k == "f1_split") h->f1_split = value != 0;
   else if (k == "xattn_half") { poem_cross_attention_half(value != 0); g_proc_switches.fetch_and(~4); g_proc_switches.fetch_or(value ? 4 : 0); }
+  else if (k == "wait_merge") { if (value < -1 || value > 7) return POEM_E_ARG; h->wait_merge = value; }
+  else if (k == "d2_first") { if (value < 0 || value > 1) return POEM_E_ARG; h->d2_first = value; }
   else if (k == "va_p1") { if (value < -1 || value > 2) return POEM_E_ARG; h->va_p1 = value; }
   else if (k == "gemm_kslab") { poem_gemm_kslab(value != 0); g_proc_switches.fetch_and(~2); g_proc_switches.fetch_or(value ? 2 : 0); }
   else if (k == "small_batch") h->small_batch = value;
