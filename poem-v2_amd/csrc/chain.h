@@ -25,4 +25,6 @@ struct ChainArgs {
   const float4* wout; const float* bout;        // packed (C x 4C)
   const float* ln2_g; const float* ln2_b;
   float* y3; int ldy3;       // feats
+  // chain16's one-unit tiles: every packed weight above has a native 16x16x4 image this many bytes away (handle.cpp native16)
+  long long native_delta;
 };

@@ -24,6 +24,16 @@
 
 #include "chain.h"
 
+#ifndef POEM_C16_DEEP
+#define POEM_C16_DEEP 8
+#endif
+#ifdef POEM_C16_STAMPS   // tools/lab/c16_lab only: 100 MHz ticks at the phase boundaries of block 0's wave 0
+__device__ long long c16_stamps[64];
+#define C16_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) c16_stamps[(k)] = wall_clock64(); } while (0)
+#else
+#define C16_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -122,6 +132,102 @@ __device__ __forceinline__ void gemm16(const __amdgpu_buffer_rsrc_t wrs, int wba
 #undef C16_MMA
 }
 
+// ---- one-unit tiles (RU * T16 <= 2), round 5: the weight ring runs ACROSS the GEMM phases of a chain.  A 16-row tile is a
+// latency chain -- 3.4 us of MFMAs per C x C phase against 5.2-6.2 us measured (tools/lab/c16_lab) -- and every phase began by
+// requesting its first seven weight chunks and waiting for them, and ended by re-requesting its last chunk seven times (the
+// clamped prefetch).  Here the last seven ring slots of a phase fetch the NEXT phase's first chunks instead, behind the
+// epilogue (bias / activation / LayerNorm / barriers / LDS write-back) of this one, and the first phase's chunks are requested
+// before the tile's fill.  Same MFMAs on the same operands in the same order: bit-identical.
+struct WSrc {
+  __amdgpu_buffer_rsrc_t rs;
+  int base, stride;      // byte offset of the wave's first 32-row tile at the contraction's start; bytes between 32-row tiles
+  bool valid;
+};
+
+// A lane needs TWO floats of a fragment image's float4 -- (x, z) in lane groups 0 and 1, (y, w) in groups 2 and 3 -- and the
+// texture addresser is paid per lane: as one 16-byte load per lane (what gemm16 does for its taller tiles, where a fragment feeds
+// RU units) a 16-row tile's weight stream costs the addresser as long as its MFMAs take (8 waves x 32 chunks x 2 x 16 cycles =
+// 3.4 us per C x C phase: measured 4.8-5.0 us per phase against 2.8-3.4 without the loads, tools/lab/c16_lab; two strided 4-byte
+// loads per lane: 9.6 us).  The NATIVE image holds each lane's two floats side by side -- per 1 KiB block of the 32-row image
+//   N[half][lane = 16 g + i] = float2( F[16 half + i + 32 (g & 1)].comp[g >> 1], .comp[(g >> 1) + 2] ),   F = the block's 64 float4
+// -- so a 16-channel tile's chunk is one fully coalesced 8-byte load per lane (512 bytes): half the addresser time, half the ring
+// registers, no selects: 3.4-4.2 us per phase.  Built once per weight at poem_create (native16_kernel), same offsets in a mirror.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 frag_load2(__amdgpu_buffer_rsrc_t rs, int lane_off_bytes, int scalar_off_bytes) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off_bytes, scalar_off_bytes, 0);
+  return float2{__uint_as_float(v[0]), __uint_as_float(v[1])};
+}
+#ifdef POEM_C16_NOLOADS      // tools/lab only: the loop without its weight stream (what the MFMA / LDS side alone costs)
+#define C16R_LOAD(SRC, D, KQ) if ((KQ) < 0) { _Pragma("unroll") for (int t = 0; t < T16; ++t) ar[D][t] = frag_load2((SRC).rs, loff0, (SRC).base); }
+#else
+#define C16R_LOAD(SRC, D, KQ)                                                                                 \
+  _Pragma("unroll") for (int t = 0; t < T16; ++t)                                                             \
+    ar[D][t] = frag_load2((SRC).rs, (t & 1) ? loff1 : loff0, (SRC).base + (t >> 1) * (SRC).stride + (KQ) * 1024);
+#endif
+
+template <int T16, int DEPTH>
+__device__ __forceinline__ void ring_preload(float2 (&ar)[DEPTH][T16], const WSrc& src, int lane) {
+  const int loff0 = lane * 8, loff1 = loff0 + 512;      // native 16x16x4 image (see below)
+#pragma unroll
+  for (int d = 0; d < DEPTH - 1; ++d) { C16R_LOAD(src, d, d) }
+}
+
+// The ring holds chunks 0..DEPTH-2 of `cur` in slots 0..DEPTH-2 on entry, and those of `nxt` on exit (when nxt.valid).
+template <int KCH, int XSP16, int RU, int T16, bool INIT0, int DEPTH>
+__device__ __forceinline__ void gemm16_ring(const WSrc& cur, const WSrc& nxt, const float* __restrict__ X, f32x4 (&acc)[T16][RU],
+                                            float2 (&ar)[DEPTH][T16], int lane) {
+  static_assert(KCH % DEPTH == 0 && KCH >= 2 * DEPTH && DEPTH % 2 == 0 && T16 % 2 == 0, "shape");
+  const int j = lane & 15, g = lane >> 4;
+  const int loff0 = lane * 8, loff1 = loff0 + 512;      // native 16x16x4 image (see below)
+  const float* xc = X + (4 * (g & 1) + (g >> 1)) * XSP16 + j;
+  if (INIT0) {
+#pragma unroll
+    for (int t = 0; t < T16; ++t)
+#pragma unroll
+      for (int u = 0; u < RU; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float xr[2][2][RU];      // [chunk parity][k pair][unit]
+#define C16R_READX(P, KCI)                                                                                    \
+  {                                                                                                           \
+    const int kq_ = min((KCI), KCH - 1);                                                                      \
+    _Pragma("unroll") for (int u = 0; u < RU; ++u) {                                                          \
+      xr[P][0][u] = xc[(kq_ * 8) * XSP16 + 16 * u];                                                           \
+      xr[P][1][u] = xc[(kq_ * 8 + 2) * XSP16 + 16 * u];                                                       \
+    }                                                                                                         \
+  }
+#define C16R_MMA(A, P)                                                                                        \
+  {                                                                                                           \
+    _Pragma("unroll") for (int u = 0; u < RU; ++u)                                                            \
+      _Pragma("unroll") for (int t = 0; t < T16; ++t) acc[t][u] = mfma16(A[t].x, xr[P][0][u], acc[t][u]);     \
+    _Pragma("unroll") for (int u = 0; u < RU; ++u)                                                            \
+      _Pragma("unroll") for (int t = 0; t < T16; ++t) acc[t][u] = mfma16(A[t].y, xr[P][1][u], acc[t][u]);     \
+  }
+  C16R_READX(0, 0)
+#pragma unroll 1
+  for (int kc = 0; kc < KCH - DEPTH; kc += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {      // chunk kc + d sits in slot d; the slot freed by the previous step takes chunk kc + d + DEPTH - 1
+      C16R_LOAD(cur, (d + DEPTH - 1) % DEPTH, kc + d + DEPTH - 1)
+      C16R_READX((d + 1) & 1, kc + d + 1)
+      C16R_MMA(ar[d], d & 1)
+    }
+  }
+  // last group of DEPTH chunks: its prefetches are the next phase's first DEPTH - 1 chunks (or nothing)
+  {
+    constexpr int kc = KCH - DEPTH;
+    const bool nx = nxt.valid;      // wave-uniform
+    C16R_LOAD(cur, DEPTH - 1, KCH - 1)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (d > 0 && nx) { C16R_LOAD(nxt, d - 1, d - 1) }
+      if (d + 1 < DEPTH) C16R_READX((d + 1) & 1, kc + d + 1)
+      C16R_MMA(ar[d], d & 1)
+    }
+  }
+#undef C16R_READX
+#undef C16R_MMA
+}
+
 }  // namespace
 
 // MAXRU: largest tile in units (4 = 64 rows; 2 at C = 512, where two activation tiles of kind D2 must fit 160 KB of LDS)
@@ -148,10 +254,40 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
   const int ru = tb + (layer < te ? 1 : 0);
   if (ru <= 0) return;
   const int tile_row0 = (cu_lo + layer * tb + min(layer, te)) * 16;
+  C16_STAMP(0);
 
   auto run_tile = [&](auto ru_tag, const int row0) {
     constexpr int RU = decltype(ru_tag)::value;
     constexpr int XS = 16 * RU;
+    // one-unit tiles: the weight ring across the phases (gemm16_ring); taller tiles: gemm16's own prologue per phase
+    constexpr bool RING = RU * T16 <= 2 && KCH % 8 == 0 && KCH >= 16;
+    constexpr int DEPTH = RING ? ((KIND == 3 && KCH >= 32) ? POEM_C16_DEEP : 8) : 1;      // D2 runs two waves per SIMD: 256 registers
+    float2 ring[DEPTH][T16];
+    const WSrc none{frag_rsrc(A.w1, 0u), 0, 0, false};
+    // (RING reads the weights' native 16x16x4 images: the same offsets, A.native_delta bytes away -- native16_kernel below)
+    auto img = [&](const float4* w) { return reinterpret_cast<const char*>(w) + (RING ? A.native_delta : 0); };
+    auto src_w1 = [&]() { return WSrc{frag_rsrc(img(A.w1), CC4), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, true}; };
+    auto src_w2 = [&](int pass) {
+      return WSrc{frag_rsrc(img(A.w2), (unsigned)A.n2 * CC4), __builtin_amdgcn_readfirstlane((pass * NTILE + tile0) * KCH * 1024), KCH * 1024, pass < A.n2};
+    };
+    auto src_f4 = [&](int slab) {      // 0 = reg_branch.0, 1 + s = slab s of intermediate.dense
+      return WSrc{frag_rsrc(img(A.wf4), 5u * CC4), __builtin_amdgcn_readfirstlane((slab * NTILE + tile0) * KCH * 1024), KCH * 1024, true};
+    };
+    auto src_wout = [&](int slab) {
+      return WSrc{frag_rsrc(img(A.wout), 4u * CC4), __builtin_amdgcn_readfirstlane(tile0 * 4 * KCH * 1024 + slab * KCH * 1024), 4 * KCH * 1024, true};
+    };
+    // one GEMM phase: D (+)= W_cur X; RING: the ring holds cur's first chunks and leaves with nxt's
+    auto phase = [&](auto init_tag, const WSrc& cur, const WSrc& nxt, const float* X, f32x4 (&acc)[T16][RU]) {
+      constexpr bool INIT0 = decltype(init_tag)::value;
+      if constexpr (RING) gemm16_ring<KCH, XSP, RU, T16, INIT0, DEPTH>(cur, nxt, X, acc, ring, lane);
+      else gemm16<KCH, XSP, RU, T16, INIT0>(cur.rs, cur.base, cur.stride, X, acc, lane);
+    };
+    using init_t = std::integral_constant<bool, true>;
+    using accum_t = std::integral_constant<bool, false>;
+    // the first phase's weights are requested before the tile's fill (behind it where the fill combines the attention's
+    // partials: that code needs the registers)
+    const bool fill_combines = KIND == 0 && A.x == nullptr;
+    if constexpr (RING) { if (KIND == 3) ring_preload<T16, DEPTH>(ring, src_f4(1), lane); }
     // channel of acc[t][u][r]: cw0 + 16 t + 4 g + r (+ pass * C); row: row0 + 16 u + j
     auto add_bias = [&](f32x4 (&acc)[T16][RU], const float* bias, int act) {
 #pragma unroll
@@ -252,17 +388,16 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
       }
     };
     // trailing wide Linear: n C-wide passes over X, results straight to global
-    auto wide_linear = [&](const float4* W, const float* bias, int n, const float* X, float* Y, int ld) {
-      const __amdgpu_buffer_rsrc_t wrs = frag_rsrc(W, (unsigned)n * CC4);
+    auto wide_linear = [&](const float* bias, int n, const float* X, float* Y, int ld) {      // (A.w2; RING: pass 0 is in the ring)
       for (int pass = 0; pass < n; ++pass) {
         f32x4 acc[T16][RU];
-        gemm16<KCH, XSP, RU, T16, true>(wrs, __builtin_amdgcn_readfirstlane((pass * NTILE + tile0) * KCH * 1024), KCH * 1024, X, acc, lane);
+        phase(init_t{}, src_w2(pass), src_w2(pass + 1), X, acc);
         add_bias(acc, bias + pass * C, 0);
         to_global(acc, Y, ld, pass * C);
       }
     };
 
-    if (KIND == 0 && A.x == nullptr) {
+    if (fill_combines) {
       // ---- fill X0 with the cross attention's context, combined from the split-key partials (chain.hip; per (row, channel)
       // the arithmetic of attn_combine_kernel, in its order).  Threads are laid out over XM >= XS rows so that a thread owns
       // one row and G float4 groups per head.
@@ -320,7 +455,9 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
           }
         }
       }
+      if constexpr (RING) ring_preload<T16, DEPTH>(ring, src_w1(), lane);
     } else {
+      if constexpr (RING) { if (KIND != 3) ring_preload<T16, DEPTH>(ring, src_w1(), lane); }
       // ---- fill X0 with the input tile, transposed: consecutive threads read consecutive channels of one row
       static_assert(NT % C == 0 || C % NT == 0, "threads and channels must nest");
       constexpr int RSTEP = NT >= C ? NT / C : 1, CSTEP = NT >= C ? C : NT;
@@ -333,26 +470,31 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
       }
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t f4rs = frag_rsrc(A.wf4, 5u * CC4);
+    C16_STAMP(1);
     if (KIND != 3) {
       // ---- stage 1: first Linear + bias + residual [+ LayerNorm] -> y1 and back into X0
       f32x4 acc[T16][RU];
-      gemm16<KCH, XSP, RU, T16, true>(frag_rsrc(A.w1, CC4), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, acc, lane);
+      phase(init_t{}, src_w1(), KIND == 2 ? src_f4(0) : src_w2(0), X0, acc);
+      C16_STAMP(2);
       add_bias(acc, A.b1, 0);
       add_rows(acc, A.res, A.ldres, A.res_mod);
+      C16_STAMP(3);
       if (KIND == 0) layer_norm(acc, A.ln_g, A.ln_b, A.eps);
+      C16_STAMP(4);
       to_global(acc, A.y1, A.ldy1, 0);
       __syncthreads();                          // every wave is done reading the input tile
       to_lds(acc, X0);
       __syncthreads();
+      C16_STAMP(5);
       if (KIND != 2) {
-        if (A.n2 > 0) wide_linear(A.w2, A.b2, A.n2, X0, A.y2, A.ldy2);
+        if (A.n2 > 0) wide_linear(A.b2, A.n2, X0, A.y2, A.ldy2);
+        C16_STAMP(6);
         return;
       }
       // ---- kind D1.  reg_branch: u = relu(f Wreg0^T + b), xyz' = xyz + u Wreg2^T + b
       {
         f32x4 uu[T16][RU];
-        gemm16<KCH, XSP, RU, T16, true>(f4rs, __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, X0, uu, lane);
+        phase(init_t{}, src_f4(0), none, X0, uu);
         add_bias(uu, A.bf4, 1);
         __syncthreads();                        // every wave is done reading f
         to_lds(uu, X0);
@@ -379,18 +521,21 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
     }
     // ---- kind D2 (X0 = f): o = sum_s gelu(f Wint_s^T + b_s) Wout[:, sC:(s+1)C]^T, slab by slab in k order
     f32x4 o[T16][RU];
-    const __amdgpu_buffer_rsrc_t wors = frag_rsrc(A.wout, 4u * CC4);
 #pragma unroll 1
     for (int sl = 0; sl < 4; ++sl) {
       f32x4 t[T16][RU];
-      gemm16<KCH, XSP, RU, T16, true>(f4rs, __builtin_amdgcn_readfirstlane(((1 + sl) * NTILE + tile0) * KCH * 1024), KCH * 1024, X0, t, lane);
+      phase(init_t{}, src_f4(1 + sl), src_wout(sl), X0, t);
+      C16_STAMP(2 + 4 * sl);
       add_bias(t, A.bf4 + (1 + sl) * C, 2);
+      C16_STAMP(3 + 4 * sl);
       __syncthreads();                        // readers of X1 (the previous slab's contraction)
       to_lds(t, X1);
       __syncthreads();
-      const int wb = __builtin_amdgcn_readfirstlane(tile0 * 4 * KCH * 1024 + sl * KCH * 1024);
-      if (sl == 0) gemm16<KCH, XSP, RU, T16, true>(wors, wb, 4 * KCH * 1024, X1, o, lane);
-      else gemm16<KCH, XSP, RU, T16, false>(wors, wb, 4 * KCH * 1024, X1, o, lane);
+      C16_STAMP(4 + 4 * sl);
+      const WSrc after = sl < 3 ? src_f4(2 + sl) : src_w2(0);      // (src_w2(0).valid = there is a trailing Linear)
+      if (sl == 0) phase(init_t{}, src_wout(sl), after, X1, o);
+      else phase(accum_t{}, src_wout(sl), after, X1, o);
+      C16_STAMP(5 + 4 * sl);
     }
     add_bias(o, A.bout, 0);
 #pragma unroll
@@ -399,14 +544,18 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
       for (int u = 0; u < RU; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[t][u][e] += X0[(cw0 + 16 * t + 4 * g + e) * XSP + 16 * u + j];
+    C16_STAMP(18);
     layer_norm(o, A.ln2_g, A.ln2_b, A.eps);
+    C16_STAMP(19);
     to_global(o, A.y3, A.ldy3, 0);
     if (A.n2 > 0) {
       __syncthreads();                        // every wave has read its residual from X0
       to_lds(o, X0);
       __syncthreads();
-      wide_linear(A.w2, A.b2, A.n2, X0, A.y2, A.ldy2);
+      C16_STAMP(20);
+      wide_linear(A.b2, A.n2, X0, A.y2, A.ldy2);
     }
+    C16_STAMP(21);
   };
 
   if constexpr (MAXRU == 4) {
@@ -450,7 +599,26 @@ static hipError_t launch_chain16_t(const ChainArgs& a, int cus, hipStream_t s) {
   }
 }
 
+// ---- native 16x16x4 image of a packed (32-row fragment order) weight: a permutation inside every 1 KiB block (see C16R_LOAD)
+__global__ void native16_kernel(const float4* __restrict__ src, float2* __restrict__ dst, size_t n2) {
+  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // output float2
+  if (o >= n2) return;
+  const size_t blk = o >> 7;
+  const int w = (int)(o & 127), half = w >> 6, g = (w >> 4) & 3, i = w & 15;
+  const float4 f = src[blk * 64 + 16 * half + i + 32 * (g & 1)];
+  dst[o] = (g >> 1) ? float2{f.y, f.w} : float2{f.x, f.z};
+}
+extern "C" hipError_t poem_launch_native16(const void* packed, void* native, size_t bytes, hipStream_t s) {
+  if (bytes % 1024) return hipErrorInvalidValue;
+  const size_t n2 = bytes / 8;
+  if (!n2) return hipSuccess;
+  hipLaunchKernelGGL(native16_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, (const float4*)packed, (float2*)native, n2);
+  return hipGetLastError();
+}
+extern "C" int poem_chain16_wants_native(int C) { return C == 128 || C == 256; }      // the widths whose one-unit tiles run the ring
+
 extern "C" hipError_t poem_launch_chain16(const ChainArgs* a, int C, hipStream_t s) {
+  if (poem_chain16_wants_native(C) && a->native_delta == 0) return hipErrorInvalidValue;      // (one-unit tiles read the native images)
   const int cus = poem_device_cus();
   switch (C) {
     case 128: return launch_chain16_t<128, 4, 4>(*a, cus, s);

@@ -100,6 +100,7 @@ struct DecoderRun {
   ChainArgs chain_args(int kind) const {
     ChainArgs a{};
     a.kind = kind; a.M = BQ; a.tile_p = h->chain_tile; a.eps = c.ln_eps;
+    a.native_delta = h->native16 ? (long long)(h->native16 - h->packed_base) : 0;
     return a;
   }
 

@@ -107,6 +107,7 @@ struct poem_handle_s {
   bool kv_presplit[8] = {};
   const char* packed_base = nullptr;
   size_t packed_size = 0;
+  char* native16 = nullptr;          // mirror of the packed arena: native 16x16x4 images of the packed weights (chain16.hip), C = 128 / 256
   char* gemm_split = nullptr;
   float* gemm_scales = nullptr;
   bool taps = false;

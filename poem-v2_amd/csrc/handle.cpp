@@ -300,8 +300,14 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
       g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
     }
   }
-  // mirror of a freshly packed fp32 image at `at`: the split image of the same row-major weight
+  if (poem_chain16_wants_native(cfg->embed) && hipMalloc((void**)&h->native16, packed_bytes) != hipSuccess) {
+    g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
+  }
+  // mirror of a freshly packed fp32 image at `at`: the split image of the same row-major weight, and (same offset in
+  // h->native16) the image's native 16x16x4 form for the chain kernels' one-unit tiles
   auto mirror = [&](const float* w_rows, int rows, int cols, const char* at) -> hipError_t {
+    if (h->native16)
+      if (hipError_t e = poem_launch_native16(at, h->native16 + (at - (const char*)packed), packed_bytes_linear(rows, cols), s); e != hipSuccess) return e;
     if (!h->gemm_split || cols % 16) return hipSuccess;
     const size_t off = (size_t)(at - (const char*)packed);
     return poem_launch_pack_split_tiles(w_rows, rows, cols, h->gemm_split + off, h->gemm_scales + off / 256, cols / 2, s);
@@ -471,6 +477,7 @@ void poem_destroy(poem_handle_t h) {
   if (h->tab_mem) (void)hipFree(h->tab_mem);
   if (h->split_mem) (void)hipFree(h->split_mem);
   if (h->gemm_split) (void)hipFree(h->gemm_split);
+  if (h->native16) (void)hipFree(h->native16);
   if (h->gemm_scales) (void)hipFree(h->gemm_scales);
   park_execs(h);
   return_kit(h);

@@ -63,6 +63,9 @@ int poem_chain_combines(int C, int heads, int chunks);
 void poem_cross_attention_partials(int B, int NQ, int NK, int C, int heads, float* scratch, const void** part_o,
                                    const void** part_ml, int* chunks, float* kc2);
 hipError_t poem_launch_chain(const ChainArgs* a, int C, hipStream_t s);
+// chain16.hip: native 16x16x4 image of a packed weight (`bytes` of 1 KiB fragment blocks), for the one-unit tiles' weight ring
+hipError_t poem_launch_native16(const void* packed, void* native, size_t bytes, hipStream_t s);
+int poem_chain16_wants_native(int C);
 hipError_t poem_launch_knn(const float* qxyz, const float* sxyz, int* idx, int B, int NQ, int NS, int fma, hipStream_t s);
 hipError_t poem_launch_vector_attention(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                         const int* idx, int shared_idx, const float* q, const float* k, const float* v,

@@ -1,0 +1,70 @@
+// Development lab: the chain16 kernels alone on random data, every kind, M = 799 B rows; HIP-event time per launch and
+// (STAMPS build) the 100 MHz ticks at the phase boundaries of block 0.
+#define POEM_C16_STAMPS 1
+#include "../../poem-v2_amd/csrc/chain16.hip"
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+__global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned x = (unsigned)i * 2654435761u + seed;
+  x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+  p[i] = ((float)(x & 0xffff) / 65536.0f - 0.5f) * 2.0f * scale;
+}
+static float* rnd(size_t n, unsigned seed, float scale = 1.0f) {
+  float* p; CK(hipMalloc(&p, n * 4));
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p, n, seed, scale);
+  return p;
+}
+// packed weights live in one arena with a native-image mirror at the same offsets (as handle.cpp lays them out)
+static char *g_arena = nullptr, *g_mirror = nullptr;
+static size_t g_used = 0;
+static const float4* rnd_w(size_t n, unsigned seed) {
+  const size_t cap = (size_t)64 << 20;
+  if (!g_arena) { CK(hipMalloc(&g_arena, cap)); CK(hipMalloc(&g_mirror, cap)); }
+  float* p = (float*)(g_arena + g_used);
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p, n, seed, 0.05f);
+  CK(poem_launch_native16(p, g_mirror + g_used, n * 4, 0));
+  g_used += n * 4;
+  return (const float4*)p;
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 2, C = 256, M = 799 * B;
+  const size_t MC = (size_t)M * C;
+  ChainArgs a{};
+  a.M = M; a.tile_p = 3; a.eps = 1e-12f;
+  a.x = rnd(MC, 1); a.ldx = C;
+  a.w1 = rnd_w((size_t)C * C, 2); a.b1 = rnd(C, 3);
+  a.res = rnd(MC, 4); a.ldres = C; a.res_mod = 0;
+  a.ln_g = rnd(C, 5); a.ln_b = rnd(C, 6);
+  a.y1 = rnd(MC, 7); a.ldy1 = C;
+  a.w2 = rnd_w((size_t)3 * C * C, 8); a.b2 = rnd(3 * C, 9); a.y2 = rnd(3 * MC, 10); a.ldy2 = 3 * C;
+  a.wf4 = rnd_w((size_t)5 * C * C, 11); a.bf4 = rnd(5 * C, 12);
+  a.wreg2 = rnd(3 * C, 13); a.breg2 = rnd(3, 14); a.xyz_in = rnd((size_t)M * 3, 15); a.xyz_out = rnd((size_t)M * 3, 16);
+  a.wout = rnd_w((size_t)4 * C * C, 17); a.bout = rnd(C, 18);
+  a.ln2_g = rnd(C, 19); a.ln2_b = rnd(C, 20); a.y3 = rnd(MC, 21); a.ldy3 = C;
+  a.native_delta = g_mirror - g_arena;
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int kinds[4] = {0, 1, 2, 3}, n2s[4] = {3, 1, 0, 2};
+  for (int ki = 0; ki < 4; ++ki) {
+    a.kind = kinds[ki]; a.n2 = n2s[ki];
+    for (int i = 0; i < 3; ++i) CK(poem_launch_chain16(&a, C, 0));
+    CK(hipDeviceSynchronize());
+    const int n = 20;
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < n; ++i) CK(poem_launch_chain16(&a, C, 0));
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    long long st[64]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(c16_stamps), sizeof(st)));
+    printf("B=%d kind %d n2=%d: %.1f us per launch (back to back).  block 0 stamps, us since start:", B, a.kind, a.n2, ms / n * 1e3);
+    const int last = a.kind == 3 ? 21 : 6;
+    for (int k = 1; k <= last; ++k) if (st[k] > st[0]) printf(" [%d] %.2f", k, (st[k] - st[0]) / 100.0);
+    printf("\n");
+    { long long z[64] = {}; CK(hipMemcpyToSymbol(HIP_SYMBOL(c16_stamps), z, sizeof(z))); }
+  }
+  return 0;
+}
