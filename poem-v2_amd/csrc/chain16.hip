@@ -24,6 +24,9 @@
 
 #include "chain.h"
 
+#ifndef POEM_C16_RING_MAX
+#define POEM_C16_RING_MAX 4      // RU * T16 up to which a tile runs the cross-phase weight ring on native images (gemm16_ring)
+#endif
 #ifndef POEM_C16_DEEP
 #define POEM_C16_DEEP 8
 #endif
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
     constexpr int RU = decltype(ru_tag)::value;
     constexpr int XS = 16 * RU;
     // one-unit tiles: the weight ring across the phases (gemm16_ring); taller tiles: gemm16's own prologue per phase
-    constexpr bool RING = RU * T16 <= 2 && KCH % 8 == 0 && KCH >= 16;
+    constexpr bool RING = RU * T16 <= POEM_C16_RING_MAX && T16 == 2 && KCH % 8 == 0 && KCH >= 16;
     constexpr int DEPTH = RING ? ((KIND == 3 && KCH >= 32) ? POEM_C16_DEEP : 8) : 1;      // D2 runs two waves per SIMD: 256 registers
     float2 ring[DEPTH][T16];
     const WSrc none{frag_rsrc(A.w1, 0u), 0, 0, false};
