@@ -32,7 +32,9 @@
 #endif
 #ifdef POEM_C16_STAMPS   // tools/lab/c16_lab only: 100 MHz ticks at the phase boundaries of block 0's wave 0
 __device__ long long c16_stamps[64];
-#define C16_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) c16_stamps[(k)] = wall_clock64(); } while (0)
+__device__ long long c16_blocks[1024 * 4];      // per block: start, end (100 MHz ticks), units, XCC id
+#define C16_STAMP(k) do { if ((blockIdx.x == 0 || blockIdx.x == 256) && threadIdx.x == 0) c16_stamps[(k) + (blockIdx.x ? 32 : 0)] = wall_clock64(); \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) { if ((k) == 0) c16_blocks[blockIdx.x * 4] = wall_clock64(); else c16_blocks[blockIdx.x * 4 + 1] = wall_clock64(); } } while (0)
 #else
 #define C16_STAMP(k) do { } while (0)
 #endif
@@ -257,7 +259,19 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
   const int ru = tb + (layer < te ? 1 : 0);
   if (ru <= 0) return;
   const int tile_row0 = (cu_lo + layer * tb + min(layer, te)) * 16;
+#ifdef POEM_C16_SKEW      // tools/lab only: the second tile of a CU starts this many 100 MHz ticks late (do co-resident tiles in lockstep lose time?)
+  if (layer == 1) { const long long t0_ = wall_clock64(); while (wall_clock64() - t0_ < POEM_C16_SKEW) __builtin_amdgcn_s_sleep(8); }
+#endif
   C16_STAMP(0);
+#ifdef POEM_C16_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    c16_blocks[blockIdx.x * 4 + 2] = (long long)(((xcc & 0xf) << 12) | (((hwid >> 13) & 7) << 8) | (((hwid >> 12) & 1) << 4) | ((hwid >> 8) & 0xf));
+    c16_blocks[blockIdx.x * 4 + 3] = ru;
+  }
+#endif
 
   auto run_tile = [&](auto ru_tag, const int row0) {
     constexpr int RU = decltype(ru_tag)::value;
@@ -282,9 +296,22 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
     // one GEMM phase: D (+)= W_cur X; RING: the ring holds cur's first chunks and leaves with nxt's
     auto phase = [&](auto init_tag, const WSrc& cur, const WSrc& nxt, const float* X, f32x4 (&acc)[T16][RU]) {
       constexpr bool INIT0 = decltype(init_tag)::value;
+#ifdef POEM_C16_PRIO
+      // Two tiles share a CU (kinds A, C, D1) and the arbiter serves the oldest wave: next to the other tile's MFMA stream the
+      // VALU / LDS / memory instructions of an epilogue (bias, residual, LayerNorm, write-back) wait for a free slot one by one --
+      // the younger tile's LayerNorm took 35 us instead of 2 (tools/lab/c16_lab).  Everything outside the GEMM loops runs at
+      // priority 3, the loops at 0: an epilogue is a few hundred instructions, the MFMAs fill every slot they leave.
+      if (KIND != 3) __builtin_amdgcn_s_setprio(0);
+#endif
       if constexpr (RING) gemm16_ring<KCH, XSP, RU, T16, INIT0, DEPTH>(cur, nxt, X, acc, ring, lane);
       else gemm16<KCH, XSP, RU, T16, INIT0>(cur.rs, cur.base, cur.stride, X, acc, lane);
+#ifdef POEM_C16_PRIO
+      if (KIND != 3) __builtin_amdgcn_s_setprio(3);
+#endif
     };
+#ifdef POEM_C16_PRIO
+    if (KIND != 3) __builtin_amdgcn_s_setprio(3);
+#endif
     using init_t = std::integral_constant<bool, true>;
     using accum_t = std::integral_constant<bool, false>;
     // the first phase's weights are requested before the tile's fill (behind it where the fill combines the attention's

@@ -4,6 +4,7 @@
 #include "../../poem-v2_amd/csrc/chain16.hip"
 #include <cstdio>
 #include <vector>
+#include <map>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 __global__ void fill_kernel(float* p, size_t n, unsigned seed, float scale) {
@@ -63,7 +64,33 @@ int main(int argc, char** argv) {
     printf("B=%d kind %d n2=%d: %.1f us per launch (back to back).  block 0 stamps, us since start:", B, a.kind, a.n2, ms / n * 1e3);
     const int last = a.kind == 3 ? 21 : 6;
     for (int k = 1; k <= last; ++k) if (st[k] > st[0]) printf(" [%d] %.2f", k, (st[k] - st[0]) / 100.0);
+    printf("\n    block 256 (same CU), us since block 0's start:");
+    for (int k = 0; k <= last; ++k) if (st[32 + k] > st[0]) printf(" [%d] %.2f", k, (st[32 + k] - st[0]) / 100.0);
     printf("\n");
+    {
+      std::vector<long long> bl(1024 * 4);
+      CK(hipMemcpyFromSymbol(bl.data(), HIP_SYMBOL(c16_blocks), bl.size() * 8));
+      long long t0 = 1LL << 62, t1 = 0; int nb = 0;
+      for (int b = 0; b < 1024; ++b) if (bl[4 * b]) { t0 = std::min(t0, bl[4 * b]); t1 = std::max(t1, bl[4 * b + 1]); ++nb; }
+      double s_late = 0, dur = 0, dmax = 0; long long smax = 0;
+      for (int b = 0; b < 1024; ++b) if (bl[4 * b]) { s_late += bl[4 * b] - t0; smax = std::max(smax, bl[4 * b] - t0); dur += bl[4 * b + 1] - bl[4 * b]; dmax = std::max(dmax, (double)(bl[4 * b + 1] - bl[4 * b])); }
+      printf("    %d blocks: first start -> last end %.1f us; block start after the first: avg %.1f max %.1f us; block duration avg %.1f max %.1f us\n",
+             nb, (t1 - t0) / 100.0, s_late / nb / 100.0, smax / 100.0, dur / nb / 100.0, dmax / 100.0);
+      {   // by physical CU: blocks, units, when the CU's last block ended
+        std::map<long long, std::vector<int>> cu;
+        for (int b = 0; b < 1024; ++b) if (bl[4 * b]) cu[bl[4 * b + 2]].push_back(b);
+        std::map<std::pair<int, int>, std::pair<int, double>> h;      // (blocks, units) -> (CUs, sum of end times)
+        for (auto& kv : cu) {
+          int u = 0; long long e = 0;
+          for (int b : kv.second) { u += (int)bl[4 * b + 3]; e = std::max(e, bl[4 * b + 1]); }
+          auto& x = h[{(int)kv.second.size(), u}]; x.first++; x.second += (e - t0) / 100.0;
+        }
+        printf("    physical CUs %zu; (blocks, units) on a CU: CUs, avg end us:", cu.size());
+        for (auto& kv : h) printf(" (%d,%d): %d, %.0f;", kv.first.first, kv.first.second, kv.second.first, kv.second.second / kv.second.first);
+        printf("\n");
+      }
+      std::vector<long long> z(1024 * 4, 0); CK(hipMemcpyToSymbol(HIP_SYMBOL(c16_blocks), z.data(), z.size() * 8));
+    }
     { long long z[64] = {}; CK(hipMemcpyToSymbol(HIP_SYMBOL(c16_stamps), z, sizeof(z))); }
   }
   return 0;
