@@ -178,7 +178,9 @@ struct HeadRun {
       mt.out = p.bps_feat; mt.B = B; mt.S = S; mt.h2_tiled = 1;
       mt.group_min_views = sm.group_min_views; mt.views_dev = sm.views_dev;
       sm.xcd_order = h->group_xcd;
-      if (group_ok) {
+      // (a batch size whose view capacity stays below the threshold can never take the grouped kernel: no launch at all --
+      //  its early exit still costs ~6 us in front of a small batch's forward; the graph is keyed by the batch size, so is this)
+      if (group_ok && plan_views >= sm.group_min_views) {
         SampleGroupArgs sg{};
         sg.sm = sm; sg.w2 = mt.w0; sg.b2 = mt.b0; sg.w3 = mt.w1; sg.b3 = mt.b1; sg.out = p.bps_feat;
         HIPCHK(poem_launch_sample_group(&sg, C, st));
