@@ -621,6 +621,46 @@ def test_chain_kernels_on_both_matrix_shapes_are_bit_identical(name):
         assert torch.equal(got[2][k], got[1][k]), k
 
 
+@pytest.mark.parametrize("views", [[8], [8, 8], [3, 10, 1, 6, 8, 2], [8] * 12])
+def test_round5_scheduling_switches_and_tile_heights_change_no_bit(views):
+    """Round 5's small-batch work is scheduling only: `d2_first` / `wait_merge` (which successor of a launch the replayed graph
+    keeps on its hardware queue; which launch carries a cross-stream wait) and the chain kernels' one- and two-unit tiles on the
+    weight ring over native 16x16x4 images (chain16.hip; batches of 1-12 samples put 1-3 units on a CU, i.e. every ring /
+    non-ring tile height).  Graph replays with every switch flipped, the 32-row chain kernels (no ring, no native images) and
+    plain launches give the same bits, stage taps included."""
+    spec = dict(embed=256, nsample=4096, views=views, seed=55, parametric=False)
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(case_setup(spec)[3], DEV)
+    eng = head._engine_for(torch.device(DEV))
+    eng.enable_taps(True)
+    B, C, Q = len(views), 256, 799
+
+    def run():
+        with torch.no_grad():
+            for _ in range(3):                                   # the third forward replays the captured graph
+                res = head(feat, metas, rj)
+        out = {"out": res["all_coords_preds"].cpu()}
+        out.update({f"b{i}.{k}": eng.tap(f"b{i}.{k}", (B, Q, 3 if k == "xyz" else C)).cpu()
+                    for i in range(3) for k in ("h_cross", "f_self", "f_cross", "feats", "xyz")})
+        return out
+
+    want = run()
+    assert bool(torch.isfinite(want["out"]).all())
+    settings = [dict(d2_first=0), dict(wait_merge=0), dict(wait_merge=7), dict(d2_first=0, wait_merge=0), dict(chain_tile=1),
+                dict(chain_tile=3), dict(graphs=0)]
+    defaults = dict(d2_first=1, wait_merge=-1, chain_tile=0, graphs=1)
+    for st in settings:
+        for k, v in st.items():
+            eng.set_option(k, v)
+        got = run()
+        for k, v in defaults.items():
+            eng.set_option(k, v)
+        for k in want:
+            assert torch.equal(want[k], got[k]), (st, k, float((want[k] - got[k]).abs().max()))
+    assert eng.graph_stats()["replays"] >= 1
+    eng.enable_taps(False)
+
+
 @pytest.mark.parametrize("name", ["small", "medium", "large", "ragged", "mediummano", "medium_hot"])
 def test_row_tile_chains_vs_operator_launches(name):
     """csrc/chain.hip (default): the query-side Linears / residual adds / LayerNorms of a block as four LDS-resident chain
