@@ -825,6 +825,8 @@ __global__ __launch_bounds__((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512, 2) voi
 static int poem_num_cus() { return poem_device_cus(); }
 static std::atomic<int> g_kslab{1};                            // A/B switch (poem_set_option "gemm_kslab"; process-wide, scheduling only)
 extern "C" void poem_gemm_kslab(int on) { g_kslab = on; }
+static std::atomic<int> g_panel_narrow{1};                     // A/B switch (lab): narrower panels when the wide ones leave waves idle
+extern "C" void poem_gemm_panel_narrow(int on) { g_panel_narrow = on; }
 static std::atomic<int> g_panel_xcd_map{1};                    // A/B switch (poem_set_option "gemm_xcd_map"; process-wide, scheduling only)
 extern "C" void poem_gemm_xcd_map(int on) { g_panel_xcd_map = on; }
 
@@ -854,14 +856,21 @@ static hipError_t launch_gemm_split_impl(const float* X, int ldx, const void* Wp
                                          int act2, const PanelSegs& segs, hipStream_t s) {
   const bool seg = segs.seg_cols > 0;
   // panel kernel: N a multiple of 32*NT, panel (NT*K*128 B) within 128 KiB of LDS, the split on a panel boundary
+  // (a few row tiles -- a small batch's F1: M = 4096 B rows -- on wide panels leave most waves without a tile: the widest panel
+  //  that still gives every wave of the chip one (row tile, panel) pair; same fma chain per output element whatever the width)
+  const bool in_split_mode = g_explicit_split.img || (g_split_ctx.packed && (const char*)Wp >= g_split_ctx.packed &&
+                                                      (const char*)Wp < g_split_ctx.packed + g_split_ctx.bytes);
   int NT = 0;
+  const long wave_slots = 8L * poem_num_cus(), row_tiles = (M + 31) / 32;
   for (int c : {4, 2, 1})
     if (N % (32 * c) == 0 && (size_t)c * K * 128 <= 128 * 1024 && (act_split >= N || act_split % (32 * c) == 0) &&
-        (!seg || segs.seg_cols % (32 * c) == 0)) { NT = c; break; }
+        (!seg || segs.seg_cols % (32 * c) == 0)) {
+      NT = c;
+      if (row_tiles * (N / (32 * c)) >= wave_slots || !g_panel_narrow || K > 256 || in_split_mode) break;
+    }
   // deep K leaves room for a single 32-column tile per panel, which re-reads X every 8 MFMAs: the K-slab kernel (weights
   // staged through LDS slab by slab) takes those shapes -- POEM-huge's Linears, the K = 4C feed-forward output
-  const bool split_mode = g_explicit_split.img || (g_split_ctx.packed && (const char*)Wp >= g_split_ctx.packed &&
-                                                   (const char*)Wp < g_split_ctx.packed + g_split_ctx.bytes);
+  const bool split_mode = in_split_mode;
   if (NT <= 1 && !split_mode && g_kslab && kslab_applies(X, ldx, M, N, K, act_split) && (!seg || (segs.seg_cols % 64 == 0 && M % 32 == 0)))
     return launch_gemm_kslab(X, ldx, Wp, bias, R, ldr, Y, ldy, M, N, K, act, act_split, act2, segs, s);
   if (!seg && NT == 1 && N >= 64 && K >= 512 && !(act_split < N && act2 != act)) NT = 0;
