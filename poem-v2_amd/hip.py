@@ -132,11 +132,15 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.poem_abi_version() != ABI_VERSION:      # a stale .so would read PoemConfig with another layout
+            raise RuntimeError(f"{LIB_PATH} has ABI {L.poem_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild it "
+                               "(python -c 'import __graft_entry__ as g; g.build()')")
         _LIB = L
     return _LIB
 
 
 POEM_E_UNSUPPORTED = -4      # include/poem_hip.h
+ABI_VERSION = 2              # poem_abi_version(): 2 = poem_config_t with the positional-encoding switches (round 5)
 
 
 def check(rc, what=""):
