@@ -983,8 +983,9 @@ def test_projections_outside_the_image_and_behind_the_camera(fused):
         assert float(g[3].abs().max()) == 0.0 and float(g[0].abs().max()) > 0.0
 
 
-@pytest.mark.parametrize("embed,fh,fw,img", [(128, 32, 32, 512), (256, 8, 24, (384, 128))])
-def test_other_feature_map_and_image_sizes_through_the_whole_path(embed, fh, fw, img):
+@pytest.mark.parametrize("embed,fh,fw,img,petr", [(128, 32, 32, 512, False), (256, 8, 24, (384, 128), False),
+                                                  (128, 32, 32, 512, True), (256, 8, 24, (384, 128), True)])
+def test_other_feature_map_and_image_sizes_through_the_whole_path(embed, fh, fw, img, petr):
     """The reference head is size-agnostic (ptEmb_head.py:831-838: inp_res from the batch, the feature map's own H x W in the
     positional table, grid_sample on whatever map arrives); PoemConfig.feat_h / feat_w carry it here.  512 x 512 images with
     32 x 32 features, and a non-square map / image: whole path against the oracle, fused and operator front ends, and a sample
@@ -999,6 +1000,8 @@ def test_other_feature_map_and_image_sizes_through_the_whole_path(embed, fh, fw,
     b["img_metas"]["cam_intr"] = K
     b["img_metas"]["inp_img_shape"] = (iw, ih)
     spec = dict(embed=embed, nsample=4096, views=views, seed=91, parametric=False)
+    if petr:      # the frustum grid follows the feature map and the (non-square) image: position_embeding's (h, w) naming, :115
+        spec.update(petr=True, lid=True, depth_num=8, depth_start=0.05, depth_end=1.4)
     cfg, w, consts, _ = case_setup(spec)
     taps = {}
     orc = run_oracle(cfg, w, consts, b, taps=taps)["all_coords_preds"]
