@@ -12,6 +12,9 @@
 // channel, registers = neighbours -- which makes the softmax over the 32 neighbours register-local (+1 exchange
 // between half-waves) and the v_j gathers coalesced.  Wave w owns output channel tiles [w*TPW, (w+1)*TPW).
 #include "common.h"
+#ifndef POEM_VA_XCD_SAMPLES
+#define POEM_VA_XCD_SAMPLES 1
+#endif
 #include <algorithm>
 #include <cstdlib>
 
@@ -188,6 +191,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
 
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
   int b = item / groups, ig = item % groups;
+  if (MODE == 0 && POEM_VA_XCD_SAMPLES && gridDim.x == (unsigned)total && (total & 7) == 0) {
+    // block ids go round-robin over the 8 XCDs: XCD x takes the x-th eighth of the (sample, query group) list, i.e. whole
+    // samples -- a sample's key / value rows (8 MB at S = 4096, C = 256) are then gathered through ONE L2 instead of all eight
+    const int it = (item & 7) * (total >> 3) + (item >> 3);
+    b = it / groups; ig = it % groups;
+  }
   if (MODE == 2) {
     if (groups % 8 == 0) {   // block ids go round-robin over the 8 XCDs: XCD x walks groups x, x + 8, ... sample by sample
       const int r = item >> 3;
