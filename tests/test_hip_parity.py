@@ -1149,7 +1149,12 @@ def test_ragged_stream_fresh_layout_every_batch_replays_one_graph():
     lib/opt.py:27-30 upstream).  300 distinct layouts through one head: every result equals the plain-launch path's bit for bit,
     the whole stream is served by ONE captured graph per batch size (no capture, no instantiate, no blocking upload per
     layout), and nothing accumulates: the process-wide count of parked graph execs does not move."""
+    import gc
     import random
+    # (the parked-exec count is process-wide: heads of EARLIER tests that the garbage collector has not freed yet would park
+    #  their execs in the middle of this stream -- seen once as 43 -> 65 -- so they are collected before the count is taken)
+    gc.collect()
+    torch.cuda.synchronize()
     spec = dict(embed=128, nsample=4096, views=[2, 3], seed=71, parametric=False)
     head = build_hip_head(spec, DEV)
     rng = random.Random(7)
@@ -1175,6 +1180,7 @@ def test_ragged_stream_fresh_layout_every_batch_replays_one_graph():
         head(*max(items, key=lambda it: len(it[1]["cam_view_num"])))      # the grow-only workspace at its high-water mark (the
         head(*items[0])                                                   # workspace pointer is part of a graph's key)
         eng = head._engine
+        gc.collect()
         before = eng.graph_stats()
         outs = [head(*it)["all_coords_preds"].clone() for it in items]
         torch.cuda.synchronize()
@@ -1248,6 +1254,8 @@ def test_retired_graph_execs_are_reused_not_accumulated():
     one over through hipGraphExecUpdate.  Ten head life cycles must not grow the parked list beyond what one cycle leaves, and
     the re-used execs must compute the same bits as fresh ones."""
     import gc
+    gc.collect()                                   # (heads of earlier tests park their execs now, not in the middle of the count)
+    torch.cuda.synchronize()
     spec = dict(embed=128, nsample=4096, views=[2, 3], seed=72, parametric=False)
     cfg, w, consts, batch = case_setup(spec)
     feat, metas, rj = batch_to(batch, DEV)
