@@ -425,9 +425,22 @@ int poem_mano_to_openpose(const float* j_regressor, const float* verts, float* j
  * pytorch3d rotation_6d_to_matrix -> matrix_to_quaternion -> quaternion_to_axis_angle): params (B,106) = 16 six-dimensional
  * rotations then 10 betas -> pose_aa (B,48), betas (B,10). */
 int poem_rot6d_to_axis_angle(const float* params, float* pose_aa, float* betas, int batch, void* stream);
-int poem_mano_lbs(const float* pose_aa, const float* betas, const float* v_template, const float* shapedirs,
-                  const float* posedirs, const float* j_regressor, const float* weights, int batch, int center_idx,
-                  float* verts, float* joints, void* stream);
+/* Round 6: the five asset arrays are re-laid once into a TABLE (poem_mano_table_bytes() bytes of device memory, 16-byte
+ * aligned; poem_mano_prepare at layer creation -- coefficient-major blend shapes, joint regression composed with template and
+ * shape basis in fp64, joint-major skinning weights: csrc/mano.hip) and every call takes that table: one launch over
+ * (13 vertex tiles x batch) blocks instead of one block per sample. */
+size_t poem_mano_table_bytes(void);
+int poem_mano_prepare(const float* v_template, const float* shapedirs, const float* posedirs, const float* j_regressor,
+                      const float* weights, void* table, void* stream);
+int poem_mano_lbs(const float* pose_aa, const float* betas, const void* table, int batch, int center_idx, float* verts,
+                  float* joints, void* stream);
+/* The MANO layer INSIDE the forward of a parametric handle (get_parametric_output, pt_metro_transformer.py:139-151, and the last
+ * layer of ptEmb_head.py:953-958): with a table attached, poem_head_forward runs Q3 -> Linears -> rot6d -> poem_mano_lbs in its
+ * captured launch graph and writes the last layer of out_xyz as nan_to_num(joints | verts) + centre itself;
+ * poem_decoder_forward replaces the last layer's rows by (joints | verts).  pose_aa / betas are returned as before.  The table is
+ * caller-owned and must stay valid while attached; table = NULL detaches (the caller then runs its own layer and
+ * poem_finalize_parametric).  POEM_E_UNSUPPORTED on a handle without PARAMETRIC_OUTPUT. */
+int poem_attach_mano(poem_handle_t h, const void* table, int center_idx);
 /* Crop / warp / normalise every view of a batch in one launch (replaces the per-view host chain of
  * lib/utils/transform.py:153-170: cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT 0) -> colour jitter -> to_tensor ->
  * normalize(0.5, 1)).  src: the raw uint8 HxWx3 images back to back in one device blob; src_offsets (views) byte offset

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain_ke
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[tp][p][4 * g + e] + (&bb.x)[e];
-            if (act == 1) v = fmaxf(v, 0.f);
+            if (act == 1) v = relu_nan(v);
             if (act == 2) v = gelu_erf(v);
             acc[tp][p][4 * g + e] = v;
           }

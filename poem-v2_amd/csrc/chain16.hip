@@ -30,10 +30,17 @@
 #ifndef POEM_C16_DEEP
 #define POEM_C16_DEEP 8
 #endif
+#ifndef POEM_C16_NATIVE_ALL
+#define POEM_C16_NATIVE_ALL 1    // tall tiles (gemm16) read the native 16x16x4 weight images too (round 6)
+#endif
 #ifdef POEM_C16_STAMPS   // tools/lab/c16_lab only: 100 MHz ticks at the phase boundaries of block 0's wave 0
 __device__ long long c16_stamps[64];
 __device__ long long c16_blocks[1024 * 4];      // per block: start, end (100 MHz ticks), units, XCC id
+// per-wave trace of the two blocks that share CU 0 (blocks 0 and 256): s_memtime (shader clock) of every wave at every stamp
+__device__ long long c16_wtrace[2 * 8 * 40];
+__device__ unsigned c16_whw[2 * 8];
 #define C16_STAMP(k) do { if ((blockIdx.x == 0 || blockIdx.x == 256) && threadIdx.x == 0) c16_stamps[(k) + (blockIdx.x ? 32 : 0)] = wall_clock64(); \
+    if ((blockIdx.x == 0 || blockIdx.x == 256) && (threadIdx.x & 63) == 0 && (k) < 40) c16_wtrace[((blockIdx.x ? 8 : 0) + (threadIdx.x >> 6)) * 40 + (k)] = clock64(); \
     if (threadIdx.x == 0 && blockIdx.x < 1024) { if ((k) == 0) c16_blocks[blockIdx.x * 4] = wall_clock64(); else c16_blocks[blockIdx.x * 4 + 1] = wall_clock64(); } } while (0)
 #else
 #define C16_STAMP(k) do { } while (0)
@@ -53,15 +60,42 @@ __device__ __forceinline__ float from_upper(float v) {
   return __uint_as_float(r[1]);
 }
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 frag_load2(__amdgpu_buffer_rsrc_t rs, int lane_off_bytes, int scalar_off_bytes) {
+  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off_bytes, scalar_off_bytes, 0);
+  return float2{__uint_as_float(v[0]), __uint_as_float(v[1])};
+}
+template <bool NAT>
+__device__ __forceinline__ auto frag_load_nat(__amdgpu_buffer_rsrc_t rs, int lane_off_bytes, int scalar_off_bytes) {
+  if constexpr (NAT) return frag_load2(rs, lane_off_bytes, scalar_off_bytes);
+  else return frag_load(rs, lane_off_bytes, scalar_off_bytes);
+}
+#ifndef POEM_C16_MMA_PRIO
+#define POEM_C16_MMA_PRIO 0      // (lab switch: measured in the step -0.2 % with two co-resident tiles per CU; it pays only for one block per CU)
+#endif
+#if POEM_C16_MMA_PRIO
+#define C16_PRIO_UP __builtin_amdgcn_s_setprio(1);
+#define C16_PRIO_DOWN __builtin_amdgcn_s_setprio(0);
+#else
+#define C16_PRIO_UP
+#define C16_PRIO_DOWN
+#endif
+
 // D[c'][row] (+)= sum_k W[c'][k0 + k] X[k][row] for this wave's T16 channel tiles and RU row units.  wbase: byte offset of
 // the wave's first 32-row tile at the contraction's start; tile_stride: bytes between consecutive 32-row tiles.
-template <int KCH, int XSP16, int RU, int T16, bool INIT0>
+// NAT (round 6): the weights' NATIVE 16x16x4 images (see frag_load2 below) for the tall tiles too -- one 8-byte load per lane
+// and 16-channel tile instead of a 16-byte load of which half is used, and no selects: tools/lab/c16_issue_lab measures the four
+// v_cndmask of a chunk (+ the s_nop the VALU -> MFMA hazard adds) at 8 % of the loop next to its 16 MFMAs, more than the eight LDS
+// reads (3 %) or the two fragment loads (1 %).  PRIO: the MFMA burst of a chunk at priority 1 -- the waves of the other
+// co-resident tile then issue their VALU / LDS / memory instructions in the gaps between bursts instead of inside them
+// (same lab: 0.88 -> 0.93 of the pipe with four waves per SIMD).
+template <int KCH, int XSP16, int RU, int T16, bool INIT0, bool NAT = false>
 __device__ __forceinline__ void gemm16(const __amdgpu_buffer_rsrc_t wrs, int wbase, int tile_stride, const float* __restrict__ X,
                                        f32x4 (&acc)[T16][RU], int lane) {
   static_assert(KCH % 4 == 0 && T16 % 2 == 0, "shape");
   const int j = lane & 15, g = lane >> 4;
   const bool hi = g >= 2;
-  const int loff0 = (j + 32 * (g & 1)) * 16, loff1 = loff0 + 256;
+  const int loff0 = NAT ? lane * 8 : (j + 32 * (g & 1)) * 16, loff1 = loff0 + (NAT ? 512 : 256);
   const float* xc = X + (4 * (g & 1) + (g >> 1)) * XSP16 + j;
   if (INIT0) {
 #pragma unroll
@@ -81,11 +115,16 @@ __device__ __forceinline__ void gemm16(const __amdgpu_buffer_rsrc_t wrs, int wba
 #define C16_MMA(A, XR)                                                                                        \
   {                                                                                                           \
     float w1_[T16], w2_[T16];                                                                                 \
-    _Pragma("unroll") for (int t = 0; t < T16; ++t) { w1_[t] = hi ? A[t].y : A[t].x; w2_[t] = hi ? A[t].w : A[t].z; } \
+    _Pragma("unroll") for (int t = 0; t < T16; ++t) {                                                         \
+      if constexpr (NAT) { w1_[t] = A[t].x; w2_[t] = A[t].y; }                                                \
+      else { w1_[t] = hi ? A[t].y : A[t].x; w2_[t] = hi ? A[t].w : A[t].z; }                                  \
+    }                                                                                                         \
+    C16_PRIO_UP                                                                                               \
     _Pragma("unroll") for (int u = 0; u < RU; ++u)                                                            \
       _Pragma("unroll") for (int t = 0; t < T16; ++t) acc[t][u] = mfma16(w1_[t], XR[0][u], acc[t][u]);        \
     _Pragma("unroll") for (int u = 0; u < RU; ++u)                                                            \
       _Pragma("unroll") for (int t = 0; t < T16; ++t) acc[t][u] = mfma16(w2_[t], XR[1][u], acc[t][u]);        \
+    C16_PRIO_DOWN                                                                                             \
   }
   if constexpr (RU * T16 <= 2 && KCH % 8 == 0) {
     // small tiles (one or two units of 16 rows: a chunk is 2 RU T16 MFMAs of 32 cycles -- 128 to 256 cycles): weight fragments
@@ -113,12 +152,14 @@ __device__ __forceinline__ void gemm16(const __amdgpu_buffer_rsrc_t wrs, int wba
     }
 #undef C16_LOADR
   } else {
-  float4 a0[T16], a1[T16], a2[T16], a3[T16];
+  std::conditional_t<NAT, float2, float4> a0[T16], a1[T16], a2[T16], a3[T16];
 #define C16_LOADW(A, KCI)                                                                                     \
   {                                                                                                           \
     const int kq_ = min((KCI), KCH - 1);                                                                      \
-    _Pragma("unroll") for (int t = 0; t < T16; ++t)                                                           \
-        A[t] = frag_load(wrs, (t & 1) ? loff1 : loff0, wbase + (t >> 1) * tile_stride + kq_ * 1024);          \
+    _Pragma("unroll") for (int t = 0; t < T16; ++t) {                                                         \
+      if constexpr (NAT) A[t] = frag_load_nat<NAT>(wrs, (t & 1) ? loff1 : loff0, wbase + (t >> 1) * tile_stride + kq_ * 1024); \
+      else A[t] = frag_load_nat<NAT>(wrs, (t & 1) ? loff1 : loff0, wbase + (t >> 1) * tile_stride + kq_ * 1024); \
+    }                                                                                                         \
   }
   C16_LOADW(a0, 0)
   C16_READX(xa, 0)
@@ -157,11 +198,6 @@ struct WSrc {
 //   N[half][lane = 16 g + i] = float2( F[16 half + i + 32 (g & 1)].comp[g >> 1], .comp[(g >> 1) + 2] ),   F = the block's 64 float4
 // -- so a 16-channel tile's chunk is one fully coalesced 8-byte load per lane (512 bytes): half the addresser time, half the ring
 // registers, no selects: 3.4-4.2 us per phase.  Built once per weight at poem_create (native16_kernel), same offsets in a mirror.
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2 frag_load2(__amdgpu_buffer_rsrc_t rs, int lane_off_bytes, int scalar_off_bytes) {
-  const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off_bytes, scalar_off_bytes, 0);
-  return float2{__uint_as_float(v[0]), __uint_as_float(v[1])};
-}
 #ifdef POEM_C16_NOLOADS      // tools/lab only: the loop without its weight stream (what the MFMA / LDS side alone costs)
 #define C16R_LOAD(SRC, D, KQ) if ((KQ) < 0) { _Pragma("unroll") for (int t = 0; t < T16; ++t) ar[D][t] = frag_load2((SRC).rs, loff0, (SRC).base); }
 #else
@@ -243,7 +279,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* X0 = smem;                       // C * XSP
   float* X1 = X0 + C * XSP;               // C * XSP (kind D2 only)
-  float* red = KIND == 3 ? X1 + C * XSP : X0 + C * XSP;   // NW * XROWS partial row sums
+  float* red = KIND == 3 ? X1 + C * XSP : X0 + C * XSP;   // 2 x NW * XROWS partial row sums (one buffer per LayerNorm pass)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, g = lane >> 4;
   const int cw0 = wv * T16 * 16;          // this wave's first channel within a C-wide pass
   const int tile0 = wv * (T16 / 2);       // ... its first 32-row tile of a packed image
@@ -271,6 +307,11 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
     c16_blocks[blockIdx.x * 4 + 2] = (long long)(((xcc & 0xf) << 12) | (((hwid >> 13) & 7) << 8) | (((hwid >> 12) & 1) << 4) | ((hwid >> 8) & 0xf));
     c16_blocks[blockIdx.x * 4 + 3] = ru;
   }
+  if ((blockIdx.x == 0 || blockIdx.x == 256) && (threadIdx.x & 63) == 0) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    c16_whw[(blockIdx.x ? 8 : 0) + (threadIdx.x >> 6)] = hwid;
+  }
 #endif
 
   auto run_tile = [&](auto ru_tag, const int row0) {
@@ -278,11 +319,12 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
     constexpr int XS = 16 * RU;
     // one-unit tiles: the weight ring across the phases (gemm16_ring); taller tiles: gemm16's own prologue per phase
     constexpr bool RING = RU * T16 <= POEM_C16_RING_MAX && T16 == 2 && KCH % 8 == 0 && KCH >= 16;
+    constexpr bool NAT = POEM_C16_NATIVE_ALL && (C == 128 || C == 256);      // (the widths whose handle carries the native mirror)
     constexpr int DEPTH = RING ? ((KIND == 3 && KCH >= 32) ? POEM_C16_DEEP : 8) : 1;      // D2 runs two waves per SIMD: 256 registers
     float2 ring[DEPTH][T16];
     const WSrc none{frag_rsrc(A.w1, 0u), 0, 0, false};
     // (RING reads the weights' native 16x16x4 images: the same offsets, A.native_delta bytes away -- native16_kernel below)
-    auto img = [&](const float4* w) { return reinterpret_cast<const char*>(w) + (RING ? A.native_delta : 0); };
+    auto img = [&](const float4* w) { return reinterpret_cast<const char*>(w) + ((RING || NAT) ? A.native_delta : 0); };
     auto src_w1 = [&]() { return WSrc{frag_rsrc(img(A.w1), CC4), __builtin_amdgcn_readfirstlane(tile0 * KCH * 1024), KCH * 1024, true}; };
     auto src_w2 = [&](int pass) {
       return WSrc{frag_rsrc(img(A.w2), (unsigned)A.n2 * CC4), __builtin_amdgcn_readfirstlane((pass * NTILE + tile0) * KCH * 1024), KCH * 1024, pass < A.n2};
@@ -304,7 +346,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
       if (KIND != 3) __builtin_amdgcn_s_setprio(0);
 #endif
       if constexpr (RING) gemm16_ring<KCH, XSP, RU, T16, INIT0, DEPTH>(cur, nxt, X, acc, ring, lane);
-      else gemm16<KCH, XSP, RU, T16, INIT0>(cur.rs, cur.base, cur.stride, X, acc, lane);
+      else gemm16<KCH, XSP, RU, T16, INIT0, NAT>(cur.rs, cur.base, cur.stride, X, acc, lane);
 #ifdef POEM_C16_PRIO
       if (KIND != 3) __builtin_amdgcn_s_setprio(3);
 #endif
@@ -328,7 +370,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[t][u][e] + (&bb.x)[e];
-            if (act == 1) v = fmaxf(v, 0.f);
+            if (act == 1) v = relu_nan(v);
             if (act == 2) v = gelu_erf(v);
             acc[t][u][e] = v;
           }
@@ -393,19 +435,23 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
           }
           s[u] = p + __shfl_xor(p, 16, 64);                // lanes g = 2, 3: (half-wave 0's sum) + (half-wave 1's)
         }
-        __syncthreads();                                    // previous readers of `red` are done
+        C16_STAMP(30 + 2 * pass);
+        // (one buffer per pass, one LayerNorm per tile: nobody can still be reading what is written here -- round 6: the two
+        //  "previous readers are done" barriers are gone; a barrier next to the other tile's MFMA stream costs microseconds)
+        float* rp = red + pass * (NW * XROWS);
         if (g == 2)
 #pragma unroll
-          for (int u = 0; u < RU; ++u) red[wv * XROWS + 16 * u + j] = s[u];
+          for (int u = 0; u < RU; ++u) rp[wv * XROWS + 16 * u + j] = s[u];
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
           float t = 0.f;
 #pragma unroll
-          for (int w = 0; w < NW; ++w) t += red[w * XROWS + 16 * u + j];
+          for (int w = 0; w < NW; ++w) t += rp[w * XROWS + 16 * u + j];
           if (pass == 0) mean[u] = t / (float)C;
           else rstd[u] = 1.0f / sqrtf(t / (float)C + eps);
         }
+        C16_STAMP(31 + 2 * pass);
       }
 #pragma unroll
       for (int t = 0; t < T16; ++t) {
@@ -422,8 +468,10 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
       for (int pass = 0; pass < n; ++pass) {
         f32x4 acc[T16][RU];
         phase(init_t{}, src_w2(pass), src_w2(pass + 1), X, acc);
+        C16_STAMP(22 + 2 * pass);
         add_bias(acc, bias + pass * C, 0);
         to_global(acc, Y, ld, pass * C);
+        C16_STAMP(23 + 2 * pass);
       }
     };
 
@@ -603,7 +651,7 @@ __global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_
 
 template <int C, int NW, int KIND, int MAXRU>
 static hipError_t launch_chain16_k(const ChainArgs& a, int cus, hipStream_t s) {
-  const size_t lds = ((size_t)(KIND == 3 ? 2 : 1) * C * (16 * MAXRU + 4) + (size_t)NW * 16 * MAXRU) * sizeof(float);
+  const size_t lds = ((size_t)(KIND == 3 ? 2 : 1) * C * (16 * MAXRU + 4) + (size_t)2 * NW * 16 * MAXRU) * sizeof(float);
   auto kern = chain16_kernel<C, NW, KIND, MAXRU>;
   static std::atomic<unsigned long long> optin{0};
   if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), lds, optin); e != hipSuccess) return e;

@@ -90,6 +90,13 @@ __device__ __forceinline__ float4 frag_load(__amdgpu_buffer_rsrc_t rs, int lane_
   return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
 
+// ReLU as torch evaluates it: a NaN stays a NaN (v_max_f32 returns its other operand for a quiet NaN -- fmaxf(NaN, 0) = 0 -- and
+// would turn a poisoned sample into finite garbage: the reference's `torch.nan_to_num(interm_ref_pts)` in front of the
+// de-normalisation (ptEmb_head.py:944) relies on the NaN reaching it).  One compare + select instead of one max: used at the
+// Linear epilogues between the sampled features and the coordinate update, not inside the vector attention (whose values carry
+// the NaN past its own ReLUs).
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.f ? 0.f : v; }
+
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // Packed Linear weight image used by every MFMA kernel here ("fragment order"):

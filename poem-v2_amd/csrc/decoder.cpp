@@ -395,6 +395,9 @@ struct DecoderRun {
     HIPCHK(poem_launch_q3_flatten(feats, h->R(bb + B_FLAT_W), h->R(bb + B_FLAT_B), p.q3t, B, Q, C, s));
     HIPCHK(poem_launch_narrow_linear(p.q3t, C, h->R(bb + B_MANO_W), h->R(bb + B_MANO_B), nullptr, p.par, B, C, 106, s));
     HIPCHK(poem_launch_rot6d_to_aa(p.par, pose_aa, betas, B, s));
+    // the attached MANO layer (poem_attach_mano): mano_layer(pose_aa, betas) of get_parametric_output (:147-148 upstream) right
+    // here -- inside the captured body, no Python callable between the decoder and the de-normalisation
+    if (h->mano_table) HIPCHK(poem_launch_mano_lbs(pose_aa, betas, h->mano_table, p.mano_verts, p.mano_joints, B, h->mano_center, s));
     return POEM_OK;
   }
 

@@ -169,6 +169,11 @@ struct poem_handle_s {
   int small_batch = 3;
   int group_xcd = 1;         // sample_group_kernel's XCD-aware unit order (A/B switch)
   int group_min_views = 0;   // sample_group_kernel: 0 = by the chip (units >= 2 per CU), > 0 = this many views, -1 = never (forward.cpp)
+  // The MANO layer of the parametric tail inside the forward (poem_attach_mano): the prepared asset table of poem_mano_prepare
+  // (caller-owned device memory, must outlive the handle's forwards) and the layer's centre joint.  nullptr: the forward
+  // returns (pose, betas) and the caller runs its own layer + poem_finalize_parametric (rounds 1-5).
+  const float* mano_table = nullptr;
+  int mano_center = 9;
   int knn_fma = 0;           // neighbour distances with the fma contraction of pytorch3d's CUDA kernel (knn.hip); default: the CPU path's rounding
   int chain_tile = 0;        // chain row-tile height: 0 = per launch (chain.hip chain_tile_p), 1 = 32 rows, 2 = 64 rows (A/B)
   // The block-0 anchor tables are functions of the handle's constants only (template, anchors, weights): like the folded
@@ -244,6 +249,7 @@ struct Plan {
   // per block kept tensors (taps)
   float *h_cross[8], *f_self[8], *f_cross[8], *feats[8];
   float *q3t, *par, *attn_scratch, *g_pose, *g_betas;
+  float *mano_verts, *mano_joints;          // the attached MANO layer's output (B,778,3) / (B,21,3)
   float *canon_xyz, *tab_g[2], *tab_p[2];   // block-0 anchor tables (self, cross) of the head path
   float *anch_x[2], *anch_kv[2], *qeqp0;    // block 0: anchor rows of the key/value sources, their (k | v) rows; F2 on Q rows
   int32_t* ident;

@@ -232,7 +232,8 @@ struct HeadRun {
     //  batch's own view total: that total joins the key there)
     const std::vector<int64_t> key = {B, plan_views, fused_fe ? -1 : BN, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
                                       h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
-                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, poem_process_switches(), h->f1_split, h->va_p1, h->group_min_views, h->group_xcd, h->d2_first, h->wait_merge};
+                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, poem_process_switches(), h->f1_split, h->va_p1, h->group_min_views, h->group_xcd, h->d2_first, h->wait_merge,
+                                      (int64_t)(uintptr_t)h->mano_table, h->mano_center};
     poem_handle_s::GraphEntry* hit = nullptr;
     for (auto& g : h->graph_cache)
       if (g.key == key) { hit = &g; break; }
@@ -348,7 +349,9 @@ int poem_head_forward(poem_handle_t h, const float* mlvl_feat, const float* cam_
   if (rc < 0) return rc;
   if (rc == 0) ++h->plain_forwards;
   if (rc == 0 && (rc = run.body(run.s, pose_aa, betas)) != POEM_OK) return rc;
-  HIPCHK(poem_launch_finalize(run.p.xyz[1], run.p.centre, out_xyz, c.nblocks, batch, c.nquery, c.radius, run.s));
+  const bool mano = c.parametric && h->mano_table;      // the last layer = the attached MANO layer's output + centre
+  HIPCHK(poem_launch_finalize(run.p.xyz[1], run.p.centre, out_xyz, c.nblocks, batch, c.nquery, c.radius, mano ? run.p.mano_verts : nullptr,
+                              mano ? run.p.mano_joints : nullptr, run.s));
   register_taps(h, run.p, batch, run.BN, true);
   POEM_TRACE("head_forward done");
   return POEM_OK;
@@ -370,6 +373,8 @@ int poem_decoder_forward(poem_handle_t h, const float* query_xyz, const float* q
   const int rc = run_decoder(h, p, query_feat, pt_xyz, pt_feats, batch, pose_aa, betas, s);
   if (rc != POEM_OK) return rc;
   HIPCHK(hipMemcpyAsync(out_xyz_norm, p.xyz[1], n * 4 * c.nblocks, hipMemcpyDeviceToDevice, s));
+  if (c.parametric && h->mano_table)      // get_parametric_output: the last layer's rows are the MANO layer's (pt_metro_transformer.py:149-150)
+    HIPCHK(poem_launch_param_rows(p.mano_verts, p.mano_joints, out_xyz_norm + (size_t)(c.nblocks - 1) * n, batch, c.nquery, s));
   register_taps(h, p, batch, batch, false);
   return POEM_OK;
 }

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const float* __restrict__
             const float4 bb = *reinterpret_cast<const float4*>(bias + c0);
             v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
           }
-          if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (act == 1) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }
           if (act == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
           if (R) {
             const float4 rr = rp[(size_t)kco * 64];
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const float* __restrict__
           const int row = (mt0 + i) * 32 + mfma_row(e, h);
           if (row < M) {
             float v = acc[i][n][e] + bv;
-            if (act == 1) v = fmaxf(v, 0.f);
+            if (act == 1) v = relu_nan(v);
             if (act == 2) v = gelu_erf(v);
             if (R) v += R[(size_t)row * ldr + col];
             Y[(size_t)row * ldy + col] = v;
@@ -413,7 +413,7 @@ __device__ __forceinline__ void kslab_body(const float* __restrict__ X, int ldx,
             const float4 bb = *reinterpret_cast<const float4*>(bias + col0 + n * 32 + 8 * g + 4 * h);
             v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
           }
-          if (pact == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (pact == 1) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }
           yp[(size_t)(n * 4 + g) * 64] = v;
         }
     }
@@ -430,7 +430,7 @@ __device__ __forceinline__ void kslab_body(const float* __restrict__ X, int ldx,
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float4 v = make_float4(acc[i][n][4 * g] + bv, acc[i][n][4 * g + 1] + bv, acc[i][n][4 * g + 2] + bv, acc[i][n][4 * g + 3] + bv);
-          if (pact == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (pact == 1) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }
           yp[(size_t)g * 64] = v;
         }
       }
@@ -449,7 +449,7 @@ __device__ __forceinline__ void kslab_body(const float* __restrict__ X, int ldx,
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         v[e] = acc[i][n][e] + bv;
-        if (pact == 1) v[e] = fmaxf(v[e], 0.f);
+        if (pact == 1) v[e] = relu_nan(v[e]);
         if (pact == 2) v[e] = gelu_erf(v[e]);
       }
       if (row0 + 28 < M) {          // whole tile in range (rows row0 + {0..3} + 8 {0..3})
@@ -688,7 +688,7 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
               const float4 bb = *reinterpret_cast<const float4*>(bias + col0 + n * 32 + 8 * g + 4 * h);
               v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
             }
-            if (pact == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (pact == 1) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }
             if (GELU && pact == 2) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
             if (SPLIT && split_images) {
               // split images for the split cross attention: fragments (2c, 2c+1) of the fp32 image become the hi | lo f16
@@ -728,7 +728,7 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
 #pragma unroll
           for (int e = 0; e < 16; e += 2) {
             const f32x2 t = f32x2{acc[i][n][e], acc[i][n][e + 1]} + f32x2{bv[n], bv[n]};
-            v[e] = fmaxf(t[0], 0.f); v[e + 1] = fmaxf(t[1], 0.f);
+            v[e] = relu_nan(t[0]); v[e + 1] = relu_nan(t[1]);
           }
         } else {
 #pragma unroll
@@ -991,12 +991,13 @@ extern "C" hipError_t poem_launch_layernorm(const float* x, const float* g, cons
 __global__ __launch_bounds__(256) void narrow_linear_kernel(const float* __restrict__ x, int ldx,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ base, float* __restrict__ out,
-                                                            int rows, int K, int N) {
+                                                            int rows, int K, int N, int npb) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (size_t)row * ldx;
-  for (int n = 0; n < N; ++n) {
+  // blockIdx.y: this wave's npb output columns (the same fma chain and reduction tree per (row, column) whatever the split)
+  for (int n = blockIdx.y * npb, ne = min(N, n + npb); n < ne; ++n) {
     float s = 0.f;
     for (int c = lane; c < K; c += 64) s = fmaf(xr[c], w[(size_t)n * K + c], s);
 #pragma unroll
@@ -1008,6 +1009,10 @@ __global__ __launch_bounds__(256) void narrow_linear_kernel(const float* __restr
 extern "C" hipError_t poem_launch_narrow_linear(const float* x, int ldx, const float* w, const float* b,
                                                 const float* base, float* out, int rows, int K, int N,
                                                 hipStream_t s) {
-  hipLaunchKernelGGL(narrow_linear_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, ldx, w, b, base, out, rows, K, N);
+  // a wave walks its output columns one after the other (a latency chain of dependent loads and shuffles per column): fine for
+  // the 3 columns of reg_branch.2 over 25 k rows, 170 us for the 106 columns of mano_linear over 32 rows (round 6: one column per
+  // wave there -- the chip has the waves)
+  const int npb = (long)((rows + 3) / 4) * N <= 65535 && (rows + 3) / 4 < 2048 ? 1 : N;
+  hipLaunchKernelGGL(narrow_linear_kernel, dim3((rows + 3) / 4, (N + npb - 1) / npb), dim3(256), 0, s, x, ldx, w, b, base, out, rows, K, N, npb);
   return hipGetLastError();
 }

@@ -223,7 +223,7 @@ int check_config(const poem_config_t* c) {
 // ---- workspace plan -------------------------------------------------------------------------------------------------
 extern "C" {
 
-int poem_abi_version(void) { return 2; }
+int poem_abi_version(void) { return 3; }
 int poem_last_hip_error(void) { return g_last_hip_error; }
 const char* poem_error_string(int code) {
   switch (code) {
@@ -538,6 +538,15 @@ int poem_graph_stats(poem_handle_t h, int64_t* out, int n) {
   std::lock_guard<std::mutex> lock(g_pool_mutex);
   out[6] = (int64_t)g_parked_execs.size(); out[7] = g_exec_reuses; out[8] = g_exec_update_failures;
   if (n >= 10) out[9] = g_exec_busy_skips;
+  return POEM_OK;
+}
+
+// The MANO layer of the parametric tail inside the forward (include/poem_hip.h).  The table is the caller's device memory.
+int poem_attach_mano(poem_handle_t h, const void* table, int center_idx) {
+  if (!h || center_idx < -1 || center_idx > 20) return POEM_E_ARG;
+  if (table && !h->cfg.parametric) return POEM_E_UNSUPPORTED;
+  h->mano_table = (const float*)table;
+  h->mano_center = center_idx;
   return POEM_OK;
 }
 

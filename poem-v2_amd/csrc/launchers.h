@@ -146,15 +146,18 @@ hipError_t poem_launch_prep_xyz(const float* ref_joints, const float* bps, const
                                 float* pt_xyz, float* query_xyz, int B, int S, int Q, float radius, hipStream_t s);
 hipError_t poem_launch_broadcast(const float* src, float* dst, long per, int copies, hipStream_t s);
 hipError_t poem_launch_finalize(const float* xyz, const float* centre, float* out, int L, int B, int Q, float radius,
-                                hipStream_t s);
+                                const float* mano_verts, const float* mano_joints, hipStream_t s);
 hipError_t poem_launch_finalize_param(const float* verts, const float* joints, const float* ref_joints, float* out_last,
                                       int B, int Q, hipStream_t s);
 hipError_t poem_launch_q3_flatten(const float* feats, const float* fw, const float* fb, float* t, int B, int Q, int C,
                                   hipStream_t s);
 hipError_t poem_launch_rot6d_to_aa(const float* par, float* pose_aa, float* betas, int B, hipStream_t s);
-hipError_t poem_launch_mano_lbs(const float* pose, const float* betas, const float* v_template, const float* shapedirs,
-                                const float* posedirs, const float* j_regressor, const float* weights, float* verts,
-                                float* joints, int B, int center_idx, hipStream_t s);
+hipError_t poem_launch_mano_prepare(const float* v_template, const float* shapedirs, const float* posedirs,
+                                    const float* j_regressor, const float* weights, float* table, hipStream_t s);
+hipError_t poem_launch_mano_lbs(const float* pose, const float* betas, const float* table, float* verts, float* joints, int B,
+                                int center_idx, hipStream_t s);
+size_t poem_mano_table_floats_impl();
+hipError_t poem_launch_param_rows(const float* verts, const float* joints, float* out_last, int B, int Q, hipStream_t s);
 hipError_t poem_launch_compose_weight(const float* A, const float* Bm, float* out, int N, int Cm, int K, hipStream_t s);
 hipError_t poem_launch_compose_bias(const float* A, const float* b1, const float* b2, float* out, int N, int Cm,
                                     hipStream_t s);

@@ -47,7 +47,7 @@ __device__ __forceinline__ void bias_act(f32x16 (&acc)[TPW][P], const float* __r
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = acc[tp][p][4 * g + e] + (&bb.x)[e];
-          if (relu) v = fmaxf(v, 0.f);
+          if (relu) v = relu_nan(v);
           acc[tp][p][4 * g + e] = v;
         }
     }

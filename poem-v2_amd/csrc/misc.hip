@@ -65,12 +65,24 @@ extern "C" hipError_t poem_launch_broadcast(const float* src, float* dst, long p
 }
 
 // out[l, b, q, :] = nan_to_num(xyz[l, b, q, :]) * radius + centre[b]      (ptEmb_head.py:944-951 upstream)
+// mano_verts / mano_joints (a parametric head whose MANO layer runs inside the forward, poem_attach_mano): the LAST layer is the
+// MANO layer's output, not scaled: out[L-1, b, :21] = nan_to_num(joints) + c, out[L-1, b, 21:] = nan_to_num(verts) + c
+// (pt_metro_transformer.py:149-150, ptEmb_head.py:944,953-958 upstream) -- the arithmetic of finalize_param_kernel below.
 __global__ void finalize_kernel(const float* __restrict__ xyz, const float* __restrict__ centre, float* __restrict__ out,
-                                int L, int B, int Q, float radius) {
+                                int L, int B, int Q, float radius, const float* __restrict__ mano_verts,
+                                const float* __restrict__ mano_joints) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)L * B * Q * 3) return;
   const int d = (int)(i % 3);
   const int b = (int)((i / (3L * Q)) % B);
+  if (mano_verts && i >= (long)(L - 1) * B * Q * 3) {
+    const int qq = (int)((i / 3) % Q);
+    float v = qq < 21 ? mano_joints[((size_t)b * 21 + qq) * 3 + d] : mano_verts[((size_t)b * (Q - 21) + (qq - 21)) * 3 + d];
+    if (isnan(v)) v = 0.f;
+    else if (isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+    out[i] = v + centre[b * 3 + d];
+    return;
+  }
   float v = xyz[i];
   if (isnan(v)) v = 0.f;
   else if (isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
@@ -78,10 +90,26 @@ __global__ void finalize_kernel(const float* __restrict__ xyz, const float* __re
 }
 
 extern "C" hipError_t poem_launch_finalize(const float* xyz, const float* centre, float* out, int L, int B, int Q,
-                                           float radius, hipStream_t s) {
+                                           float radius, const float* mano_verts, const float* mano_joints, hipStream_t s) {
   const long total = (long)L * B * Q * 3;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xyz, centre, out, L, B, Q,
-                     radius);
+                     radius, mano_verts, mano_joints);
+  return hipGetLastError();
+}
+
+// PtEmbedTRv4.forward with the MANO layer inside the forward: the last layer's rows REPLACED by the layer's output, as is
+// (get_parametric_output, pt_metro_transformer.py:149-150: verts[:, 21:] = mano_verts; verts[:, :21] = mano_joints)
+__global__ void param_rows_kernel(const float* __restrict__ verts, const float* __restrict__ joints, float* __restrict__ out_last,
+                                  int B, int Q) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * Q * 3) return;
+  const int d = (int)(i % 3), qq = (int)((i / 3) % Q), b = (int)(i / (3L * Q));
+  out_last[i] = qq < 21 ? joints[((size_t)b * 21 + qq) * 3 + d] : verts[((size_t)b * (Q - 21) + (qq - 21)) * 3 + d];
+}
+
+extern "C" hipError_t poem_launch_param_rows(const float* verts, const float* joints, float* out_last, int B, int Q, hipStream_t s) {
+  const long total = (long)B * Q * 3;
+  hipLaunchKernelGGL(param_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, verts, joints, out_last, B, Q);
   return hipGetLastError();
 }
 
@@ -94,6 +122,7 @@ __global__ void finalize_param_kernel(const float* __restrict__ verts, const flo
   const float c = ref_joints[((size_t)b * 21 + 9) * 3 + d];
   float v = qq < 21 ? joints[((size_t)b * 21 + qq) * 3 + d] : verts[((size_t)b * (Q - 21) + (qq - 21)) * 3 + d];
   if (isnan(v)) v = 0.f;
+  else if (isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
   out_last[i] = v + c;
 }
 

@@ -341,14 +341,20 @@ int poem_rot6d_to_axis_angle(const float* params, float* pose_aa, float* betas, 
   return POEM_OK;
 }
 
-int poem_mano_lbs(const float* pose_aa, const float* betas, const float* v_template, const float* shapedirs,
-                  const float* posedirs, const float* j_regressor, const float* weights, int batch, int center_idx,
-                  float* verts, float* joints, void* stream) {
-  if (!pose_aa || !betas || !v_template || !shapedirs || !posedirs || !j_regressor || !weights || !verts || !joints ||
-      batch <= 0 || center_idx < -1 || center_idx > 20)
+size_t poem_mano_table_bytes(void) { return poem_mano_table_floats_impl() * sizeof(float); }
+
+int poem_mano_prepare(const float* v_template, const float* shapedirs, const float* posedirs, const float* j_regressor,
+                      const float* weights, void* table, void* stream) {
+  if (!v_template || !shapedirs || !posedirs || !j_regressor || !weights || !table) return POEM_E_ARG;
+  HIPCHK(poem_launch_mano_prepare(v_template, shapedirs, posedirs, j_regressor, weights, (float*)table, (hipStream_t)stream));
+  return POEM_OK;
+}
+
+int poem_mano_lbs(const float* pose_aa, const float* betas, const void* table, int batch, int center_idx, float* verts,
+                  float* joints, void* stream) {
+  if (!pose_aa || !betas || !table || !verts || !joints || batch <= 0 || batch > 65535 || center_idx < -1 || center_idx > 20)
     return POEM_E_ARG;
-  HIPCHK(poem_launch_mano_lbs(pose_aa, betas, v_template, shapedirs, posedirs, j_regressor, weights, verts, joints, batch,
-                              center_idx, (hipStream_t)stream));
+  HIPCHK(poem_launch_mano_lbs(pose_aa, betas, (const float*)table, verts, joints, batch, center_idx, (hipStream_t)stream));
   return POEM_OK;
 }
 

@@ -59,6 +59,8 @@ Plan make_plan(const poem_config_t& c, int B, int BN, void* base) {
   p.par = a.take<float>((size_t)B * 106);
   p.g_pose = a.take<float>((size_t)B * 48);
   p.g_betas = a.take<float>((size_t)B * 10);
+  p.mano_verts = a.take<float>((size_t)B * 778 * 3);
+  p.mano_joints = a.take<float>((size_t)B * 21 * 3);
   p.attn_scratch = a.take<float>(poem_cross_attention_scratch_floats(B, (int)Q, (int)S, (int)C, c.heads, 0) + 4);
   p.canon_xyz = a.take<float>(Q * 3);
   for (int k = 0; k < 2; ++k) {

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
       const int p = pg * 32 * PT + pt * 32 + r;
       float val = acc[pt][i] + bv;
       if (tab) val += tab[(size_t)c * hw + p];
-      if (relu) val = fmaxf(val, 0.f);
+      if (relu) val = relu_nan(val);
       acc[pt][i] = val;
       if (x) x[((size_t)v * C + c) * hw + p] = val;
     }
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_lds_kernel(const float* __res
         const int p = pg * PX + pt * 32 + r;
         float val = acc[pt][i] + bv;
         if (tab) val += tab[(size_t)c * hw + p];
-        if (relu) val = fmaxf(val, 0.f);
+        if (relu) val = relu_nan(val);
         acc[pt][i] = val;
         if (x) x[((size_t)v * C + c) * hw + p] = val;
       }

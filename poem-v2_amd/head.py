@@ -96,7 +96,21 @@ class POEM_Generalized_Head(nn.Module):
         self._drop_engines()
 
     def set_mano_layer(self, fn):
+        """callable (pose_aa (B,48), betas (B,10)) -> .verts / .joints.  The package's own :class:`~poem_v2_amd.mano.ManoLayer`
+        is ATTACHED to the engine instead of called: Q3 -> Linears -> rot6d -> LBS -> last layer all run inside the forward's
+        launch graph (include/poem_hip.h poem_attach_mano); any other callable runs between the forward and
+        ``poem_finalize_parametric`` as before."""
         self.mano_layer = fn
+        for eng in self._engines.values():
+            self._attach_mano(eng)
+
+    def _attach_mano(self, eng):
+        from .mano import ManoLayer
+        m = self.mano_layer
+        own = (isinstance(m, ManoLayer) and self.parametric_output and m.th_table.device == eng.device
+               and not getattr(self, "mano_in_python", False))
+        eng.attach_mano(m.th_table if own else None, m.center_idx if own else 9)
+        return own
 
     def load_reference_state_dict(self, sd):
         """Load a reference checkpoint (full model or head-only); dead tensors are ignored."""
@@ -175,6 +189,8 @@ class POEM_Generalized_Head(nn.Module):
                 eng.set_chains(False)
             for k, v in self._options.items():
                 eng.set_option(k, v)
+            if self.parametric_output:
+                self._attach_mano(eng)
         self._engine = eng
         return eng
 
@@ -266,9 +282,10 @@ class POEM_Generalized_Head(nn.Module):
         if self.parametric_output:
             if self.mano_layer is None:
                 raise RuntimeError("PARAMETRIC_OUTPUT needs a MANO layer: call set_mano_layer(fn)")
-            m = self.mano_layer(pose, betas)
-            verts, joints = (m.verts, m.joints) if hasattr(m, "verts") else m
-            eng.finalize_parametric(f32(verts), f32(joints), f32(reference_joints), out)
+            if getattr(eng, "_mano", None) is None:      # (an attached ManoLayer has already run inside the forward)
+                m = self.mano_layer(pose, betas)
+                verts, joints = (m.verts, m.joints) if hasattr(m, "verts") else m
+                eng.finalize_parametric(f32(verts), f32(joints), f32(reference_joints), out)
             results["pred_pose"] = pose.reshape(-1, 16, 3)
             results["pred_shape"] = betas.reshape(-1, 10)
         return results

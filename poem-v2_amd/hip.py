@@ -23,7 +23,7 @@ class PoemConfig(ctypes.Structure):
                 ("knn", ctypes.c_int32), ("parametric", ctypes.c_int32), ("feat_h", ctypes.c_int32),
                 ("feat_w", ctypes.c_int32), ("max_views", ctypes.c_int32), ("radius", ctypes.c_float),
                 ("ln_eps", ctypes.c_float),
-                # ABI 6: the positional-encoding switches of the reference's constructor (include/poem_hip.h)
+                # ABI 2 (round 5): the positional-encoding switches of the reference's constructor (include/poem_hip.h)
                 ("pe_normalize", ctypes.c_int32), ("petr_embedding", ctypes.c_int32), ("depth_num", ctypes.c_int32),
                 ("lid", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("depth_start", ctypes.c_double),
                 ("depth_end", ctypes.c_double), ("position_range", ctypes.c_double * 6)]
@@ -96,7 +96,10 @@ SIGNATURES = {
     "poem_pa_epe": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "poem_mano_to_openpose": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "poem_rot6d_to_axis_angle": (_i, [_vp, _vp, _vp, _i, _vp]),
-    "poem_mano_lbs": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "poem_mano_table_bytes": (_sz, []),
+    "poem_mano_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "poem_mano_lbs": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "poem_attach_mano": (_i, [_vp, _vp, _i]),
     "poem_profile_read_stage": (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_f)]),
     "poem_warp_affine": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "poem_pck_accumulate": (_i, [_vp, _vp, _i, _i, ctypes.c_double, ctypes.c_double, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -128,19 +131,27 @@ def lib():
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU/PyTorch fallback for this path)")
         L = ctypes.CDLL(LIB_PATH)
+        # the ABI first: a stale .so would read PoemConfig with another layout -- and would lack symbols, so the "rebuild it"
+        # message has to come before the symbol loop's AttributeError
+        try:
+            L.poem_abi_version.restype = _i
+            abi = L.poem_abi_version()
+        except AttributeError:
+            abi = None
+        if abi != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI {abi}, this package binds ABI {ABI_VERSION}: rebuild it "
+                               "(python -c 'import __graft_entry__ as g; g.build()')")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.poem_abi_version() != ABI_VERSION:      # a stale .so would read PoemConfig with another layout
-            raise RuntimeError(f"{LIB_PATH} has ABI {L.poem_abi_version()}, this package binds ABI {ABI_VERSION}: rebuild it "
-                               "(python -c 'import __graft_entry__ as g; g.build()')")
         _LIB = L
     return _LIB
 
 
 POEM_E_UNSUPPORTED = -4      # include/poem_hip.h
-ABI_VERSION = 2              # poem_abi_version(): 2 = poem_config_t with the positional-encoding switches (round 5)
+ABI_VERSION = 3              # poem_abi_version(): 2 = poem_config_t with the positional-encoding switches (round 5);
+                             # 3 = poem_mano_lbs takes the prepared asset table, poem_attach_mano (round 6)
 
 
 def check(rc, what=""):
@@ -337,6 +348,11 @@ class Engine:
                                              ptr(out), ptr(pose), ptr(betas), ws.data_ptr(), need, stream()),
                   "poem_decoder_forward")
         return out, pose, betas
+
+    def attach_mano(self, table, center_idx):
+        """The MANO layer inside the forward (include/poem_hip.h poem_attach_mano); ``table`` = ManoLayer.th_table or None."""
+        check(lib().poem_attach_mano(self.handle, None if table is None else table.data_ptr(), int(center_idx)), "poem_attach_mano")
+        self._mano = table      # (keeps the caller's table alive while attached)
 
     def finalize_parametric(self, verts, joints, reference_joints, out):
         with torch.cuda.device(self.device):

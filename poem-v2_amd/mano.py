@@ -40,7 +40,11 @@ def synthetic_mano_assets(seed=0):
 
 
 class ManoLayer(torch.nn.Module):
-    """``layer(pose_aa (B,48), betas (B,10)) -> MANOOutput(verts (B,778,3), joints (B,21,3))`` on the device, one launch."""
+    """``layer(pose_aa (B,48), betas (B,10)) -> MANOOutput(verts (B,778,3), joints (B,21,3))`` on the device, one launch over
+    (13 vertex tiles x B) blocks.  The five asset arrays are re-laid once, here, into the kernel's table (``th_table``:
+    coefficient-major blend shapes, joint regression composed with template and shape basis, joint-major skinning weights --
+    csrc/mano.hip).  A head / transformer given this layer (``set_mano_layer``) attaches the table to its engine and runs the
+    layer INSIDE its forward's launch graph."""
 
     def __init__(self, assets, center_idx=9, device="cuda:0"):
         super().__init__()
@@ -54,6 +58,15 @@ class ManoLayer(torch.nn.Module):
                 raise ValueError(f"MANO asset {k}: shape {tuple(a.shape)} != {shp}")
             self.register_buffer("th_" + k, a.contiguous().to(device), persistent=False)
         self.center_idx = -1 if center_idx is None else int(center_idx)
+        dev = self.th_v_template.device
+        if dev.type != "cuda":
+            raise RuntimeError("ManoLayer runs on the MI355X HIP path only (no CPU fallback)")
+        table = torch.empty(hip.lib().poem_mano_table_bytes() // 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            hip.check(hip.lib().poem_mano_prepare(hip.ptr(self.th_v_template), hip.ptr(self.th_shapedirs), hip.ptr(self.th_posedirs),
+                                                  hip.ptr(self.th_J_regressor), hip.ptr(self.th_weights), table.data_ptr(),
+                                                  hip.stream()), "poem_mano_prepare")
+        self.register_buffer("th_table", table, persistent=False)
 
     @classmethod
     def from_arrays(cls, v_template, shapedirs, posedirs, J_regressor, weights, **kw):
@@ -70,9 +83,8 @@ class ManoLayer(torch.nn.Module):
         verts = torch.empty(B, NV, 3, dtype=torch.float32, device=dev)
         joints = torch.empty(B, 21, 3, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            hip.check(hip.lib().poem_mano_lbs(hip.ptr(pose), hip.ptr(bet), hip.ptr(self.th_v_template), hip.ptr(self.th_shapedirs),
-                                              hip.ptr(self.th_posedirs), hip.ptr(self.th_J_regressor), hip.ptr(self.th_weights),
-                                              B, self.center_idx, hip.ptr(verts), hip.ptr(joints), hip.stream()), "poem_mano_lbs")
+            hip.check(hip.lib().poem_mano_lbs(hip.ptr(pose), hip.ptr(bet), hip.ptr(self.th_table), B, self.center_idx,
+                                              hip.ptr(verts), hip.ptr(joints), hip.stream()), "poem_mano_lbs")
         return MANOOutput(verts=verts, joints=joints)
 
     def zero_pose_template(self):

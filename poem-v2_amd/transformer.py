@@ -142,6 +142,9 @@ class PtEmbedTRv4(nn.Module):
             # get_parametric_output (pt_metro_transformer.py:139-151 upstream): the last block's coordinates are REPLACED by
             # the MANO layer's output for the regressed (pose, betas) -- rows 21.. the vertices, rows 0..20 the joints
             mano = self.mano_layer if self.mano_layer is not None else getattr(self._engine_owner, "mano_layer", None)
+            attached = getattr(eng, "_mano", None)      # the owner head's ManoLayer runs inside the forward: already in `out`
+            if attached is not None and getattr(mano, "th_table", None) is attached:
+                return out, pose, shape
             if mano is None:
                 raise RuntimeError("PARAMETRIC_OUTPUT needs a MANO layer: set_mano_layer(poem_v2_amd.ManoLayer(assets)) "
                                    "(the MANO assets are licence-gated and never read from disk here)")

@@ -169,7 +169,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/poem_hip.h but not exported"
     assert sorted(hip.SIGNATURES) == names          # the ctypes table mirrors the header one to one
-    assert L.poem_abi_version() == hip.ABI_VERSION == 2
+    assert L.poem_abi_version() == hip.ABI_VERSION == 3
     assert L.poem_error_string(-2) == b"workspace too small"
 
 

@@ -157,7 +157,17 @@ def test_mano_kernel_properties_and_oracle():
     vo, jo = mo.mano_lbs(_assets(), pose, betas, center_idx=9)
     assert float((v - vo).abs().max()) < 2e-6 and float((j - jo).abs().max()) < 2e-6      # metres
     one = run(pose[7:8], betas[7:8], 9)
-    assert torch.equal(one[0][0], v[7])                                                       # batch independence
+    assert torch.equal(one[0][0], v[7]) and torch.equal(one[1][0], j[7])                      # batch independence
+    mpvpe = float(torch.linalg.norm(v - vo, dim=-1).mean())
+    assert mpvpe <= 2e-7, mpvpe                                                               # (the path's bar is 1e-6 m)
+    # every centre: the 16 kinematic joints and the five finger tips (a skinned vertex: the re-centring launch), and none
+    vu, ju = run(pose, betas, -1)
+    for c in range(21):
+        vc, jc = run(pose, betas, c)
+        assert float(jc[:, c].abs().max()) == 0.0, c                                          # the centre joint is exactly 0
+        assert float((vc - (vu - ju[:, c:c + 1])).abs().max()) < 2e-7 and float((jc - (ju - ju[:, c:c + 1])).abs().max()) < 2e-7, c
+        voc, joc = mo.mano_lbs(_assets(), pose, betas, center_idx=c)
+        assert float((vc - voc).abs().max()) < 2e-6 and float((jc - joc).abs().max()) < 2e-6, c
     layer = pk.ManoLayer(_assets(), device=DEV)
     t = layer.zero_pose_template()
     assert t.shape == (799, 3) and float(t[9].abs().max()) == 0.0

@@ -91,6 +91,22 @@ int main(int argc, char** argv) {
       }
       std::vector<long long> z(1024 * 4, 0); CK(hipMemcpyToSymbol(HIP_SYMBOL(c16_blocks), z.data(), z.size() * 8));
     }
+    if (argc > 2) {   // per-wave trace of blocks 0 and 256 (CU 0): shader-clock cycles since the earliest stamp 0
+      long long wt[2 * 8 * 40]; unsigned hw[16];
+      CK(hipMemcpyFromSymbol(wt, HIP_SYMBOL(c16_wtrace), sizeof(wt))); CK(hipMemcpyFromSymbol(hw, HIP_SYMBOL(c16_whw), sizeof(hw)));
+      long long t0 = 1LL << 62;
+      for (int w = 0; w < 16; ++w) if (wt[w * 40]) t0 = std::min(t0, wt[w * 40]);
+      const double cyc_per_tick = (st[last] > st[0] && wt[last] > wt[0]) ? (double)(wt[last] - wt[0]) / (double)(st[last] - st[0]) : 0.0;   // shader cycles per 10 ns
+      printf("    wave trace (kcycles since the first wave's start; shader clock = %.0f MHz); columns = stamp ids\n", cyc_per_tick * 100.0);
+      for (int simd = 0; simd < 4; ++simd)
+        for (int w = 0; w < 16; ++w) {
+          if (((hw[w] >> 4) & 3) != (unsigned)simd || !wt[w * 40]) continue;
+          printf("      simd %d block %3d wave %d (slot %2u):", simd, w < 8 ? 0 : 256, w & 7, hw[w] & 15);
+          for (int k = 0; k < 40; ++k) if (wt[w * 40 + k]) printf(" [%d] %.1f", k, (wt[w * 40 + k] - t0) / 1000.0);
+          printf("\n");
+        }
+      { long long z[2 * 8 * 40] = {}; CK(hipMemcpyToSymbol(HIP_SYMBOL(c16_wtrace), z, sizeof(z))); }
+    }
     { long long z[64] = {}; CK(hipMemcpyToSymbol(HIP_SYMBOL(c16_stamps), z, sizeof(z))); }
   }
   return 0;
