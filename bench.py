@@ -852,8 +852,13 @@ def main():
                                 "views_total": int(sum(vws)), "executed_TFLOPs": exx / sec / 1e12,
                                 "frac_of_fp32_matrix_peak": exx / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS}
                 if par:
-                    extras[name]["note"] = ("parametric tail on the device: Q3 flatten + Linears + rot6d -> axis-angle + MANO linear "
-                                            "blend skinning (csrc/mano.hip) with a synthetic asset set of MANO's shapes")
+                    extras[name]["note"] = ("parametric tail on the device and INSIDE the forward's launch graph (poem_attach_mano): Q3 "
+                                            "flatten + Linears + rot6d -> axis-angle + MANO linear blend skinning (csrc/mano.hip) with a "
+                                            "synthetic asset set of MANO's shapes.  Third-party legs unpinned upstream: manotorch's "
+                                            "ManoLayer, the MANO assets and pytorch3d's rot6d -> axis-angle chain are absent from the "
+                                            "reference tree -- the MPVPE bar of this config (tests: <= 1e-3 mm) is against the oracle's "
+                                            "restatement of the published MANO model, not against the third-party code")
+                    extras[name]["vs_headline"] = (len(vws) / sec) / res["value"]
                 del h2, b2
                 torch.cuda.empty_cache()
             except Exception as e:   # informational: never fail the bench line on it

@@ -446,6 +446,8 @@ def head_forward(w, cfg, consts, mlvl_feat, cam_intr, cam_extr, cam_view_num, re
     query_xyz = (ref_pts - centre[:, None, :]) / cfg.radius                                      # :935
     if taps is not None:
         taps.update(x=x, uv=uv, g=g, bps_feat=bps_feat, pt_xyz=pt_xyz, query_xyz=query_xyz)
+        if taps.get("__stop_after_sampling__"):      # (tests of the sampling stage alone: the decoder is 90 % of the oracle's time)
+            return None
     feats, xyz = query_feat, query_xyz
     stack = []
     pose = shape = None

@@ -160,7 +160,7 @@ struct HeadRun {
       sm.view_sample = p.view_sample; sm.offs = p.offs;
       sm.w0 = (const float4*)h->P(T_M00_W); sm.b0 = h->R(T_M00_B); sm.w1 = (const float4*)h->P(T_M02_W); sm.b1 = h->R(T_M02_B);
       sm.h2 = p.h2; sm.q1 = p.q1; sm.S = S; sm.hw = HW; sm.h2_tiled = 1;
-      sm.views = plan_views; sm.views_dev = p.offs + B;      // the grid is sized for the plan, the kernel reads the batch's own count
+      sm.views = plan_views; sm.B = B; sm.views_dev = p.offs + B;      // the grid is sized for the plan, the kernel reads the batch's own count
       // The samples whose view count divides 8 go through sample_group_kernel (the whole stage in one kernel: merge_net[0]'s
       // hidden rows never reach HBM) when the batch has enough views to fill the chip with its 8-tile units; the two-kernel
       // form takes the rest.  Which samples go where is decided on the device from the layout (the launch graph is keyed by the
@@ -176,7 +176,7 @@ struct HeadRun {
       mt.h2 = p.h2; mt.q1 = p.q1; mt.offs = p.offs;
       mt.w0 = (const float4*)h->P(T_M10_W); mt.b0 = h->R(T_M10_B); mt.w1 = (const float4*)h->P(T_M12_W); mt.b1 = h->R(T_M12_B);
       mt.out = p.bps_feat; mt.B = B; mt.S = S; mt.h2_tiled = 1;
-      mt.group_min_views = sm.group_min_views; mt.views_dev = sm.views_dev;
+      mt.group_min_views = sm.group_min_views; mt.views_dev = sm.views_dev; mt.views = sm.views;
       sm.xcd_order = h->group_xcd;
       // (a batch size whose view capacity stays below the threshold can never take the grouped kernel: no launch at all --
       //  its early exit still costs ~6 us in front of a small batch's forward; the graph is keyed by the batch size, so is this)

@@ -37,20 +37,34 @@ std::map<int, std::vector<CaptureKit>> g_kit_pool;         // device id -> idle 
 // (hipGraphExecUpdate rewrites node parameters) only on its own device and only once the event has completed.
 struct ParkedExec { hipGraphExec_t exec; uint64_t shape; int device; hipEvent_t done; };
 std::vector<ParkedExec> g_parked_execs;                    // never destroyed (see above); re-used by poem_reuse_graph_exec
-std::vector<hipEvent_t> g_idle_done_events;                // events of re-used execs, kept for the next parking (never destroyed either)
+std::map<int, std::vector<hipEvent_t>> g_idle_done_events; // device -> events of re-used execs, kept for the next parking (never destroyed either)
 int64_t g_exec_reuses = 0, g_exec_update_failures = 0, g_exec_busy_skips = 0;
 
-// (g_pool_mutex held) an event recorded on `last_stream` behind the exec's last launch; nullptr when it never ran
-hipEvent_t done_event_locked(hipStream_t last_stream, bool launched) {
+// (g_pool_mutex held) an event recorded on `last_stream` behind the exec's last launch; nullptr when it never ran.  An event
+// belongs to the device it was created on and records only on that device's streams: the pool is per device and creation runs
+// with the exec's device current (poem_destroy may be called -- from a Python finaliser -- with another device current).
+// `*ok` = false: the exec DID run and no event could be recorded behind it -- nobody can tell when its last launch ends, so the
+// caller parks it with shape 0 (never offered for an update again) instead of as "never ran".
+hipEvent_t done_event_locked(hipStream_t last_stream, bool launched, int device, bool* ok) {
+  *ok = true;
   if (!launched) return nullptr;
+  int cur = -1;
+  const bool switched = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
   hipEvent_t ev = nullptr;
-  if (!g_idle_done_events.empty()) { ev = g_idle_done_events.back(); g_idle_done_events.pop_back(); }
-  else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  if (hipEventRecord(ev, last_stream) != hipSuccess) {       // (a destroyed caller stream: the work on it has drained)
+  auto& idle = g_idle_done_events[device];
+  if (!idle.empty()) { ev = idle.back(); idle.pop_back(); }
+  else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+  if (ev && hipEventRecord(ev, last_stream) != hipSuccess) {
     (void)hipGetLastError();
-    g_idle_done_events.push_back(ev);
-    return nullptr;
+    idle.push_back(ev);
+    ev = nullptr;
   }
+  if (!ev) {
+    // (a destroyed caller stream is the common cause: drain the device once -- rare path -- and the exec is idle after all)
+    *ok = hipDeviceSynchronize() == hipSuccess;
+    (void)hipGetLastError();
+  }
+  if (switched) (void)hipSetDevice(cur);
   return ev;
 }
 
@@ -108,15 +122,20 @@ void return_kit(poem_handle_t h) {
 
 void park_execs(poem_handle_t h) {
   std::lock_guard<std::mutex> lock(g_pool_mutex);
-  for (auto& g : h->graph_cache)
-    g_parked_execs.push_back({g.exec, g.shape, h->stream_device, done_event_locked(g.last_stream, g.launched)});
+  for (auto& g : h->graph_cache) {
+    bool ok = true;
+    hipEvent_t ev = done_event_locked(g.last_stream, g.launched, h->stream_device, &ok);
+    g_parked_execs.push_back({g.exec, ok ? g.shape : 0, h->stream_device, ev});
+  }
   h->graph_cache.clear();
 }
 }  // namespace
 
 void poem_park_graph_exec(hipGraphExec_t e, uint64_t shape, int device, hipStream_t last_stream, bool launched) {
   std::lock_guard<std::mutex> lock(g_pool_mutex);
-  g_parked_execs.push_back({e, shape, device, done_event_locked(last_stream, launched)});
+  bool ok = true;
+  hipEvent_t ev = done_event_locked(last_stream, launched, device, &ok);
+  g_parked_execs.push_back({e, ok ? shape : 0, device, ev});
 }
 
 // A parked exec of the same shape, updated in place to the freshly captured graph (kernel arguments, grids and functions of
@@ -131,7 +150,7 @@ hipGraphExec_t poem_reuse_graph_exec(hipGraph_t graph, uint64_t shape, int devic
       if (pe.shape != shape || pe.device != device) continue;
       if (pe.done) {
         if (hipEventQuery(pe.done) != hipSuccess) { (void)hipGetLastError(); ++g_exec_busy_skips; continue; }   // still running its last launch
-        g_idle_done_events.push_back(pe.done);
+        g_idle_done_events[pe.device].push_back(pe.done);
         pe.done = nullptr;
       }
       cand = pe;
@@ -269,6 +288,16 @@ size_t poem_packed_bytes(const poem_config_t* cfg) {
   return total;
 }
 
+// The part of the arena that holds packed weight images (everything in front of the index arrays): what the native-image mirror
+// of the chain kernels has to cover -- not the folded positional table, the sine scratch or the init-time composites behind it
+// (tens of MB per engine at max_views = 10).
+static size_t packed_weight_extent(const poem_config_t* cfg) {
+  const size_t hw = (size_t)cfg->feat_h * cfg->feat_w, C = cfg->embed;
+  const size_t tail = align_up((size_t)poem_handle_s::IDX_CAP * 4, 256) + align_up(pe_views(cfg->max_views) * C * hw * 4, 256) +
+                      align_up(pe_views(cfg->max_views) * (3 * C / 2) * hw * 4, 256) + align_up((6 * C * C + 2 * C * C + 8 * C) * 4, 256) + 256;
+  return poem_packed_bytes(cfg) - tail;
+}
+
 size_t poem_packed_linear_bytes(int out_features, int in_features) {
   if (in_features % 8) return 0;
   return packed_bytes_linear(out_features, in_features);
@@ -300,7 +329,7 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
       g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
     }
   }
-  if (poem_chain16_wants_native(cfg->embed) && hipMalloc((void**)&h->native16, packed_bytes) != hipSuccess) {
+  if (poem_chain16_wants_native(cfg->embed) && hipMalloc((void**)&h->native16, packed_weight_extent(cfg)) != hipSuccess) {
     g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH;
   }
   // mirror of a freshly packed fp32 image at `at`: the split image of the same row-major weight, and (same offset in
@@ -433,6 +462,7 @@ int poem_create(const poem_config_t* cfg, const void* const* raw_host, int n, co
     }
     if (!ok) { g_last_hip_error = (int)hipGetLastError(); poem_destroy(h); return POEM_E_LAUNCH; }
   }
+  if ((size_t)(cur - (char*)packed) > packed_weight_extent(cfg)) { poem_destroy(h); return POEM_E_ARG; }      // (the mirror's extent)
   h->idx_dev = (int32_t*)cur;
   cur += align_up((size_t)poem_handle_s::IDX_CAP * 4, 256);
   h->pe_table = (float*)cur;

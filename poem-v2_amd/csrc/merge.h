@@ -13,6 +13,7 @@ struct SampleMergeArgs {
   float* h2;                  // (views * S, C/2): merge_net[0] of every Q1 row, in the layout `h2_tiled` selects
   float* q1;                  // (B * S, C): the Q1 rows with n == 0 (the residual of merge_features_mv / _sv)
   int views, S, hw;
+  int B;                      // samples (offs has B + 1 entries)
   int h2_tiled;               // 0: row-major Q1 rows; 1: tile-major (see merge.hip)
   // Layout-independent launches (forward.cpp, hipGraph replay): when set, the kernel reads the batch's view count from device
   // memory (= view_offsets[B]) and `views` is only the capacity the grid was sized for -- the captured launch then serves every
@@ -55,4 +56,5 @@ struct MergeTailArgs {
   int h2_tiled;
   int group_min_views;        // as SampleMergeArgs (with views_dev): the samples the grouped kernel takes are skipped here
   const int* views_dev;
+  int views;                  // the view capacity the launch was sized for (the device count is clamped to it, as in the other two kernels)
 };

@@ -70,6 +70,13 @@ __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[TPW][P], float* _
 // its units; sample_merge_kernel / merge_tail_kernel skip them.  Both forms produce the same bits (same fma chains, same
 // reduction trees), so the choice may depend on the batch.
 __device__ __forceinline__ bool poem_group_n(int N) { return N == 1 || N == 2 || N == 4 || N == 8; }
+// ... and whether the grouped kernel runs at all in this forward: ONE expression for the three kernels (the batch's own view
+// count, read from device memory and clamped to the capacity the launches were sized for, against the threshold) -- if they
+// disagreed, samples would be sampled twice or not at all.
+__device__ __forceinline__ int poem_view_count(const int* views_dev, int views_cap) { return views_dev ? min(*views_dev, views_cap) : views_cap; }
+__device__ __forceinline__ bool poem_grouped_forward(const int* views_dev, int views_cap, int group_min_views) {
+  return views_dev && poem_view_count(views_dev, views_cap) >= group_min_views;
+}
 
 template <int C, int P, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMergeArgs A) {
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
   // and tables (384 KB per view) stay in every XCD's L2.  (An XCD-aware order -- the blocks of XCD x = blockIdx % 8 walking
   // the views x, x + 8, ... -- measured 1 % slower.)
   const int slot = (int)blockIdx.x, L = (int)gridDim.x;
-  const int nv = A.views_dev ? min(*A.views_dev, A.views) : A.views;
+  const int nv = poem_view_count(A.views_dev, A.views);
   const unsigned CC4 = (unsigned)(C * C * 4);
   const int q = lane / LPP, cg = lane % LPP;
 
@@ -102,9 +109,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_merge_kernel(SampleMer
       to[i] = A.tabo[p0 + k];
     }
   };
-  const bool grouped = A.views_dev && nv >= A.group_min_views;      // sample_group_kernel takes the samples with N | 8
+  const bool grouped = poem_grouped_forward(A.views_dev, A.views, A.group_min_views);      // sample_group_kernel takes the samples with N | 8
   if (grouped) {                          // ... all of them? (a fixed-view batch of 1, 2, 4 or 8 views: nothing to do here)
-    const int B = (int)(A.views_dev - A.offs);
+    const int B = A.B;
     int mine = 0;
     for (int b = tid; b < B; b += NW * 64) mine |= !poem_group_n(A.offs[b + 1] - A.offs[b]);
     if (!__syncthreads_or(mine)) return;
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(NW * 64, 2) void merge_tail_kernel(MergeTailArgs A)
   // tiles of the fused kernel (XS rows there = 32 * P' with P' = 2 for C <= 256, 1 for C = 512)
   constexpr int FXS = C == 512 ? 32 : 64;
   const int TPV = (C / FXS) * NSEG;
-  const bool grouped = A.views_dev && *A.views_dev >= A.group_min_views;
+  const bool grouped = poem_grouped_forward(A.views_dev, A.views, A.group_min_views);
   if (grouped) {
     int mine = 0;
     for (int b = tid; b < A.B; b += NW * 64) mine |= !poem_group_n(A.offs[b + 1] - A.offs[b]);
@@ -384,8 +391,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sample_group_kernel(SampleGro
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 31, h = lane >> 5;
   const int NSEG = A.S / C, UPC = NSEG / USEG, UPV = (C / XS) * UPC;
   const int slot = (int)blockIdx.x, L = (int)gridDim.x;
-  const int nv = A.views_dev ? min(*A.views_dev, A.views) : A.views;
-  if (nv < A.group_min_views) return;
+  const int nv = poem_view_count(A.views_dev, A.views);
+  if (!poem_grouped_forward(A.views_dev, A.views, A.group_min_views)) return;
   const unsigned CC4 = (unsigned)(C * C * 4);
   const int q = lane / LPP, cg = lane % LPP;
   const int t2 = wv / P, p2 = wv % P;     // this wave's (32-channel tile, column tile) of h

@@ -5,6 +5,7 @@
 tensor the forward reads.  The nn.Modules below only hold parameters; all arithmetic runs in libpoem_hip.so through
 one ``poem_head_forward`` call.  There is no CPU / eager fallback."""
 import warnings
+import weakref
 
 import numpy as np
 import torch
@@ -19,10 +20,14 @@ from .weights import live_key_shapes
 # `blocks[1] = ...`, parametrize.register_parametrization, add_module).  The head caches the `_parameters` dicts of its
 # submodules (see _engine_for) and re-walks its tree only when this moved -- a replaced SUBMODULE is seen at the next forward.
 _TREE_EPOCH = [0]
+# ... of the module trees that BELONG to a POEM head (weak: a head that is dropped takes its entries along): the hook is
+# process-global, and an unrelated model that is being built or edited per request must not force this head's 0.3 ms re-walk.
+_TRACKED = weakref.WeakSet()
 
 
 def _on_module_registration(module, name, submodule):
-    _TREE_EPOCH[0] += 1
+    if module in _TRACKED:
+        _TREE_EPOCH[0] += 1
     return None
 
 
@@ -146,6 +151,11 @@ class POEM_Generalized_Head(nn.Module):
         self._plist = None                     # .to() / .cuda() / .float(): the parameters move
         return super()._apply(fn, *a, **k)
 
+    def __delattr__(self, name):
+        self._plist = None                     # `del head.x`: a removed submodule's cached _parameters dict must not be read again
+        _TREE_EPOCH[0] += 1
+        super().__delattr__(name)
+
     def _engine_for(self, device):
         # The engine packs the weights once; it is rebuilt when any parameter's identity, storage or version counter changes
         # (load_state_dict incl. assign=True, `module.weight = nn.Parameter(...)`, .to(), in-place edits).  The submodules'
@@ -159,7 +169,10 @@ class POEM_Generalized_Head(nn.Module):
         # memory and may overlap on the GPU (bench.py small_batch_scope `two_streams`: +7 % at batch 4, nothing at batch <= 2
         # with the default four hardware queues).  Same kernels, same bits.
         if getattr(self, "_plist", None) is None or self._plist_epoch != _TREE_EPOCH[0]:
-            self._plist = [m._parameters for m in self.modules()]      # (the module set itself: re-walked when a module tree changed)
+            mods = list(self.modules())
+            self._plist = [m._parameters for m in mods]      # (the module set itself: re-walked when a module tree changed)
+            for m in mods:
+                _TRACKED.add(m)
             self._plist_epoch = _TREE_EPOCH[0]
         sig = (str(device),) + tuple((id(p), p.data_ptr(), p._version) for d in self._plist for p in d.values() if p is not None)
         if self._engine_sig != sig:

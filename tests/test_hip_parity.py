@@ -750,6 +750,9 @@ def test_fused_sampling_vs_operator_sequence(name):
     assert mp(out[1], out[0]) < (1e-6 if "hot" in name else 2e-7)
 
 
+_DECODER_ORACLE = {}
+
+
 @pytest.mark.parametrize("embed,chains", [(128, 1), (256, 1), (256, 0), (512, 1)])
 def test_decoder_entry_with_caller_queries_vs_oracle(embed, chains):
     """PtEmbedTRv4.forward / poem_decoder_forward (ptEmb_transformer.py:371-376): the decoder on the CALLER's query coordinates
@@ -766,12 +769,14 @@ def test_decoder_entry_with_caller_queries_vs_oracle(embed, chains):
     qf, pf = torch.randn(B, 799, embed, generator=g), torch.randn(B, 4096, embed, generator=g)
     with torch.no_grad():
         got, pose, shape = head.transformer(qxyz.to(DEV), qf.to(DEV), pxyz.to(DEV), pf.to(DEV))
-        feats, xyz, ref = qf, qxyz, []
-        for i in range(cfg.nblocks):
-            feats, xyz, _, _ = po.decoder_block(w, cfg, i, xyz, feats, pxyz, pf, consts)
-            ref.append(xyz)
+        if embed not in _DECODER_ORACLE:      # (the same inputs for chains = 0 / 1: the oracle's three blocks once per width)
+            feats, xyz, ref = qf, qxyz, []
+            for i in range(cfg.nblocks):
+                feats, xyz, _, _ = po.decoder_block(w, cfg, i, xyz, feats, pxyz, pf, consts)
+                ref.append(xyz)
+            _DECODER_ORACLE[embed] = torch.stack(ref)
     assert pose is None and shape is None
-    ref = torch.stack(ref)
+    ref = _DECODER_ORACLE[embed]
     got = got.cpu()
     assert got.shape == ref.shape == (3, B, 799, 3)
     for layer in range(3):
@@ -900,22 +905,26 @@ def test_fused_sampling_every_view_count(embed):
     spec = dict(embed=embed, nsample=4096, views=[7, 1, 10, 3, 2, 9, 5, 4, 8, 6], seed=77, parametric=False)
     cfg, w, consts, batch = case_setup(spec)
     taps = {}
-    orc = run_oracle(cfg, w, consts, batch, taps=taps)["all_coords_preds"]
+    # (the decoder behind the sampling stage is compared with the oracle at C = 128; at C = 256 the two front ends' vertices with
+    #  each other -- the oracle's decoder on ten samples is 20 s of CPU time that other tests already spend on this width)
+    orc = run_oracle(cfg, w, consts, batch, taps=taps, stop_after_sampling=embed != 128)
     head = build_hip_head(spec, DEV)
     feat, metas, rj = batch_to(batch, DEV)
     eng = head._engine_for(torch.device(DEV))
     eng.enable_taps(True)
-    bf = {}
+    bf, outs = {}, {}
     for mode in (1, 0):
         eng.set_option("fused_sampling", mode)
         with torch.no_grad():
-            got = head(feat, metas, rj)["all_coords_preds"].cpu()
+            outs[mode] = got = head(feat, metas, rj)["all_coords_preds"].cpu()
         bf[mode] = eng.tap("bps_feat", (10, 4096, embed)).cpu()
         scale = max(1.0, float(taps["bps_feat"].abs().max()))
         per_sample = (bf[mode] - taps["bps_feat"]).abs().amax(dim=(1, 2))
         assert float(per_sample.max()) < 2e-5 * scale, (mode, per_sample)
-        assert float(torch.norm(got[-1] - orc[-1], dim=-1).mean()) < 1e-6
+        if orc is not None:
+            assert float(torch.norm(got[-1] - orc["all_coords_preds"][-1], dim=-1).mean()) < 1e-6
     assert _md(bf[1], bf[0]) < 1e-5 * scale
+    assert float(torch.norm(outs[1][-1] - outs[0][-1], dim=-1).mean()) < 1e-6
 
 
 @pytest.mark.parametrize("embed", [128, 256, 512])
@@ -929,7 +938,7 @@ def test_grouped_sampling_kernel_is_bit_identical_to_the_two_kernel_form(embed):
     spec = dict(embed=embed, nsample=4096, views=[7, 1, 10, 3, 2, 9, 5, 4, 8, 6, 8, 1, 2, 4], seed=78, parametric=False)
     cfg, w, consts, batch = case_setup(spec)
     taps = {}
-    run_oracle(cfg, w, consts, batch, taps=taps)
+    run_oracle(cfg, w, consts, batch, taps=taps, stop_after_sampling=True)
     head = build_hip_head(spec, DEV)
     feat, metas, rj = batch_to(batch, DEV)
     eng = head._engine_for(torch.device(DEV))
@@ -1390,16 +1399,18 @@ def test_nan_features_of_one_sample_give_its_centre_and_leave_the_others_alone()
         bad[sl] = float("nan")
         with torch.no_grad():
             outs = [head(bad, metas, rj)["all_coords_preds"] for _ in range(3)]      # plain launches, capture, graph replay
-        b2 = dict(batch, mlvl_feat=bad.cpu())
-        ref = run_oracle(cfg, w, consts, b2)["all_coords_preds"]
-        poisoned = bool(torch.equal(ref[:, 1], batch["reference_joints"][1, 9].expand(3, 799, 3)))
-        assert poisoned or case == "one pixel", case          # (a single pixel poisons the sample iff a basis point taps it)
+        # the oracle (torch: ReLU and softmax propagate NaN, nan_to_num at the end) decides the single-pixel case -- a pixel poisons
+        # the sample iff a basis point taps it; for whole NaN views the answer is the centre (checked against the oracle on the
+        # CPU in tests/test_oracle_golden.py::test_nan_views_give_the_centre)
+        ref = run_oracle(cfg, w, consts, dict(batch, mlvl_feat=bad.cpu()))["all_coords_preds"] if case == "one pixel" else None
+        poisoned = ref is None or bool(torch.equal(ref[:, 1], batch["reference_joints"][1, 9].expand(3, 799, 3)))
         for out in outs:
             assert torch.isfinite(out).all(), case
             if poisoned:
                 assert torch.equal(out[:, 1], rj[1, 9].expand(3, 799, 3)), case
             assert torch.equal(out[:, 0], clean[:, 0]) and torch.equal(out[:, 2], clean[:, 2]), case
-            assert float((out.cpu() - ref).abs().max()) < 1e-6, case
+            if ref is not None:
+                assert float((out.cpu() - ref).abs().max()) < 1e-6, case
 
 
 def test_full_size_config_c3_medium_mano_8_views_batch_32():

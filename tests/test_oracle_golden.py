@@ -377,3 +377,19 @@ def test_committed_fixture_is_what_the_generator_writes_today(name, tmp_path):
         assert bytes(new["meta"]) == bytes(old["meta"])
     finally:
         shutil.copy(keep, committed)
+
+
+@pytest.mark.parametrize("sl", [(slice(1, 3),), (slice(2, 3),)], ids=["all_views", "non_master_view"])
+def test_nan_views_give_the_centre(sl):
+    """ptEmb_head.py:944 (`torch.nan_to_num(interm_ref_pts)`) seen from the whole path: a sample with NaN backbone features --
+    all its views, or only a non-master view (the NaN then enters through merge_features_mv's dot products) -- comes out as its
+    hand centre in every layer; the other sample is untouched.  (The GPU twin: tests/test_hip_parity.py::test_nan_features_...)"""
+    spec = dict(embed=32, nsample=1024, views=[1, 2], seed=19, parametric=False)
+    cfg, w, consts, batch = case_setup(spec)
+    clean = run_oracle(cfg, w, consts, batch)["all_coords_preds"]
+    bad = dict(batch, mlvl_feat=batch["mlvl_feat"].clone())
+    bad["mlvl_feat"][sl] = float("nan")
+    out = run_oracle(cfg, w, consts, bad)["all_coords_preds"]
+    assert torch.isfinite(out).all()
+    assert torch.equal(out[:, 1], batch["reference_joints"][1, 9].expand(3, 799, 3))
+    assert torch.equal(out[:, 0], clean[:, 0])

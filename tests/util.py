@@ -46,13 +46,58 @@ def case_setup(spec):
     return cfg, w, consts, batch
 
 
-def run_oracle(cfg, w, consts, batch, taps=None, hoist=False, anchor_tables=False):
+# The oracle is a torch-CPU restatement: 3-30 s per release-shape case, and several tests evaluate it on the SAME seeded case
+# (final vertices, stage taps, both block-0 forms).  Results are kept per process, keyed by the CONTENT of everything the oracle
+# reads (so a test that edits a camera or a feature map gets its own entry): the GPU suite spends its time on the GPU path
+# instead of re-running the checker (round 5: 776 s of the driver's 1200 s limit).
+_ORACLE_CACHE = {}
+
+
+def _oracle_key(cfg, w, consts, batch, hoist, anchor_tables):
+    import hashlib
+    import struct
+    h = hashlib.sha1()
+    m = batch["img_metas"]
+    h.update(repr((cfg, bool(hoist), bool(anchor_tables), [int(v) for v in m["cam_view_num"]], tuple(m["inp_img_shape"]))).encode())
+    for t in (batch["mlvl_feat"], m["cam_intr"], m["cam_extr"], batch["reference_joints"], consts["bps"], consts["anchor"],
+              consts["anchor_idx"], consts["template"]):
+        h.update(t.detach().cpu().contiguous().numpy().tobytes())
+    for k in sorted(w):
+        t = w[k].detach().double()
+        h.update(k.encode())
+        h.update(struct.pack("dd", float(t.sum()), float(t.abs().sum())))
+    return h.hexdigest()
+
+
+def run_oracle(cfg, w, consts, batch, taps=None, hoist=False, anchor_tables=False, stop_after_sampling=False, cache=True):
+    """``stop_after_sampling``: only the sampling stage's taps are wanted (x, uv, g, bps_feat, pt_xyz, query_xyz) -- the decoder
+    blocks, 90 % of the oracle's time, are skipped and None is returned."""
     m = batch["img_metas"]
     mano_fn = po.toy_mano(consts["template"], cfg.center_idx) if cfg.parametric else None
+    # (cache=False: a test that swaps one of the oracle's own functions for an experiment; the key also carries the identity of
+    #  the functions tests are known to replace)
+    key = _oracle_key(cfg, w, consts, batch, hoist, anchor_tables) + f"|{id(po.linear)}|{id(po.knn_distances)}"
+    hit = _ORACLE_CACHE.get(key) if cache else None
+    if hit is not None and (taps is None or hit[1] is not None):
+        if taps is not None:
+            taps.update(hit[1])
+        return None if stop_after_sampling else dict(hit[0])
+    if stop_after_sampling:
+        assert taps is not None
+        taps["__stop_after_sampling__"] = True
+    # (taps are recorded whenever they are small enough to keep: the next test of the same case asks for them)
+    small = batch["mlvl_feat"].shape[0] * cfg.embed * cfg.nsample * 4 < (256 << 20)
+    rec = taps if taps is not None else ({} if small else None)
     with torch.no_grad():
-        return po.head_forward(w, cfg, consts, batch["mlvl_feat"], m["cam_intr"], m["cam_extr"], m["cam_view_num"],
-                               batch["reference_joints"], inp_img_shape=m["inp_img_shape"], taps=taps, hoist=hoist,
-                               mano_fn=mano_fn, anchor_tables=anchor_tables)
+        out = po.head_forward(w, cfg, consts, batch["mlvl_feat"], m["cam_intr"], m["cam_extr"], m["cam_view_num"],
+                              batch["reference_joints"], inp_img_shape=m["inp_img_shape"], taps=rec, hoist=hoist,
+                              mano_fn=mano_fn, anchor_tables=anchor_tables)
+    if out is None:
+        rec.pop("__stop_after_sampling__", None)
+        return None
+    if cache:
+        _ORACLE_CACHE[key] = (dict(out), dict(rec) if (rec is not None and small) else None)
+    return out
 
 
 from poem_v2_amd.configs import head_cfg  # noqa: E402,F401

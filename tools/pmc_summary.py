@@ -63,6 +63,26 @@ if m:
             e["GRBM_GUI_ACTIVE"] = gui[k]["avg"]
             if k in busy:
                 e["SQ_BUSY_CYCLES"] = busy[k]["avg"]
+# round 6: issue / wait accounting and the L2 -> memory write requests (tools/collect_pmc.sh passes pmc_issue, pmc_wr), and the
+# derived figures the reviews quote: MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (128 GRBM_GUI_ACTIVE)
+for sub in ("pmc_issue", "pmc_wr"):
+    g = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    if not g:
+        continue
+    names = sorted({r["Counter_Name"] for r in csv.DictReader(open(g[0]))})
+    for cn in names:
+        pk = per_kernel(g[0], cn)
+        for k, e in out["kernels"].items():
+            if k in pk:
+                e[cn] = pk[k]["avg"]
+for k, e in out["kernels"].items():
+    if e.get("GRBM_GUI_ACTIVE"):
+        e["mfma_busy"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * e["GRBM_GUI_ACTIVE"]), 4)
+    if e.get("SQ_INSTS_MFMA"):
+        e["valu_per_mfma"] = round((e.get("SQ_INSTS_VALU", 0.0) - e["SQ_INSTS_MFMA"]) / e["SQ_INSTS_MFMA"], 3)      # SQ_INSTS_VALU counts the MFMAs too
+ar = os.path.join(src, "args.txt")
+if os.path.exists(ar):
+    out["bench_args"] = open(ar).read().strip() or "(headline)"
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if st:
