@@ -187,7 +187,9 @@ int poem_set_chains(poem_handle_t h, int enable);
  * "gemm_kslab" (default 1; process-wide): K >= 512 Linears on the K-slab kernel; "bps_defer" (default 0): 1 / 2 / 3 = the
  * basis-point GEMM of block i+1 behind block i's first / second cross attention / its chain instead of up front; "va_p1"
  * (default -1 = small batches): one-query blocks of the full vector attention (0 never, 1 / 2 always with 3 / 2 waves per SIMD);
- * "xattn_merge" -1 / 0 / 1 as above; "xattn_half" (default 1; process-wide): a single sample's merged cross attention on
+ * "xattn_merge" -1 / 0 / 1 as above; "xattn_tail" (round 6, default 1; process-wide; bit-identical): the remainder items of a
+ * cross-attention launch -- 4 of a CU pair's 100 at the headline batch, a 13th item on half of the SIMDs -- run as channel-tile
+ * halves on every SIMD (csrc/attn.hip xattn_half_item); "xattn_half" (default 1; process-wide): a single sample's merged cross attention on
  * 32-channel-tile items (twice the blocks, 48 instead of 64 MFMAs per key tile each); "small_batch" (default 3), a bit mask of launch-count / dependency shortcuts: 1 = one input
  * launch (coordinates + inverse extrinsics + projection table) and no query-embedding broadcast where block 0 runs on the anchor
  * tables, 2 = block 0's anchor keys / values read out of the rows its chain projects (batches of <= 5 samples).

@@ -100,6 +100,88 @@ __device__ long long xattn_ph[8];
 #define XA_STAMP(k) do { } while (0)
 #endif
 
+// ---- round 6: the REMAINDER items of a launch as channel-tile halves.  The static map deals a CU pair's n items to its 8 W waves
+// round-robin: n = 100 at the headline batch, 24 waves -> four full rounds and a remainder of 4 items, which four of the pair's
+// eight SIMDs run as a 13th item while the other four idle (12.5 items per SIMD on average, 13 on the busiest: the kernel's
+// 0.96 quantisation; at 64 samples, 25.0 items per SIMD, the same kernel is 0.885 MFMA-busy instead of 0.845).  A remainder of
+// r <= 4 items is dealt as 2 r HALF items instead, one per SIMD of the pair: the item's full score contraction and softmax but
+// ONE 32-channel tile of P V (48 instead of 64 MFMAs per key tile, the HALF idea of the merged kernel), so the last round is
+// 0.75 of an item on every SIMD instead of a whole one on half of them.  Each output element of the partial is the same fma
+// chain over the keys whichever wave owns its channel tile, and (m, l) -- functions of the scores only -- are written by the
+// tile-0 half: bit-identical partials, same layout.
+template <int DH>
+__device__ __forceinline__ void xattn_half_item(const float* __restrict__ q, int ldq, int qbr, const __amdgpu_buffer_rsrc_t krs,
+                                                const __amdgpu_buffer_rsrc_t vrs, float4* __restrict__ part_o,
+                                                float2* __restrict__ part_ml, int item, int d0, int nqt, int chunks, int heads, int NQ,
+                                                int nkt, int C, int tpc, float kc2, float lazy_raw) {
+  constexpr int KC = DH / 8, DTF = DH / 32, DT = 1;
+  // (the lane id afresh from the hardware -- mbcnt -- instead of the kernel's `lane`: keeping that one alive across the main
+  //  item loop for this tail was the 169th register of a kernel that fits three waves per SIMD in 168)
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int r = lane & 31, h = lane >> 5, loff = lane * 16;
+  const int qt = item % nqt;
+  int t = item / nqt;
+  const int ch = t % chunks;
+  t /= chunks;
+  const int head = t % heads, b = t / heads;
+  const int qrow = min(qt * 32 + r, NQ - 1);
+  float4 qf[KC];
+  {
+    const float* qp = q + ((size_t)b * qbr + qrow) * ldq + head * DH + 4 * h;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) qf[kc] = *reinterpret_cast<const float4*>(qp + 8 * kc);
+  }
+  const int kt0 = ch * tpc;
+  const int ktile_bytes = C * 128;
+  int koff = __builtin_amdgcn_readfirstlane((b * nkt + kt0) * ktile_bytes + head * KC * 1024);
+  int voff = __builtin_amdgcn_readfirstlane((b * nkt + kt0) * ktile_bytes + ((head * DH) / 32 + d0) * 4096);
+  float4 kf[KC], vf[DT][4];
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) kf[kc] = frag_load(krs, loff, koff + kc * 1024);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) vf[0][g] = frag_load(vrs, loff, voff + g * 1024);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 o[DT];
+  o[0] = zero16();
+  float m_ref = -INFINITY, nbias = 0.f, l_run = 0.f;
+  for (int kt = 0; kt < tpc; ++kt) {
+    if ((kt & 3) == 0 && kt) __builtin_amdgcn_s_barrier();      // (as the full items: the block's live waves stay on the same tiles)
+    f32x16 s = zero16();
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+      s = mfma32(kf[kc].x, qf[kc].x, s);
+      s = mfma32(kf[kc].y, qf[kc].y, s);
+      s = mfma32(kf[kc].z, qf[kc].z, s);
+      s = mfma32(kf[kc].w, qf[kc].w, s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int adv = (kt + 1 < tpc) ? ktile_bytes : 0;
+    koff += adv;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) kf[kc] = frag_load(krs, loff, koff + kc * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    POEM_SOFTMAX_TILE(DT)
+    __builtin_amdgcn_sched_barrier(0);
+    voff += adv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      o[0] = mfma32((&vf[0][i >> 2].x)[i & 3], s[i], o[0]);
+      if ((i & 3) == 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        vf[0][i >> 2] = frag_load(vrs, loff, voff + (i >> 2) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  l_run = half_sum(l_run);
+  float4* po = part_o + (size_t)item * (DTF * 4) * 64 + lane;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) nt_store4(po + (d0 * 4 + g) * 64, make_float4(o[0][4 * g], o[0][4 * g + 1], o[0][4 * g + 2], o[0][4 * g + 3]));
+  if (h == 0 && d0 == 0) part_ml[(size_t)item * 32 + r] = make_float2(m_ref, l_run);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
 // MERGE (round 3; four key chunks, the head path's shape): the four chunks of a query tile run on four waves of ONE block at
 // the same time -- wave w = (group w / 4, chunk w % 4), a block's W groups take consecutive query tiles -- and the block
 // merges their partials through LDS (attn_combine_kernel's arithmetic, chunk order) and writes the normalised context rows:
@@ -116,6 +198,8 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
                                                            float4* __restrict__ part_o, float2* __restrict__ part_ml,
                                                            int B, int NQ, int NK, int C, int heads, int tpc, float kc2,
                                                            float lazy_raw, int map, int prio_rot, float* __restrict__ ctx) {
+  const bool split_tail = (map & 16) != 0;      // (bit 4 of `map`: the remainder items as halves)
+  map &= 15;
   constexpr int KC = DH / 8;               // K fragments (float4) per key tile
   constexpr int DTF = (DH + 31) / 32;      // 32-channel tiles of the output
   constexpr int DT = HALF ? 1 : DTF;       // ... of an item
@@ -153,7 +237,17 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
   long long dbg_ph[4] = {0, 0, 0, 0}, dbg_last = 0;
 #endif
 
-  for (int item = lo + first; item < hi; item += stride) {
+  // (pair map, head dim 64: a remainder of <= 4 items behind the full rounds runs as halves -- xattn_half_item above)
+  // (wave-uniform values the compiler cannot prove uniform -- they derive from threadIdx -- pinned to scalar registers: the
+  //  kernel sits at its 168-register budget for three waves per SIMD)
+  int hi_full = hi;
+  if constexpr (!MERGE && DH == 64) {
+    const int rem = (hi - lo) % stride;
+    if (pair && split_tail && rem > 0 && 2 * rem <= 8 && W == 3) hi_full = hi - rem;
+    hi_full = __builtin_amdgcn_readfirstlane(hi_full);
+  }
+  const int tail_items = __builtin_amdgcn_readfirstlane(hi - hi_full), tail_first = __builtin_amdgcn_readfirstlane(first);
+  for (int item = lo + first; item < hi_full; item += stride) {
 #ifdef POEM_LAB
     ++dbg_items;
 #endif
@@ -311,6 +405,12 @@ __global__ __launch_bounds__(256 * W, W) void xattn_kernel(const float* __restri
     // drain the stores here: with stores possibly pending at the key loop's header hipcc cannot count on in-order
     // returns and waits for vmcnt(0) on every iteration, i.e. for the V prefetch it has just issued
     __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
+  if constexpr (!MERGE && DH == 64) {
+    // halves of the remainder: pair-wave index `first` (even: first block of the pair, odd: second) -> SIMD first % 8 of the pair
+    if (tail_first < 2 * tail_items)
+      xattn_half_item<DH>(q, ldq, qbr, krs, vrs, part_o, part_ml, hi_full + (tail_first >> 1), tail_first & 1, nqt, chunks, heads, NQ, nkt, C,
+                          tpc, kc2, lazy_raw);
   }
 #ifdef POEM_LAB
   if (lane == 0) {
@@ -756,6 +856,8 @@ static int poem_attn_cus() { return poem_device_cus(); }
 // and by the operator-level entry point); head dims 32 and 64 only, the others keep the exact kernels
 static std::atomic<int> g_xattn_half{1};      // A/B: channel-tile items of the merged kernel for a single sample (poem_set_option "xattn_half")
 extern "C" void poem_cross_attention_half(int on) { g_xattn_half = on; }
+static std::atomic<int> g_xattn_tail_halves{1};      // A/B: a launch's remainder items as channel-tile halves (poem_set_option "xattn_tail")
+extern "C" void poem_cross_attention_tail_halves(int on) { g_xattn_tail_halves = on; }
 static thread_local int g_xattn_split = 0;      // per host thread, like gemm.hip's split context.  1: split from fp32 images, 2: the images are already split (gemm.hip split output modes)
 extern "C" void poem_cross_attention_split(int on) { g_xattn_split = on; }
 
@@ -811,10 +913,10 @@ extern "C" hipError_t poem_launch_cross_attention_imgq(const float* q, int ldq, 
         e_ != hipSuccess) return e_;                                                                               \
   }                                                                                                                \
   hipLaunchKernelGGL((xattn_stream_kernel<D, WV>), dim3(grid), dim3(256 * WV), (size_t)4 * WV * (D / 8) * 1024, s, q, ldq, qbr, (const float4*)kimg,   \
-                     (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map);           \
+                     (const float4*)vimg, part_o, part_ml, B, NQ, NK, C, heads, tpc, kc2, lazy_raw, map & 15);      \
   if (ctx) hipLaunchKernelGGL((attn_combine_kernel<D>), dim3((waves + 3) / 4), dim3(256), 0, s, part_o, part_ml, ctx, NQ, C, \
                      heads, chunks, waves, kc2)
-  int wsel = 0, map = 2, prio_rot = 0;      // (map 2: two CUs of an XCD share an item range -- 27 % fewer HBM bytes, same time)
+  int wsel = 0, map = 2 | (g_xattn_tail_halves ? 16 : 0), prio_rot = 0;      // (map 2: two CUs of an XCD share an item range -- 27 % fewer HBM bytes, same time; bit 4: remainder items as halves)
   (void)wsel;
 #ifdef POEM_LAB
   if (const char* e = getenv("POEM_ATTN_PRIO")) prio_rot = atoi(e);

@@ -5,10 +5,10 @@
 #include <atomic>
 thread_local int g_last_hip_error = 0;
 
-// The launcher switches that are PROCESS-wide (gemm_xcd_map | gemm_kslab << 1 | xattn_half << 2: statics of gemm.hip / attn.hip,
+// The launcher switches that are PROCESS-wide (gemm_xcd_map | gemm_kslab << 1 | xattn_half << 2 | xattn_tail << 3: statics of gemm.hip / attn.hip,
 // scheduling only, bit-identical results): whichever handle sets one sets it for every handle, so the launch-graph key carries the
 // process's current values, not a per-handle copy that the launches would not follow.
-static std::atomic<int> g_proc_switches{7};
+static std::atomic<int> g_proc_switches{15};
 int poem_process_switches() { return g_proc_switches.load(); }
 
 // Everything of a handle that takes part in a stream capture -- the capture stream, the two side streams, the fork / join
@@ -544,6 +544,7 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "gemm_xcd_map") { poem_gemm_xcd_map(value != 0); g_proc_switches.fetch_and(~1); g_proc_switches.fetch_or(value ? 1 : 0); }
   else if (k == "f1_split") h->f1_split = value != 0;
   else if (k == "xattn_half") { poem_cross_attention_half(value != 0); g_proc_switches.fetch_and(~4); g_proc_switches.fetch_or(value ? 4 : 0); }
+  else if (k == "xattn_tail") { poem_cross_attention_tail_halves(value != 0); g_proc_switches.fetch_and(~8); g_proc_switches.fetch_or(value ? 8 : 0); }
   else if (k == "wait_merge") { if (value < -1 || value > 7) return POEM_E_ARG; h->wait_merge = value; }
   else if (k == "d2_first") { if (value < 0 || value > 1) return POEM_E_ARG; h->d2_first = value; }
   else if (k == "va_p1") { if (value < -1 || value > 2) return POEM_E_ARG; h->va_p1 = value; }

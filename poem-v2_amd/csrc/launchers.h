@@ -88,6 +88,7 @@ void poem_gemm_split_context(const void* packed, size_t bytes, const void* split
 void poem_gemm_split_explicit(const void* img, const float* scales);
 void poem_cross_attention_split(int on);
 void poem_cross_attention_half(int on);
+void poem_cross_attention_tail_halves(int on);
 int poem_cross_attention_merges(int NK, int C, int heads);
 hipError_t poem_launch_cross_attention_merged_rm(const float* q, const float* k, const float* v, float* ctx, int B, int NQ, int NK,
                                                  int C, int heads, float* scratch, hipStream_t s);

@@ -167,6 +167,33 @@ def test_cross_attention_merged_in_kernel_equals_partials_and_combine(B, NQ):
         hip.cross_attention(qd, kd[:, :1024].contiguous(), vd[:, :1024].contiguous(), heads, merged=True)   # one chunk: not taken
 
 
+@pytest.mark.parametrize("B,NQ", [(32, 799), (16, 799), (8, 799), (24, 799), (12, 799), (32, 130)])
+def test_cross_attention_remainder_items_as_halves_are_bit_identical(B, NQ):
+    """attn.hip xattn_half_item (round 6; option "xattn_tail"): the remainder items of a launch -- the 13th item of half the SIMDs at
+    the headline batch -- run as two channel-tile halves on different SIMDs.  Every output element of a partial is the same fma
+    chain over the keys: the context rows equal the all-full-items run BIT for bit.  Batches whose CU-pair ranges leave a
+    remainder of 1 .. 4 items (halves) and of more (12 samples: none), a query count with another tile count, a spiked key."""
+    g = torch.Generator().manual_seed(B * 11 + NQ)
+    NK, C, heads = 4096, 256, 4
+    q = torch.randn(B, NQ, C, generator=g) * 2.0
+    k, v = torch.randn(B, NK, C, generator=g), torch.randn(B, NK, C, generator=g)
+    k[B - 1, 3000] = q[B - 1, 5] * 4
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    L = hip.lib()
+    try:
+        L.poem_cross_attention_tail_halves(0)
+        full = hip.cross_attention(qd, kd, vd, heads)
+    finally:
+        L.poem_cross_attention_tail_halves(1)
+    halves = hip.cross_attention(qd, kd, vd, heads)
+    assert torch.equal(full, halves)
+    sl = slice(B - 1, B)      # (the fp64 reference on one sample)
+    dh = C // heads
+    sp = lambda t: t[sl].double().view(1, -1, heads, dh).permute(0, 2, 1, 3)   # noqa: E731
+    ref = (torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(dh), -1) @ sp(v)).permute(0, 2, 1, 3).reshape(1, NQ, C)
+    assert _md(halves[sl], ref) < 2e-5
+
+
 def test_cross_attention_spiked_key_forces_rescale():
     # one key dominates late in the sequence: the running max jumps -> alpha-rescale branch must be right
     g = torch.Generator().manual_seed(9)
