@@ -561,7 +561,16 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
   const size_t lane_yo = (size_t)(4 * h) * ldy + r, lane_ro = (size_t)(4 * h) * ldr + r;
   // (part / nparts: this block's share of the row groups -- the XCD's range under PanelSegs::xcd_map)
   const int rg_lo = (int)((long)rgroups * part / nparts), rg_hi = (int)((long)rgroups * (part + 1) / nparts);
+#ifndef POEM_PANEL_LAB
+#define POEM_PANEL_LAB 0          // tools/lab/f1_lab: 1 = no image stores (timing only), 4 = store epilogue at priority 3
+#endif
+#ifdef POEM_PANEL_SKEW            // tools/lab/f1_lab: the second wave of every SIMD starts this many 100 MHz ticks late
+  if (wv >= NWV / 2) { const long long t0_ = wall_clock64(); while (wall_clock64() - t0_ < POEM_PANEL_SKEW) __builtin_amdgcn_s_sleep(32); }
+#endif
   for (int rg = rg_lo + bip * NWV + wv; rg < rg_hi; rg += blocks_in_panel * NWV) {
+#if POEM_PANEL_LAB & 4
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const int mt0 = rg * MT;
     // X fragments through the buffer descriptor: per-lane byte offset (row, half) computed once per row group, the
     // k-chunk offset is scalar -- no VALU address arithmetic inside the MFMA loop
@@ -666,6 +675,9 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
       __builtin_amdgcn_sched_barrier(0);
     }
     if (kc < KC) { POEM_MMA(a0, b0) }
+#if POEM_PANEL_LAB & 4
+    __builtin_amdgcn_s_setprio(3);
+#endif
 #undef POEM_LOADA
 #undef POEM_LOADB
 #undef POEM_MMA
@@ -684,8 +696,8 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             float4 v = make_float4(acc[i][n][4 * g], acc[i][n][4 * g + 1], acc[i][n][4 * g + 2], acc[i][n][4 * g + 3]);
-            if (bias) {
-              const float4 bb = *reinterpret_cast<const float4*>(bias + col0 + n * 32 + 8 * g + 4 * h);
+            if (bias) {      // (from LDS: see gemm_panel_kernel)
+              const float4 bb = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(wl + NT * KC * 64) + n * 32 + 8 * g + 4 * h);
               v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
             }
             if (pact == 1) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }
@@ -701,7 +713,11 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
               }
               vprev = v;
             } else {
+#if POEM_PANEL_LAB & 1
+              asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#else
               yp[(size_t)(n * 4 + g) * 64] = v;
+#endif
             }
           }
       }
@@ -751,7 +767,13 @@ __device__ __forceinline__ void panel_rows(const float* __restrict__ X, int ldx,
             }
           } else {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) yp[(size_t)g * 64] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+          for (int g = 0; g < 4; ++g) {
+#if POEM_PANEL_LAB & 1
+            asm volatile("" :: "v"(v[4 * g]), "v"(v[4 * g + 1]), "v"(v[4 * g + 2]), "v"(v[4 * g + 3]));
+#else
+            yp[(size_t)g * 64] = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+#endif
+          }
           }
         } else if (full) {
           if (rl) {
@@ -797,6 +819,11 @@ __global__ __launch_bounds__((SPLIT && !GELU) ? POEM_GS_WAVES * 64 : 512, 2) voi
   {
     const float4* src = Wp + (size_t)panel * NT * KC * 64;
     for (int i = tid; i < NT * KC * 64; i += NWV * 64) wl[i] = src[i];
+    // the panel's NT * 32 bias values behind it (round 6): the K-image epilogue read them from global memory between its stores,
+    // and on gfx9 a load's `s_waitcnt vmcnt(0)` also waits for every older STORE to be acknowledged -- the epilogue was a chain
+    // of 32 store round trips per wave and row group (13 % of the F1 GEMM, tools/lab/f1_lab).  LDS reads count on lgkmcnt.
+    float* lb = reinterpret_cast<float*>(wl + NT * KC * 64);
+    if (tid < NT * 32) lb[tid] = bias ? bias[panel * NT * 32 + tid] : 0.f;
   }
   __syncthreads();
   const int col0 = panel * NT * 32;
@@ -835,10 +862,10 @@ static hipError_t launch_panel_t(const float* X, int ldx, const void* Wp, const 
                                  float* Y, int ldy, int M, int N, int K, int act, int act_split, int act2,
                                  const PanelSegs& segs, hipStream_t s, const float* tile_scales = nullptr,
                                  int scale_stride = 0) {
-  const size_t lds = (size_t)NT * (K / 8) * 64 * 16;
+  const size_t lds = (size_t)NT * (K / 8) * 64 * 16 + (size_t)NT * 32 * sizeof(float);      // W panel | its bias values
   auto kern = gemm_panel_kernel<NT, MT, GELU, SPLIT>;
   static std::atomic<unsigned long long> optin{0};
-  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), 128 * 1024, optin); e != hipSuccess) return e;
+  if (hipError_t e = poem_optin_lds(reinterpret_cast<const void*>(kern), 128 * 1024 + 512, optin); e != hipSuccess) return e;
   const int panels = N / (32 * NT);
   const int grid = std::max(poem_num_cus(), panels);
   PanelSegs sg = segs;
