@@ -27,13 +27,16 @@ def ring_extrinsics(n_views, ring=8, hand=(0.0, 0.0, 0.6), jitter=None):
     return out.float()
 
 
-def synthetic_batch(views, seed=0, in_channels=160, feat_hw=16, img=256, ring=None):
-    """views: list of views per sample.  Returns the arguments of ``POEM_Generalized_Head.forward``."""
+def synthetic_batch(views, seed=0, in_channels=160, feat_hw=16, img=256, ring=None, nan_views=None):
+    """views: list of views per sample.  Returns the arguments of ``POEM_Generalized_Head.forward``.  ``nan_views``: global view
+    indices whose feature maps are NaN (the *nan fixtures: what `torch.nan_to_num`, ptEmb_head.py:944 upstream, is there for)."""
     g = torch.Generator().manual_seed(seed)
     views = [int(v) for v in views]
     B, BN = len(views), int(sum(views))
     ring = ring or max(8, max(views))
     mlvl_feat = torch.randn(BN, in_channels, feat_hw, feat_hw, generator=g)
+    for v in (nan_views or ()):
+        mlvl_feat[int(v)] = float("nan")
     K = torch.tensor([[300.0, 0, img / 2], [0, 300.0, img / 2], [0, 0, 1]])
     cam_intr = K[None].repeat(BN, 1, 1).contiguous()
     extr = []

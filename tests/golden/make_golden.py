@@ -80,6 +80,12 @@ CASES = {
                         pe_normalize=False, lid=True, depth_num=16, depth_start=0.05, depth_end=1.5,
                         position_range=[-0.5, -0.7, 0.1, 0.7, 0.5, 1.4]),
     "mediumpetr": dict(model="medium", embed=256, nsample=4096, views=[3, 5], seed=34, parametric=False, full=False, petr=True),
+    # round 6.  What the reference does with a NaN sample (ptEmb_head.py:944: torch.nan_to_num in front of the de-normalisation):
+    # the single view of sample 1 / only a NON-master view of sample 1 is NaN -- that sample comes out as its hand centre in
+    # every layer, the others as without it.  (A v_max-style ReLU would launder the NaN before nan_to_num sees it.)
+    "tinynan": dict(model="medium", embed=32, nsample=1024, views=[2, 1, 3], seed=13, parametric=False, full=False, nan_views=[2]),
+    "tinynan2": dict(model="medium", embed=32, nsample=1024, views=[2, 3], seed=14, parametric=False, full=False, nan_views=[3]),
+    "smallnan": dict(model="small", embed=128, nsample=4096, views=[2, 3, 2], seed=17, parametric=False, full=False, nan_views=[3]),
 }
 
 
@@ -150,7 +156,7 @@ def run_reference(spec):
             assert k in ref_sd and tuple(ref_sd[k].shape) == tuple(v.shape), f"key/shape mismatch: {k}"
         missing, unexpected = head.load_state_dict(sd, strict=False)
         assert not unexpected, unexpected
-        batch = synthetic_batch(spec["views"], seed=spec["seed"])
+        batch = synthetic_batch(spec["views"], seed=spec["seed"], nan_views=spec.get("nan_views"))
         taps = {}
         import lib.models.heads.ptEmb_head as H
         orig_gs = H.F.grid_sample

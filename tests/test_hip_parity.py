@@ -1409,6 +1409,25 @@ def test_full_size_config_c5_ragged_2_to_10_views_batch_64():
     _full_size_properties(dict(embed=256, nsample=4096, views=views, seed=51, parametric=False), n_oracle=2)
 
 
+@pytest.mark.parametrize("name", ["tinynan", "tinynan2", "smallnan"])
+def test_nan_fixtures_vs_reference(name):
+    """The reference's own outputs for a batch with a NaN sample (round-6 fixtures, tests/golden/make_golden.py): the HIP head
+    returns the poisoned sample's centre bit for bit and the clean samples within the path's bar (operator front end at C = 32,
+    fused front end and chains at C = 128)."""
+    z, meta = load_golden(name)
+    spec = meta["spec"]
+    ref = torch.from_numpy(z["all_coords_preds"])
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(case_setup(spec)[3], DEV)
+    with torch.no_grad():
+        outs = [head(feat, metas, rj)["all_coords_preds"].cpu() for _ in range(3)]      # plain launches, capture, replay
+    for out in outs:
+        assert torch.isfinite(out).all()
+        assert torch.equal(out[:, 1], ref[:, 1])                       # the poisoned sample: its centre, exactly
+        for b in range(ref.shape[1]):
+            assert float(torch.norm(out[-1, b, 21:] - ref[-1, b, 21:], dim=-1).mean()) < 1e-6, b
+
+
 def test_nan_features_of_one_sample_give_its_centre_and_leave_the_others_alone():
     """SURVEY a20, whole path: ``interm_ref_pts = torch.nan_to_num(interm_ref_pts)`` (ptEmb_head.py:944) in front of the
     de-normalisation -- a sample whose backbone features are NaN comes out as its hand centre in every layer (0 * radius + c), and,

@@ -42,7 +42,7 @@ def case_setup(spec):
                         **{k: (tuple(spec[k]) if k == "position_range" else spec[k]) for k in PE_SPEC_KEYS if k in spec})
     w = seeded_weights(spec)
     consts = oracle_consts(spec["nsample"])
-    batch = synthetic_batch(spec["views"], seed=spec["seed"])
+    batch = synthetic_batch(spec["views"], seed=spec["seed"], nan_views=spec.get("nan_views"))
     return cfg, w, consts, batch
 
 
