@@ -661,7 +661,10 @@ static hipError_t launch_chain16_k(const ChainArgs& a, int cus, hipStream_t s) {
   // tiles per CU: two co-resident ones from 3 units on where the LDS holds two (one block's fill / LayerNorm / stores then
   // overlap the other's MFMAs: B = 16, 4 units per CU, 127 us as one tile vs 116 us as two), else as few as fit
   const bool pair = 2 * lds <= 160 * 1024 && per_cu >= 3;
-  const int layers = std::max(pair ? 2 : 1, (per_cu + MAXRU - 1) / MAXRU);
+  int layers = std::max(pair ? 2 : 1, (per_cu + MAXRU - 1) / MAXRU);
+#ifdef POEM_C16_STAMPS   // tools/lab only: more, smaller tiles per CU (the later ones go to whichever CU frees a slot first)
+  if (const char* e = getenv("POEM_C16_LAYERS")) layers = std::max(layers, atoi(e));
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)(ncu * layers)), dim3(NW * 64), lds, s, a, ncu, layers);
   return hipGetLastError();
 }
