@@ -80,7 +80,10 @@ typedef struct poem_config {
   int32_t nquery;      /* Q: 799 */
   int32_t heads;       /* NUM_ATTENTION_HEADS (4) */
   int32_t nblocks;     /* N_BLOCKS (3) */
-  int32_t knn;         /* N_NEIGHBOR = N_NEIGHBOR_QUERY; must be 32 */
+  int32_t knn;         /* N_NEIGHBOR (ptEmb_transformer.py:30), 1..32; N_NEIGHBOR_QUERY (:31) is the same unless
+                          poem_set_option(h, "knn_query", k) says otherwise.  The release configs set 32 for both; counts below 32
+                          run the masked vector attention (the search's first k of its 32 nearest).  Block 0 takes the 32 fixed
+                          anchors whatever the keys say (assets/anchor.npy, point_transformers.py:10-32). */
   int32_t parametric;  /* TRANSFORMER.PARAMETRIC_OUTPUT */
   int32_t feat_h, feat_w; /* backbone feature map (16x16) */
   int32_t max_views;   /* largest views-per-sample the positional table is folded for */
@@ -182,6 +185,7 @@ int poem_set_chains(poem_handle_t h, int enable);
  * kernels, 1 = 32 rows, 2 = 64 rows (csrc/chain.hip), 3 = 16-row units on v_mfma_f32_16x16x4_f32 (csrc/chain16.hip) -- any
  * choice gives the same bits; "knn_fma" (default 0): neighbour distances rounded as pytorch3d's CUDA kernel (poem_knn_ex below)
  * -- the one switch that is NOT round-off neutral by design.
+ * "knn_query" (round 6; default 0 = poem_config_t.knn): N_NEIGHBOR_QUERY, 1..32 -- part of the model's configuration, not an A/B switch.
  * Round 4, all bit-identical: "gemm_xcd_map" (default 1; process-wide): panel GEMM blocks of one XCD own a row range and all its
  * column panels (csrc/gemm.hip); "f1_split" (default 1): the basis-point GEMM of blocks >= 1 as a 4C- and a 2C-column launch;
  * "gemm_kslab" (default 1; process-wide): K >= 512 Linears on the K-slab kernel; "bps_defer" (default 0): 1 / 2 / 3 = the

@@ -32,7 +32,8 @@ class PathConfig:
     nquery: int = 799         # hard-coded 799 in the reference
     heads: int = 4            # NUM_ATTENTION_HEADS
     nblocks: int = 3          # N_BLOCKS
-    knn: int = 32             # N_NEIGHBOR = N_NEIGHBOR_QUERY
+    knn: int = 32             # N_NEIGHBOR: the vector cross attention's neighbours (pt_metro_transformer.py:27-31)
+    knn_query: int = 0        # N_NEIGHBOR_QUERY: the vector self attention's (:26); 0 = the same as knn (every release config: 32 / 32)
     radius: float = 0.1       # RADIUS_SAMPLE
     parametric: bool = False  # TRANSFORMER.PARAMETRIC_OUTPUT
     center_idx: int = 9       # TRANSFORMER_CENTER_IDX
@@ -382,7 +383,7 @@ def decoder_block(w, cfg, i, query_xyz, query_feats, pt_xyz, pt_feats, consts, h
         nxyz_s = consts["anchor"].view(1, 1, -1, 3).expand(B, Q, -1, -1)
         idx_c, nxyz_c = idx_s, nxyz_s
     else:
-        idx_s = knn_indices(query_xyz, query_xyz, cfg.knn, cfg.knn_fma)
+        idx_s = knn_indices(query_xyz, query_xyz, cfg.knn_query or cfg.knn, cfg.knn_fma)
         nxyz_s = gather_xyz(query_xyz, idx_s)
         idx_c = knn_indices(query_xyz, pt_xyz, cfg.knn, cfg.knn_fma)
         nxyz_c = gather_xyz(pt_xyz, idx_c)

@@ -320,7 +320,9 @@ struct DecoderRun {
     const float* xyz = p.xyz[i];
     if (ov && i > 0 && !knn_waited[i]) HIPCHK(hipStreamWaitEvent(s, h->ev_knn[i], 0));
     const bool prof = prof_begin();
+    const int kq = shared ? 32 : (h->knn_query ? h->knn_query : c.knn);      // N_NEIGHBOR_QUERY (block 0: the 32 anchors)
     if (h->precision != POEM_PRECISION_FP32) {
+      if (kq != 32) return POEM_E_UNSUPPORTED;      // the split-precision kernel has no masked form
       const auto& sw = h->split[2 * i];
       HIPCHK(poem_launch_vector_attention_split(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
                                                 h->R(vsb + 5), sw.w[0], h->R(vsb + 7), sw.w[1], sw.w[2], sw.scales, p.rs, B, Q, C,
@@ -336,10 +338,12 @@ struct DecoderRun {
                                                    p.tab_p[0], p.rs, B, Q, C, 3 * C, 2 * C, 2 * C, s));
       }
     } else {
-      poem_vecattn_one_query_blocks(h->va_p1);           // (thread-local launcher switch: this handle's value for this launch only)
+      poem_vecattn_one_query_blocks(h->va_p1);           // (thread-local launcher switches: this handle's values for this launch only)
+      poem_vecattn_valid_neighbours(kq);
       const hipError_t ve = poem_launch_vector_attention(xyz, xyz, anchor, idx_s, shared, p.y3, p.y3 + C, p.y3 + 2 * C, Q, h->R(vsb + 4),
                                                          h->R(vsb + 5), h->P(vsb + 6), h->R(vsb + 7), h->fused[i].w[5], h->R(vsb + 9),
                                                          h->P(vsb + 10), h->R(vsb + 11), p.rs, B, Q, C, 3 * C, 3 * C, 3 * C, 1, s);
+      poem_vecattn_valid_neighbours(32);
       poem_vecattn_one_query_blocks(0);
       HIPCHK(ve);
     }
@@ -368,7 +372,9 @@ struct DecoderRun {
         bps_waited[k] = true;
       }
     const bool prof = prof_begin();
+    const int kc = shared ? 32 : c.knn;                                       // N_NEIGHBOR
     if (h->precision != POEM_PRECISION_FP32) {
+      if (kc != 32) return POEM_E_UNSUPPORTED;
       const auto& sw = h->split[2 * i + 1];
       HIPCHK(poem_launch_vector_attention_split(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
                                                 p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4), h->R(vcb + 5), sw.w[0],
@@ -379,10 +385,12 @@ struct DecoderRun {
                                                    p.tab_p[1], p.rc, B, Q, C, C, 2 * C, 2 * C, s));
     } else {
       poem_vecattn_one_query_blocks(h->va_p1);
+      poem_vecattn_valid_neighbours(kc);
       const hipError_t ve = poem_launch_vector_attention(xyz, pt_xyz, anchor, idx_c, shared, p.qc, p.y1[i] + 4 * (size_t)BS * C,
                                                          p.y1[i] + 5 * (size_t)BS * C, S, h->R(vcb + 4), h->R(vcb + 5), h->P(vcb + 6),
                                                          h->R(vcb + 7), h->fused[i].w[6], h->R(vcb + 9), h->P(vcb + 10), h->R(vcb + 11), p.rc, B,
                                                          Q, C, C, C, C, 1, s);
+      poem_vecattn_valid_neighbours(32);
       poem_vecattn_one_query_blocks(0);
       HIPCHK(ve);
     }

@@ -174,6 +174,8 @@ struct poem_handle_s {
   // returns (pose, betas) and the caller runs its own layer + poem_finalize_parametric (rounds 1-5).
   const float* mano_table = nullptr;
   int mano_center = 9;
+  int knn_query = 0;         // N_NEIGHBOR_QUERY when it differs from cfg.knn (= N_NEIGHBOR); 0: the same.  Both 1..32: counts below 32 mask
+                             // the vector attention's last columns (vecattn.hip MODE 3); block 0 takes the 32 anchors either way (Q2)
   int knn_fma = 0;           // neighbour distances with the fma contraction of pytorch3d's CUDA kernel (knn.hip); default: the CPU path's rounding
   int chain_tile = 0;        // chain row-tile height: 0 = per launch (chain.hip chain_tile_p), 1 = 32 rows, 2 = 64 rows (A/B)
   // The block-0 anchor tables are functions of the handle's constants only (template, anchors, weights): like the folded

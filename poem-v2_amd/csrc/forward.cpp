@@ -232,7 +232,7 @@ struct HeadRun {
     //  batch's own view total: that total joins the key there)
     const std::vector<int64_t> key = {B, plan_views, fused_fe ? -1 : BN, (int64_t)(uintptr_t)workspace, h->precision, h->anchor_tables, h->chains,
                                       h->fused_sampling, h->tables_first, h->chain_combine, h->knn_early, h->overlap, h->chain_tile,
-                                      h->tables_cached, h->knn_fma, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, poem_process_switches(), h->f1_split, h->va_p1, h->group_min_views, h->group_xcd, h->d2_first, h->wait_merge,
+                                      h->tables_cached, h->knn_fma, h->knn_query, h->taps, c.parametric, h->xattn_merge, h->small_batch, h->bps_defer, poem_process_switches(), h->f1_split, h->va_p1, h->group_min_views, h->group_xcd, h->d2_first, h->wait_merge,
                                       (int64_t)(uintptr_t)h->mano_table, h->mano_center};
     poem_handle_s::GraphEntry* hit = nullptr;
     for (auto& g : h->graph_cache)

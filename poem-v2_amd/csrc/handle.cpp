@@ -222,7 +222,7 @@ int check_config(const poem_config_t* c) {
   if (!c) return POEM_E_ARG;
   const int C = c->embed;
   if (C < 32 || C > 1024 || (C & (C - 1))) return POEM_E_UNSUPPORTED;       // 32,64,...,1024
-  if (c->knn != 32) return POEM_E_UNSUPPORTED;
+  if (c->knn < 1 || c->knn > 32) return POEM_E_UNSUPPORTED;       // the attention tile holds 32 neighbour columns (vecattn.hip)
   if (c->in_channels % 8 || c->nsample % 32 || c->nsample % C) return POEM_E_UNSUPPORTED;
   if (c->heads <= 0 || C % c->heads) return POEM_E_UNSUPPORTED;
   const int dh = C / c->heads;
@@ -539,6 +539,11 @@ int poem_set_option(poem_handle_t h, const char* name, int value) {
   else if (k == "tables_first") h->tables_first = value != 0;
   else if (k == "tables_cached") h->tables_cached = value != 0;
   else if (k == "knn_fma") h->knn_fma = value != 0;
+  else if (k == "knn_query") {
+    if (value < 0 || value > 32) return POEM_E_ARG;
+    if (h->precision != POEM_PRECISION_FP32 && value != 0 && value != 32) return POEM_E_UNSUPPORTED;
+    h->knn_query = value;
+  }
   else if (k == "graphs") h->graphs = value != 0;
   else if (k == "graph_eager") h->graph_eager = value != 0;
   else if (k == "gemm_xcd_map") { poem_gemm_xcd_map(value != 0); g_proc_switches.fetch_and(~1); g_proc_switches.fetch_or(value ? 1 : 0); }
@@ -590,6 +595,8 @@ int poem_set_anchor_tables(poem_handle_t h, int enable) {
 int poem_set_precision(poem_handle_t h, int mode) {
   if (!h || mode < POEM_PRECISION_FP32 || mode > POEM_PRECISION_SPLIT_F16X3_ALL) return POEM_E_ARG;
   if (mode != POEM_PRECISION_FP32 && (!h->split_mem || !h->gemm_split)) return POEM_E_UNSUPPORTED;      // embed < 128
+  if (mode != POEM_PRECISION_FP32 && (h->cfg.knn != 32 || (h->knn_query && h->knn_query != 32)))
+    return POEM_E_UNSUPPORTED;      // the split-precision vector attention has no masked form (decoder.cpp checks again)
   h->precision = mode;
   return POEM_OK;
 }

@@ -99,6 +99,7 @@ void poem_gemm_split_images(int on);
 void poem_gemm_xcd_map(int on);
 void poem_gemm_kslab(int on);
 void poem_vecattn_one_query_blocks(int on);
+void poem_vecattn_valid_neighbours(int k);
 hipError_t poem_launch_vector_attention_split(const float* query_xyz, const float* src_xyz, const float* anchor_xyz,
                                               const int* idx, int shared_idx, const float* q, const float* k,
                                               const float* v, int nsrc, const float* wd1, const float* bd1,

@@ -50,6 +50,7 @@ struct VecAttnArgs {
   int composed;             // 1: q, k are W_g1 q + (W_g1 b_d2 + b_g1) and W_g1 k, `wg1` is W_g1 W_d2 (see vecattn_kernel)
   float4* tab_g;            // MODE 1 writes / MODE 2 reads: (W_g1 W_d2) h_ij per (query, anchor), C/D fragment images
   float4* tab_p;            // MODE 1 writes / MODE 2 reads: pos_ij = W_d2 h_ij + b_d2, transposed (lane = channel) images
+  int kvalid;               // MODE 3: the first `kvalid` of the 32 neighbour columns count (N_NEIGHBOR / N_NEIGHBOR_QUERY < 32)
 };
 
 // arrival parity per CU (key: XCC id, HW_ID[15:8]); atomicInc wraps 0 -> 1 -> 0, so the table resets itself when
@@ -153,9 +154,14 @@ __device__ __forceinline__ void chain_gemm(const float4* __restrict__ Wp, const 
 //   MODE 2  per sample: g = relu(qg_i - kg_j + tab_g) -> X, GEMM 3, softmax-sum with pos from tab_p -- one C x C GEMM per
 //           neighbour column instead of three, no coordinate stage, no transpose scratch.  Items are dealt so that the
 //           blocks an XCD runs back to back share a query group (its table tiles stay in that XCD's L2).
+//   MODE 3  = MODE 0 for neighbour counts below 32 (the reference's N_NEIGHBOR / N_NEIGHBOR_QUERY keys, ptEmb_transformer.py:30-31
+//           upstream; every release config sets 32): the search returns its 32 nearest in ascending order, the tile keeps its 32
+//           columns, and the softmax takes the columns from `kvalid` on as -inf -- weight exactly 0 in the sum and in the weighted
+//           sum.  The 32-neighbour kernels are untouched by it.
 template <int C, int P, int NW, int MINW, bool COMP, int MODE = 0>
 __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
   static_assert(MODE == 0 || COMP, "table modes exist for the composed form only");
+  constexpr bool MASK = MODE == 3;
   constexpr int NTILE = C / 32;
   constexpr int TPW = C / 32 / NW;
   constexpr int XS = 32 * P;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
 
   for (int item = blockIdx.x; item < total; item += gridDim.x) {
   int b = item / groups, ig = item % groups;
-  if (MODE == 0 && POEM_VA_XCD_SAMPLES && gridDim.x == (unsigned)total && (total & 7) == 0) {
+  if ((MODE == 0 || MODE == 3) && POEM_VA_XCD_SAMPLES && gridDim.x == (unsigned)total && (total & 7) == 0) {
     // block ids go round-robin over the 8 XCDs: XCD x takes the x-th eighth of the (sample, query group) list, i.e. whole
     // samples -- a sample's key / value rows (8 MB at S = 4096, C = 256) are then gathered through ONE L2 instead of all eight
     const int it = (item & 7) * (total >> 3) + (item >> 3);
@@ -509,6 +515,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void vecattn_kernel(VecAttnArgs A) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) pt[i] = COMP ? pos[tp][p][i] : scr[mfma_row(i, h) * 33 + j];
       f32x16& a = acc[tp][p];
+      if (MASK) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (mfma_row(i, h) >= A.kvalid) a[i] = -INFINITY;
+      }
       float mx = fmaxf(fmaxf(a[0], a[1]), a[2]);
 #pragma unroll
       for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, a[i]), a[i + 1]);
@@ -558,8 +569,14 @@ template <int C, int P, int NW, int MINW>
 static hipError_t launch_va(const VecAttnArgs& a, hipStream_t s, int mode = 0) {
   if (mode == 1) return launch_va_t<C, P, NW, MINW, true, 1>(a, s);
   if (mode == 2) return launch_va_t<C, P, NW, MINW, true, 2>(a, s);
+  if (mode == 3) return a.composed ? launch_va_t<C, P, NW, MINW, true, 3>(a, s) : hipErrorInvalidValue;
   return a.composed ? launch_va_t<C, P, NW, MINW, true>(a, s) : launch_va_t<C, P, NW, MINW, false>(a, s);
 }
+
+// Neighbour count of the next full-kernel launches from this thread (decoder.cpp sets it around the launches of blocks >= 1 when the
+// handle's N_NEIGHBOR / N_NEIGHBOR_QUERY is below 32, and back): 32 = the unmasked kernels.
+static thread_local int g_va_kvalid = 32;
+extern "C" void poem_vecattn_valid_neighbours(int k) { g_va_kvalid = k; }
 
 // One-query blocks for the full kernel (MODE 0) at embed 256 (A/B: poem_set_option "va_p1"; the table modes keep the query
 // groups their images are laid out for): twice the items, half the work each -- a batch of two leaves the busiest CU with 7
@@ -571,6 +588,10 @@ extern "C" void poem_vecattn_one_query_blocks(int on) { g_va_p1 = on; }
 static int va_group_size(int C) { return C == 128 ? 4 : (C >= 512 ? 1 : 2); }
 
 static hipError_t dispatch_va(const VecAttnArgs& a, int C, hipStream_t s, int mode) {
+  if (mode == 0 && a.kvalid != 32) {
+    if (a.kvalid < 1 || a.kvalid > 32) return hipErrorInvalidValue;
+    mode = 3;
+  }
   switch (C) {
     case 32: return launch_va<32, 2, 1, 1>(a, s, mode);
     case 64: return launch_va<64, 2, 2, 1>(a, s, mode);
@@ -600,7 +621,7 @@ extern "C" hipError_t poem_launch_vector_attention_tables(const float* query_xyz
                                                           const float* bd2, const void* wg1d2, float* tab_g,
                                                           float* tab_p, int Q, int C, hipStream_t s) {
   VecAttnArgs a{query_xyz, nullptr, anchor_xyz, idx, 1, nullptr, nullptr, nullptr, 1, wd1, bd1, (const float4*)wd2, bd2,
-                (const float4*)wg1d2, nullptr, nullptr, nullptr, nullptr, 1, Q, 0, 0, 0, 0, 1, (float4*)tab_g, (float4*)tab_p};
+                (const float4*)wg1d2, nullptr, nullptr, nullptr, nullptr, 1, Q, 0, 0, 0, 0, 1, (float4*)tab_g, (float4*)tab_p, 32};
   return dispatch_va(a, C, s, 1);
 }
 
@@ -610,7 +631,7 @@ extern "C" hipError_t poem_launch_vector_attention_anchored(const int* idx, cons
                                                             const float* tab_g, const float* tab_p, float* out, int B,
                                                             int Q, int C, int ldq, int ldk, int ldv, hipStream_t s) {
   VecAttnArgs a{nullptr, nullptr, nullptr, idx, 1, qg, kg, v, nsrc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                (const float4*)wg2, nullptr, out, B, Q, ldq, ldk, ldv, 0, 1, (float4*)tab_g, (float4*)tab_p};
+                (const float4*)wg2, nullptr, out, B, Q, ldq, ldk, ldv, 0, 1, (float4*)tab_g, (float4*)tab_p, 32};
   return dispatch_va(a, C, s, 2);
 }
 
@@ -621,7 +642,7 @@ extern "C" hipError_t poem_launch_vector_attention(const float* query_xyz, const
                                                    const void* wg2, const float* bg2, float* out, int B, int Q, int C,
                                                    int ldq, int ldk, int ldv, int composed, hipStream_t s) {
   VecAttnArgs a{query_xyz, src_xyz, anchor_xyz, idx, shared_idx, q, k, v, nsrc, wd1, bd1, (const float4*)wd2, bd2,
-                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q, ldq, ldk, ldv, 0, composed, nullptr, nullptr};
+                (const float4*)wg1, bg1, (const float4*)wg2, bg2, out, B, Q, ldq, ldk, ldv, 0, composed, nullptr, nullptr, g_va_kvalid};
 #ifdef POEM_LAB
   static const int stagger_env = getenv("POEM_VA_STAGGER") ? atoi(getenv("POEM_VA_STAGGER")) : 0;   // lab only, read once
   a.stagger = stagger_env;

@@ -186,8 +186,8 @@ class POEM_Generalized_Head(nn.Module):
                 self._engines.pop(next(iter(self._engines)))
             t = self.transformer
             cfg = hip.make_config(self.embed_dims, in_channels=self.in_channels, nsample=self.nsample, nquery=799,
-                                  heads=t.num_attention_heads, nblocks=t.layer_num, parametric=self.parametric_output,
-                                  max_views=self.max_views, radius=self.radius, ln_eps=t.layer_norm_eps,
+                                  heads=t.num_attention_heads, nblocks=t.layer_num, knn=t.nneighbor,
+                                  parametric=self.parametric_output, max_views=self.max_views, radius=self.radius, ln_eps=t.layer_norm_eps,
                                   feat_h=self._feat_hw[0], feat_w=self._feat_hw[1], pe_normalize=self.pe_normalize,
                                   petr_embedding=self.PETR_embedding, depth_num=self.depth_num, lid=self.LID,
                                   depth_start=self.depth_start, depth_end=self.depth_end, position_range=self.position_range)
@@ -200,6 +200,8 @@ class POEM_Generalized_Head(nn.Module):
                 eng.set_anchor_tables(False)
             if not self._chains:
                 eng.set_chains(False)
+            if t.nneighbor_query != t.nneighbor:
+                eng.set_option("knn_query", t.nneighbor_query)
             for k, v in self._options.items():
                 eng.set_option(k, v)
             if self.parametric_output:

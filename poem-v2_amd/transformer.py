@@ -80,8 +80,9 @@ class PtEmbedTRv4(nn.Module):
         self.nneighbor_query = cfg.N_NEIGHBOR_QUERY
         self.layer_num = cfg.N_BLOCKS
         self.nquery = 799
-        if self.nneighbor != 32 or self.nneighbor_query != 32:
-            raise NotImplementedError("the MI355X kernels are specialised for N_NEIGHBOR = N_NEIGHBOR_QUERY = 32")
+        if not (1 <= self.nneighbor <= 32 and 1 <= self.nneighbor_query <= 32):
+            raise NotImplementedError("the MI355X vector attention holds 32 neighbour columns per query: N_NEIGHBOR and "
+                                      "N_NEIGHBOR_QUERY must be in 1..32 (counts below 32 run the masked kernel)")
         # BertConfig defaults the reference reads from config/backbone/bert_cfg.json (ptEmb_transformer.py:334)
         self.initializer_range, self.layer_norm_eps = 0.02, 1e-12
         p = os.path.join("config", "backbone", "bert_cfg.json")
@@ -121,9 +122,11 @@ class PtEmbedTRv4(nn.Module):
             w = {k: (sd[k] if k in sd else torch.zeros(s)) for k, s in shapes.items()}
             cfg = hip.make_config(C, heads=self.num_attention_heads, nblocks=self.layer_num,
                                   parametric=self.parametric_output, ln_eps=self.layer_norm_eps,
-                                  nsample=self._nsample)
+                                  nsample=self._nsample, knn=self.nneighbor)
             bps, anchor, aidx = hip.load_assets(self._nsample)
             eng = hip.Engine(cfg, w, bps, anchor, aidx, torch.zeros(self.nquery, 3), device)
+            if self.nneighbor_query != self.nneighbor:
+                eng.set_option("knn_query", self.nneighbor_query)
             self._own_engine = (sig, eng)
         return self._own_engine[1]
 

@@ -86,6 +86,14 @@ CASES = {
     "tinynan": dict(model="medium", embed=32, nsample=1024, views=[2, 1, 3], seed=13, parametric=False, full=False, nan_views=[2]),
     "tinynan2": dict(model="medium", embed=32, nsample=1024, views=[2, 3], seed=14, parametric=False, full=False, nan_views=[3]),
     "smallnan": dict(model="small", embed=128, nsample=4096, views=[2, 3, 2], seed=17, parametric=False, full=False, nan_views=[3]),
+    # round 6.  N_NEIGHBOR / N_NEIGHBOR_QUERY below the release configs' 32 (ptEmb_transformer.py:30-31; the vector cross / self
+    # attention of blocks 1, 2 -- block 0 takes the 32 anchors of assets/anchor.npy whatever the keys say): stage taps at a toy
+    # width, hot weights at the small release shape (the neighbour sets matter), the medium release shape
+    "tinyk": dict(model="medium", embed=32, nsample=1024, views=[2, 1, 3], seed=41, parametric=False, full=True, knn=16, knn_query=8),
+    "smallk": dict(model="small", embed=128, nsample=4096, views=[3, 2], seed=42, parametric=False, full=False, gain=2.5,
+                   ln_spread=0.3, knn=20, knn_query=12),
+    "mediumk": dict(model="medium", embed=256, nsample=4096, views=[4, 2], seed=43, parametric=False, full=False, knn=16,
+                    knn_query=24),
 }
 
 
@@ -137,6 +145,8 @@ def run_reference(spec):
     cfg["TRANSFORMER"]["PARAMETRIC_OUTPUT"] = spec["parametric"]
     cfg["POSITIONAL_ENCODING"]["NUM_FEATS"] = C // 2
     cfg["POSITIONAL_ENCODING"]["NORMALIZE"] = bool(spec.get("pe_normalize", True))
+    cfg["TRANSFORMER"]["N_NEIGHBOR"] = spec.get("knn", 32)
+    cfg["TRANSFORMER"]["N_NEIGHBOR_QUERY"] = spec.get("knn_query") or spec.get("knn", 32)
     if spec.get("petr"):
         cfg["PETR_EMBEDDING"] = True
         for key, name in (("DEPTH_NUM", "depth_num"), ("LID", "lid"), ("DEPTH_START", "depth_start"), ("DEPTH_END", "depth_end"),

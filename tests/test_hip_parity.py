@@ -404,7 +404,7 @@ def test_frustum_features_match_the_oracle(lid, depth_num, fh, fw, img):
     assert float(((got.abs() > clamp - 1e-3) != edge).float().mean()) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinypetr", "tinynonorm", "tinypetrlid"])
+@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinypetr", "tinynonorm", "tinypetrlid", "tinyk"])
 def test_head_tiny_stage_taps_vs_golden(name):
     z, meta = load_golden(name)
     spec = meta["spec"]
@@ -434,7 +434,7 @@ def test_head_tiny_stage_taps_vs_golden(name):
         assert _md(out["pred_shape"], torch.from_numpy(z["pred_shape"])) < 2e-5
 
 
-@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano", "mediumpetr"])
+@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano", "mediumpetr", "mediumk"])
 def test_head_release_shapes_vs_golden_and_oracle(name):
     """BASELINE.json bar: MPVPE of the HIP path vs the reference <= 1e-3 mm (1e-6 m), last decoder layer."""
     z, meta = load_golden(name)
@@ -1574,3 +1574,58 @@ def test_eval_single_script_runs_the_path(tmp_path):
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["scope"] == "shards->images->verts" and res["samples"] == 8 and np.isfinite(res["MPVPE_mm_vs_record_gt"])
     assert sorted(os.listdir(tmp_path / "shards")) == [f"DexYCB_mv_test-00000{i}.tar" for i in range(4)]
+
+
+@pytest.mark.gpu
+def test_neighbour_counts_below_32_are_part_of_the_handle_and_split_precision_refuses_them():
+    """N_NEIGHBOR / N_NEIGHBOR_QUERY < 32 (round 6: the masked vector attention, vecattn.hip MODE 3): the counts reach the engine
+    (`poem_config_t.knn`, option "knn_query"), a head built with 32 / 32 on the same weights lands elsewhere, graph replay and plain
+    launches agree bit for bit, and the split-precision kernels -- which have no masked form -- refuse instead of ignoring the keys."""
+    z, meta = load_golden("smallk")
+    spec = meta["spec"]
+    cfg, w, consts, batch = case_setup(spec)
+    feat, metas, rj = batch_to(batch, DEV)
+    head = build_hip_head(spec, DEV)
+    with torch.no_grad():
+        a = head(feat, metas, rj)["all_coords_preds"].clone()
+        b = head(feat, metas, rj)["all_coords_preds"].clone()            # replayed graph
+        head.set_option("graphs", 0)
+        c = head(feat, metas, rj)["all_coords_preds"].clone()            # plain launches
+    assert torch.equal(a, b) and torch.equal(a, c)
+    ref = torch.from_numpy(z["all_coords_preds"])
+    # hot weights: the neighbour sets decide.  Every query whose first-k set differs from the reference's is a near-tie at rank k
+    # of the reference's own distances (fp32 round-off), and there are few of them; the mesh stays within 1e-2 mm.
+    eng = head._engine
+    eng.enable_taps(True)
+    with torch.no_grad():
+        head(feat, metas, rj)
+    B, Q = len(spec["views"]), 799
+    pt_xyz = eng.tap("pt_xyz", (B, spec["nsample"], 3)).cpu()
+    for blk in (1, 2):
+        xyz = torch.from_numpy(z[f"tap.b{blk - 1}.xyz"])
+        for which, k in (("self", spec["knn_query"]), ("cross", spec["knn"])):
+            want = torch.from_numpy(z[f"tap.b{blk}.idx_{which}"].astype(np.int64))
+            assert want.shape == (B, Q, k)
+            got = eng.tap(f"b{blk}.idx_{which}", (B, Q, 32), torch.int32).cpu().long()[..., :k]
+            same = (torch.sort(got, dim=-1).values == torch.sort(want, dim=-1).values).all(-1)
+            assert float(same.float().mean()) > 0.995, (blk, which)
+            for bb, q in torch.nonzero(~same).tolist():
+                src = xyz if which == "self" else pt_xyz
+                d = xyz[bb, q][None] - src[bb]
+                d = d * d
+                sd = torch.sort((d[:, 0] + d[:, 1]) + d[:, 2]).values
+                assert float((sd[k] - sd[k - 1]) / sd[k - 1]) < 1e-5, (blk, which, bb, q)
+    mpvpe = torch.norm(a.cpu()[-1, :, 21:] - ref[-1, :, 21:], dim=-1).mean(dim=1)
+    assert float(mpvpe.max()) < 1e-5, mpvpe
+    eng.enable_taps(False)
+    full = build_hip_head(dict(spec, knn=32, knn_query=32), DEV)
+    with torch.no_grad():
+        d = full(feat, metas, rj)["all_coords_preds"]
+    assert _md(d.cpu(), ref) > 1e-3
+    head2 = build_hip_head(spec, DEV)
+    with pytest.raises(RuntimeError):
+        head2.set_precision("split_f16x3")            # (no engine yet: refused when the first forward creates it)
+        with torch.no_grad():
+            head2(feat, metas, rj)
+    with pytest.raises(RuntimeError):
+        head.set_precision("split_f16x3")             # a live engine refuses at once

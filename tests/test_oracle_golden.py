@@ -11,7 +11,7 @@ def _maxdiff(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
 
 
-@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinypetr", "tinynonorm", "tinypetrlid"])
+@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinypetr", "tinynonorm", "tinypetrlid", "tinyk"])
 def test_tiny_stage_taps(name):
     z, meta = load_golden(name)
     cfg, w, consts, batch = case_setup(meta["spec"])
@@ -33,7 +33,7 @@ def test_tiny_stage_taps(name):
         assert _maxdiff(out["pred_shape"], z["pred_shape"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano", "mediumpetr"])
+@pytest.mark.parametrize("name", ["small", "medium", "large", "huge", "ragged", "mediummano", "mediumpetr", "smallk", "mediumk"])
 def test_release_shapes(name):
     z, meta = load_golden(name)
     cfg, w, consts, batch = case_setup(meta["spec"])
@@ -352,7 +352,7 @@ def test_split_precision_arithmetic_emulated_in_the_oracle():
 
 
 @pytest.mark.skipif(not __import__("os").path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
-@pytest.mark.parametrize("name", ["tiny", "tinymano"])
+@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinyk"])
 def test_committed_fixture_is_what_the_generator_writes_today(name, tmp_path):
     """`tests/golden/make_golden.py <case>` run against /root/reference reproduces the committed fixture: the same keys and
     bit-identical arrays (round 5's tiny.npz had fallen behind its generator by four index taps).  The two full-tap cases run
@@ -444,3 +444,22 @@ def test_neighbour_search_against_an_independent_kd_tree(NQ, NS, seed):
                         assert set(got[b, i, lo:k + 1]) == set(i64[i, lo:k + 1])
                     lo = k + 1
     assert strict > 0.95 * 2 * NQ * 32          # nearly every position is decided by a clear gap
+
+
+def test_neighbour_count_fixtures_depend_on_the_counts():
+    """`tinyk` / `smallk` / `mediumk` (N_NEIGHBOR / N_NEIGHBOR_QUERY = 16 / 8, 20 / 12, 16 / 24; the reference head's own outputs)
+    really exercise the two keys: the fixtures hold neighbour taps of exactly those widths, and on the hot-weight case the oracle
+    with the release value 32 -- or with the two keys swapped -- lands millimetres away (6e-8 m with the right ones)."""
+    import dataclasses
+    for name, counts in (("tinyk", (16, 8)), ("smallk", (20, 12)), ("mediumk", (16, 24))):
+        z, meta = load_golden(name)
+        assert (meta["spec"]["knn"], meta["spec"]["knn_query"]) == counts
+        for b in (1, 2):
+            assert z[f"tap.b{b}.idx_cross"].shape[-1] == counts[0] and z[f"tap.b{b}.idx_self"].shape[-1] == counts[1]
+    z, meta = load_golden("smallk")
+    cfg, w, consts, batch = case_setup(meta["spec"])
+    assert (cfg.knn, cfg.knn_query) == (20, 12)
+    ref = z["all_coords_preds"]
+    assert _maxdiff(run_oracle(cfg, w, consts, batch)["all_coords_preds"], ref) < 2e-6
+    for other in (dataclasses.replace(cfg, knn=32, knn_query=0), dataclasses.replace(cfg, knn=12, knn_query=20)):
+        assert _maxdiff(run_oracle(other, w, consts, batch)["all_coords_preds"], ref) > 1e-3
