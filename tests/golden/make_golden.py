@@ -94,6 +94,12 @@ CASES = {
                    ln_spread=0.3, knn=20, knn_query=12),
     "mediumk": dict(model="medium", embed=256, nsample=4096, views=[4, 2], seed=43, parametric=False, full=False, knn=16,
                     knn_query=24),
+    # ... and the remaining TRANSFORMER keys away from the release values: N_BLOCKS 2 / 4, NUM_ATTENTION_HEADS 2 / 8 (with the
+    # neighbour counts, NORMALIZE and the parametric tail mixed in), full stage taps
+    "tinycfg2": dict(model="medium", embed=64, nsample=1024, views=[1, 4], seed=51, parametric=False, full=True, heads=2, nblocks=2,
+                     knn=9, knn_query=5, pe_normalize=False),
+    "tinycfg4": dict(model="medium_MANO", embed=64, nsample=1024, views=[3, 2], seed=52, parametric=True, full=True, heads=8, nblocks=4,
+                     knn=15, knn_query=21),
 }
 
 
@@ -145,6 +151,8 @@ def run_reference(spec):
     cfg["TRANSFORMER"]["PARAMETRIC_OUTPUT"] = spec["parametric"]
     cfg["POSITIONAL_ENCODING"]["NUM_FEATS"] = C // 2
     cfg["POSITIONAL_ENCODING"]["NORMALIZE"] = bool(spec.get("pe_normalize", True))
+    cfg["TRANSFORMER"]["N_BLOCKS"] = spec.get("nblocks", 3)
+    cfg["TRANSFORMER"]["NUM_ATTENTION_HEADS"] = spec.get("heads", 4)
     cfg["TRANSFORMER"]["N_NEIGHBOR"] = spec.get("knn", 32)
     cfg["TRANSFORMER"]["N_NEIGHBOR_QUERY"] = spec.get("knn_query") or spec.get("knn", 32)
     if spec.get("petr"):
@@ -160,7 +168,8 @@ def run_reference(spec):
         head = build_head(cfg, data_preset=CN(y["DATA_PRESET"]))
         head.eval()
         sd = pk.weights.seeded_state_dict(C, seed=spec["seed"], parametric=spec["parametric"], gain=spec.get("gain", 1.0),
-                                          ln_spread=spec.get("ln_spread", 0.02), **petr_kwargs(spec))
+                                          ln_spread=spec.get("ln_spread", 0.02), **petr_kwargs(spec),
+                                          **({"nblocks": spec["nblocks"]} if "nblocks" in spec else {}))
         ref_sd = head.state_dict()
         for k, v in sd.items():
             assert k in ref_sd and tuple(ref_sd[k].shape) == tuple(v.shape), f"key/shape mismatch: {k}"
@@ -215,7 +224,7 @@ def run_reference(spec):
             out = head(batch["mlvl_feat"], batch["img_metas"], batch["reference_joints"])
         H.F.grid_sample = orig_gs
         PT.knn_points = orig_knn
-        assert len(knn_calls) == 4, len(knn_calls)
+        assert len(knn_calls) == 2 * (spec.get("nblocks", 3) - 1), len(knn_calls)
         for n, t in enumerate(knn_calls):
             taps[f"b{1 + n // 2}.idx_{'self' if n % 2 == 0 else 'cross'}"] = t.to(torch.int16)
         for h in hooks:

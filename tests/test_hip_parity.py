@@ -404,7 +404,7 @@ def test_frustum_features_match_the_oracle(lid, depth_num, fh, fw, img):
     assert float(((got.abs() > clamp - 1e-3) != edge).float().mean()) < 1e-4
 
 
-@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinypetr", "tinynonorm", "tinypetrlid", "tinyk"])
+@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinypetr", "tinynonorm", "tinypetrlid", "tinyk", "tinycfg2", "tinycfg4"])
 def test_head_tiny_stage_taps_vs_golden(name):
     z, meta = load_golden(name)
     spec = meta["spec"]
@@ -421,7 +421,7 @@ def test_head_tiny_stage_taps_vs_golden(name):
     assert _md(eng.tap("bps_feat", (B, S, C)), torch.from_numpy(z["tap.bps_feat"])) < 1e-4
     assert _md(eng.tap("pt_xyz", (B, S, 3)), torch.from_numpy(z["tap.pt_xyz"])) == 0.0
     assert _md(eng.tap("query_xyz", (B, Q, 3)), torch.from_numpy(z["tap.query_xyz"])) == 0.0
-    for i in range(3):
+    for i in range(spec.get("nblocks", 3)):
         for k, tol in (("h_cross", 5e-5), ("f_self", 5e-5), ("f_cross", 5e-5), ("feats", 1e-4)):
             assert _md(eng.tap(f"b{i}.{k}", (B, Q, C))[:, ::9], torch.from_numpy(z[f"tap.b{i}.{k}"])) < tol, (i, k)
         assert _md(eng.tap(f"b{i}.xyz", (B, Q, 3)), torch.from_numpy(z[f"tap.b{i}.xyz"])) < 5e-5, i
@@ -1629,3 +1629,40 @@ def test_neighbour_counts_below_32_are_part_of_the_handle_and_split_precision_re
             head2(feat, metas, rj)
     with pytest.raises(RuntimeError):
         head.set_precision("split_f16x3")             # a live engine refuses at once
+
+
+def _random_constructor_specs(n, seed=2026):
+    """Seeded draws over the constructor keys the path reads (widths with their legal head counts, block counts, both neighbour
+    counts, basis-point counts (the anchor ids of the shipped asset reach 765: at least 1024), NORMALIZE, the parametric tail) and ragged view layouts."""
+    g = np.random.default_rng(seed)
+    specs = []
+    for i in range(n):
+        C = int(g.choice([32, 64, 128]))
+        heads = int(g.choice([h for h in (1, 2, 4, 8, 16) if C % h == 0 and C // h in (8, 16, 32, 64)]))
+        B = int(g.integers(1, 4))
+        specs.append(dict(embed=C, heads=heads, nblocks=int(g.integers(1, 5)), nsample=int(g.choice([1024, 2048])),
+                          knn=int(g.integers(1, 33)), knn_query=int(g.integers(1, 33)), views=[int(v) for v in g.integers(1, 5, size=B)],
+                          seed=100 + i, parametric=bool(g.integers(0, 4) == 0), pe_normalize=bool(g.integers(0, 2))))
+    return specs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", _random_constructor_specs(12), ids=lambda s: "C{embed}h{heads}b{nblocks}S{nsample}k{knn}q{knn_query}".format(**s))
+def test_random_constructor_configs_vs_oracle(spec):
+    """Whole path at constructor settings no fixture holds (1-4 decoder blocks, 1-16 heads of 8-64 channels, neighbour counts 1-32,
+    1024 / 2048 basis points, ragged 1-4 views): HIP head vs the oracle on the same seeded weights and inputs, every layer."""
+    cfg, w, consts, batch = case_setup(spec)
+    assert (cfg.heads, cfg.nblocks, cfg.knn, cfg.knn_query) == (spec["heads"], spec["nblocks"], spec["knn"], spec["knn_query"])
+    head = build_hip_head(spec, DEV)
+    feat, metas, rj = batch_to(batch, DEV)
+    with torch.no_grad():
+        res = head(feat, metas, rj)
+        again = head(feat, metas, rj)["all_coords_preds"]                 # replayed graph
+    orc = run_oracle(cfg, w, consts, batch)
+    got = res["all_coords_preds"].cpu()
+    assert got.shape == orc["all_coords_preds"].shape == (spec["nblocks"], len(spec["views"]), 799, 3)
+    assert torch.equal(res["all_coords_preds"], again)
+    assert _md(got, orc["all_coords_preds"]) < 5e-6                                                   # metres
+    if spec["parametric"]:
+        assert _md(res["pred_pose"], orc["pred_pose"]) < 2e-4
+        assert _md(res["pred_shape"], orc["pred_shape"]) < 2e-5

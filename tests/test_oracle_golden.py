@@ -11,7 +11,7 @@ def _maxdiff(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
 
 
-@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinypetr", "tinynonorm", "tinypetrlid", "tinyk"])
+@pytest.mark.parametrize("name", ["tiny", "tinymano", "tinypetr", "tinynonorm", "tinypetrlid", "tinyk", "tinycfg2", "tinycfg4"])
 def test_tiny_stage_taps(name):
     z, meta = load_golden(name)
     cfg, w, consts, batch = case_setup(meta["spec"])
@@ -23,7 +23,8 @@ def test_tiny_stage_taps(name):
     assert _maxdiff(taps["bps_feat"], z["tap.bps_feat"]) < 5e-5        # Q1 + merge (sv and mv)
     assert _maxdiff(taps["pt_xyz"], z["tap.pt_xyz"]) == 0.0
     assert _maxdiff(taps["query_xyz"], z["tap.query_xyz"]) == 0.0
-    for i in range(3):
+    assert out["all_coords_preds"].shape[0] == meta["spec"].get("nblocks", 3)
+    for i in range(meta["spec"].get("nblocks", 3)):
         for k, tol in (("h_cross", 2e-5), ("f_self", 2e-5), ("f_cross", 2e-5), ("feats", 5e-5)):
             assert _maxdiff(taps[f"b{i}.{k}"][:, ::9], z[f"tap.b{i}.{k}"]) < tol, (i, k)
         assert _maxdiff(taps[f"b{i}.xyz"], z[f"tap.b{i}.xyz"]) < 2e-5, i

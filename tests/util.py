@@ -29,12 +29,14 @@ def oracle_consts(nsample=4096):
 
 def seeded_weights(spec):
     extra = dict(petr=True, depth_num=spec.get("depth_num", 32)) if spec.get("petr") else {}
+    if "nblocks" in spec:
+        extra["nblocks"] = spec["nblocks"]
     return pk.weights.seeded_state_dict(spec["embed"], seed=spec["seed"], parametric=spec["parametric"],
                                         gain=spec.get("gain", 1.0), ln_spread=spec.get("ln_spread", 0.02), **extra)
 
 
 PE_SPEC_KEYS = ("pe_normalize", "petr", "depth_num", "lid", "depth_start", "depth_end", "position_range",      # round 5
-                "knn", "knn_query")                                                                              # round 6
+                "knn", "knn_query", "heads", "nblocks")                                                         # round 6
 
 
 def case_setup(spec):
@@ -109,6 +111,8 @@ def build_hip_head(spec, device="cuda:0"):
     hc = head_cfg(spec["embed"], spec["nsample"], spec["parametric"])
     hc["POSITIONAL_ENCODING"]["NORMALIZE"] = bool(spec.get("pe_normalize", True))
     hc["PETR_EMBEDDING"] = bool(spec.get("petr", False))
+    hc["TRANSFORMER"]["N_BLOCKS"] = spec.get("nblocks", 3)
+    hc["TRANSFORMER"]["NUM_ATTENTION_HEADS"] = spec.get("heads", 4)
     hc["TRANSFORMER"]["N_NEIGHBOR"] = spec.get("knn", 32)
     hc["TRANSFORMER"]["N_NEIGHBOR_QUERY"] = spec.get("knn_query") or spec.get("knn", 32)
     for key, name in (("DEPTH_NUM", "depth_num"), ("LID", "lid"), ("DEPTH_START", "depth_start"), ("DEPTH_END", "depth_end"),
