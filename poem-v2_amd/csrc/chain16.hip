@@ -273,7 +273,7 @@ __device__ __forceinline__ void gemm16_ring(const WSrc& cur, const WSrc& nxt, co
 
 // MAXRU: largest tile in units (4 = 64 rows; 2 at C = 512, where two activation tiles of kind D2 must fit 160 KB of LDS)
 template <int C, int NW, int KIND, int MAXRU>
-__global__ __launch_bounds__(NW * 64, KIND == 3 ? NW / 4 : NW / 2) void chain16_kernel(ChainArgs A, int ncu, int layers) {
+__global__ __launch_bounds__(NW * 64, (KIND == 3 || (C == 512 && MAXRU == 4)) ? NW / 4 : NW / 2) void chain16_kernel(ChainArgs A, int ncu, int layers) {
   constexpr int XSP = 16 * MAXRU + 4, XROWS = 16 * MAXRU, T16 = C / 16 / NW, KCH = C / 8, NT = NW * 64, NTILE = C / 32;
   static_assert((C / 16) % NW == 0 && T16 % 2 == 0, "waves must divide the 32-channel tiles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -704,7 +704,17 @@ extern "C" hipError_t poem_launch_chain16(const ChainArgs* a, int C, hipStream_t
   switch (C) {
     case 128: return launch_chain16_t<128, 4, 4>(*a, cus, s);
     case 256: return launch_chain16_t<256, 8, 4>(*a, cus, s);
-    case 512: return launch_chain16_t<512, 8, 2>(*a, cus, s);
+    case 512:
+#ifdef POEM_C16_STAMPS   // tools/lab only: one tile of up to 4 units per CU for kinds A / C / D1 (139 KB of LDS; the weights cross the L2 once per CU)
+      if (getenv("POEM_C16_RU512") && a->kind != 3) {
+        switch (a->kind) {
+          case 0: return launch_chain16_k<512, 8, 0, 4>(*a, cus, s);
+          case 1: return launch_chain16_k<512, 8, 1, 4>(*a, cus, s);
+          default: return launch_chain16_k<512, 8, 2, 4>(*a, cus, s);
+        }
+      }
+#endif
+      return launch_chain16_t<512, 8, 2>(*a, cus, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -33,7 +33,7 @@ static const float4* rnd_w(size_t n, unsigned seed) {
 }
 
 int main(int argc, char** argv) {
-  const int B = argc > 1 ? atoi(argv[1]) : 2, C = 256, M = 799 * B;
+  const int B = argc > 1 ? atoi(argv[1]) : 2, C = getenv("C16_LAB_C") ? atoi(getenv("C16_LAB_C")) : 256, M = 799 * B;
   const size_t MC = (size_t)M * C;
   ChainArgs a{};
   a.M = M; a.tile_p = 3; a.eps = 1e-12f;
